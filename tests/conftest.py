@@ -1,0 +1,38 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+GOLD = os.path.join(HERE, "golden")
+
+
+def load_filter(name):
+    return np.load(os.path.join(GOLD, "filters", name + ".npy"))
+
+
+@pytest.fixture(scope="session")
+def pilotcut():
+    return load_filter("jj1bdx_48khz_fmaudio")
+
+
+@pytest.fixture(scope="session")
+def fm_medium():
+    return load_filter("jj1bdx_fm_384kHz_medium")
+
+
+@pytest.fixture(scope="session")
+def am_narrow():
+    return load_filter("jj1bdx_am_48khz_narrow")

@@ -1,0 +1,91 @@
+"""Property tests of the oracle chain IfResampler -> FmDecoder / AmDecoder on the
+synthetic configs of BASELINE.json.  CPU only."""
+import numpy as np
+import pytest
+
+import oracle_py as ora
+import siggen
+
+DELAY3 = np.array([0.0, 1.0, 0.0], dtype=np.float32)
+
+
+def _tone_amp(x, fs, f):
+    n = len(x)
+    t = np.arange(n) / fs
+    w = np.hanning(n)
+    return 2 * abs(np.sum(x * w * np.exp(-2j * np.pi * f * t))) / np.sum(w)
+
+
+@pytest.fixture(scope="module")
+def fm_stereo_run(pilotcut):
+    fs = 10e6
+    nblk = 130  # 0.85 s: lock needs 0.5 s
+    x = siggen.fm_stereo_iq(nblk * 65536, fs)
+    ifr = ora.IfResampler(fs, 384e3)
+    fm = ora.FmDecoder(False, DELAY3, True, 50.0, False, 0, pilotcut)
+    audio, locked_at = [], None
+    for i, b in enumerate(siggen.blocks(x, 65536)):
+        a = fm.process(ifr.process(b))
+        audio.append(a)
+        if fm.stereo_detected() and locked_at is None:
+            locked_at = i
+    return fm, np.concatenate(audio), locked_at
+
+
+def test_fm_stereo_decode_config2(fm_stereo_run):
+    fm, audio, locked_at = fm_stereo_run
+    assert locked_at is not None and 70 <= locked_at <= 80  # ~0.5 s of 2517-sample blocks
+    assert fm.get_pilot_level() == pytest.approx(0.1, rel=0.02)
+    assert fm.get_if_rms() == pytest.approx(0.3, rel=0.01)
+    assert abs(fm.get_tuning_offset()) < 200.0
+    left, right = audio[0::2], audio[1::2]
+    tail = slice(len(left) - 9600, len(left))  # last 0.2 s, after lock
+    de1k = 1 / np.sqrt(1 + (2 * np.pi * 1000 * 50e-6) ** 2)
+    de400 = 1 / np.sqrt(1 + (2 * np.pi * 400 * 50e-6) ** 2)
+    aL = _tone_amp(left[tail], 48000.0, 1000.0)
+    aR = _tone_amp(right[tail], 48000.0, 400.0)
+    assert aL == pytest.approx(0.9 * de1k, rel=0.03)
+    assert aR == pytest.approx(0.9 * de400, rel=0.03)
+    # channel separation better than 30 dB
+    assert _tone_amp(left[tail], 48000.0, 400.0) < 0.03 * aR
+    assert _tone_amp(right[tail], 48000.0, 1000.0) < 0.03 * aL
+    # 19 kHz pilot is removed by the pilot-cut FIR
+    assert _tone_amp(left[tail], 48000.0, 19000.0) < 1e-4
+
+
+def test_fm_mono_config1(pilotcut):
+    fs = 1e6
+    x = siggen.fm_mono_iq(300 * 2048, fs)
+    ifr = ora.IfResampler(fs, 384e3)
+    fm = ora.FmDecoder(False, DELAY3, False, 50.0, False, 0, pilotcut)
+    audio = np.concatenate([fm.process(ifr.process(b)) for b in siggen.blocks(x, 2048)])
+    assert abs(len(audio) - len(x) * 0.048) < 64
+    tail = audio[-9600:]
+    de1k = 1 / np.sqrt(1 + (2 * np.pi * 1000 * 50e-6) ** 2)
+    assert _tone_amp(tail, 48000.0, 1000.0) == pytest.approx(50.0 / 75.0 * de1k, rel=0.01)
+
+
+def test_am_config3(am_narrow):
+    fs = 384e3
+    x = siggen.am_iq(400 * 2048, fs)
+    ifr = ora.IfResampler(fs, 48e3)
+    am = ora.AmDecoder(am_narrow, ora.MODE_AM)
+    audio = np.concatenate([am.process(ifr.process(b)) for b in siggen.blocks(x, 2048)])
+    assert abs(len(audio) - len(x) / 8) < 64
+    tail = audio[-9600:]
+    assert _tone_amp(tail, 48000.0, 1000.0) > 0.1
+    assert am.get_if_agc_current_gain() == pytest.approx(9.4, rel=0.05)
+
+
+def test_block_partition_changes_result_only_at_head_quirk_level(pilotcut):
+    """Hazard H1/H4: the decoder output depends on the block partition, but only
+    at the |c[0]| ~ 1e-6 level of the FIR head quirk (before lock)."""
+    fs = 384e3
+    x = siggen.fm_stereo_iq(40 * 2048, fs)
+    outs = []
+    for blk in (2048, 4096):
+        fm = ora.FmDecoder(False, DELAY3, True, 50.0, False, 0, pilotcut)
+        outs.append(np.concatenate([fm.process(b) for b in siggen.blocks(x, blk)]))
+    n = min(len(outs[0]), len(outs[1]))
+    d = outs[0][:n] - outs[1][:n]
+    assert 0 < np.max(np.abs(d)) < 1e-5

@@ -1,0 +1,94 @@
+"""Specification tests of the resampler stand-in (oracle side).
+
+r8brain-free-src is absent from the reference tree, so the two resamplers are
+"parity unpinned" (SURVEY.md 8c); they are accepted on these specification
+tests: rate law, unity DC gain, pass-band flatness, stop-band rejection,
+latency-compensated linear phase, chunking independence."""
+import numpy as np
+import pytest
+
+import oracle_py as ora
+
+
+def _run(rs, x, blk):
+    out = [rs.process(x[i:i + blk]) for i in range(0, len(x), blk)]
+    return np.concatenate(out), [len(o) for o in out]
+
+
+@pytest.mark.parametrize("fin,fout,att", [(10e6, 384e3, 140.0), (1e6, 384e3, 140.0), (384e3, 48e3, 180.0)])
+def test_design_and_rate_law(fin, fout, att):
+    rs = ora.Resampler(fin, fout, att)
+    info = rs.info()
+    assert info["L"] * fin == info["M"] * fout
+    assert info["LB"] * (fin / info["D"]) == info["MB"] * fout
+    n = 200000
+    x = np.ones(n)
+    y, counts = _run(rs, x, 65536 if fin > 2e6 else 2048)
+    # output-count law: about n*L/M minus the look-ahead still pending
+    expect = n * fout / fin
+    assert expect - (info["NA"] / info["D"] + info["TB"]) * fout / (fin / info["D"]) - 2 <= len(y) <= expect + 1
+    # unity DC gain once the start-up transient has passed
+    assert np.max(np.abs(y[200:] - 1.0)) < 1e-6
+
+
+def test_if_block_counts_10M():
+    rs = ora.Resampler(10e6, 384e3, 140.0)
+    x = np.zeros(65536)
+    counts = [len(rs.process(x)) for _ in range(40)]
+    assert set(counts[1:]) == {2516, 2517}
+    assert abs(np.mean(counts[1:]) - 65536 * 0.0384) < 0.05
+
+
+def test_chunking_independence():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(50000)
+    a, _ = _run(ora.Resampler(1e6, 384e3, 140.0), x, 50000)
+    b, _ = _run(ora.Resampler(1e6, 384e3, 140.0), x, 777)
+    np.testing.assert_array_equal(a, b[:len(a)])
+    assert len(b) == len(a)
+
+
+@pytest.mark.parametrize("fin,fout,att", [(10e6, 384e3, 140.0), (384e3, 48e3, 180.0)])
+def test_passband_tone_amplitude_and_alignment(fin, fout, att):
+    """A pass-band tone comes out with unit gain and zero delay (output k sits at
+    input time k*M/L): latency-compensated linear phase."""
+    f0 = 0.8 * 0.885 * fout / 2
+    n = int(fin * 0.02)
+    t = np.arange(n) / fin
+    rs = ora.Resampler(fin, fout, att)
+    y = rs.process(np.cos(2 * np.pi * f0 * t))
+    k = np.arange(len(y))
+    ref = np.cos(2 * np.pi * f0 * k / fout)
+    s = 400
+    assert np.max(np.abs(y[s:] - ref[s:])) < 2e-6
+
+
+@pytest.mark.parametrize("fin,fout,att,floor_db", [(10e6, 384e3, 140.0, -135.0), (384e3, 48e3, 180.0, -170.0)])
+def test_stopband_rejection(fin, fout, att, floor_db):
+    """Tones that would alias into the protected band are rejected to the design floor."""
+    fpass = 0.885 * fout / 2
+    n = max(int(fin * 0.01), 60000)
+    t = np.arange(n) / fin
+    worst = -400.0
+    for f in (fout - fpass + 1.0, fout + 0.3 * fpass, 2 * fout - 0.5 * fpass, fin / 2 * 0.9):
+        if f >= fin / 2:
+            continue
+        rs = ora.Resampler(fin, fout, att)
+        y = rs.process(np.cos(2 * np.pi * f * t))
+        y = y[500:]
+        # measure only what lands inside the protected band |f| <= fpass
+        spec = np.fft.rfft(y * np.blackman(len(y))) / (np.sum(np.blackman(len(y))) / 2)
+        freqs = np.fft.rfftfreq(len(y), 1 / fout)
+        lvl = 20 * np.log10(np.max(np.abs(spec[freqs <= fpass])) + 1e-300)
+        worst = max(worst, lvl)
+    assert worst < floor_db
+
+
+def test_if_resampler_complex_lockstep():
+    import siggen
+    x = siggen.fm_stereo_iq(3 * 65536, 10e6)
+    r = ora.IfResampler(10e6, 384e3)
+    y = np.concatenate([r.process(b) for b in siggen.blocks(x, 65536)])
+    assert y.dtype == np.complex64
+    # FM signal keeps its constant envelope (0.3) through the front end
+    assert np.abs(np.abs(y[300:]).mean() - 0.3) < 1e-3
