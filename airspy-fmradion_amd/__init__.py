@@ -1,0 +1,250 @@
+"""airspy-fmradion_amd -- MI355X-native FM/AM demodulation hot path.
+
+Python-side binding of the C-ABI (include/fmradion_amd.h) used by the tests
+and by bench.py.  The product is libfmradion_amd.so (hand-written HIP kernels,
+csrc/); this module only loads it with ctypes.  There is no CPU fallback: if
+the library is missing or no GPU is present, creation fails loudly.
+
+The directory name carries a hyphen (the contract's package name), so import it
+with importlib:  fmr = importlib.import_module("airspy-fmradion_amd").
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libfmradion_amd.so")
+SRC = os.path.join(_DIR, "csrc", "fmradion_amd.hip")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+MODE_NONE, MODE_FM, MODE_AM, MODE_DSB = -1, 0, 2, 3
+OK = 0
+
+EXPORTS = [
+    "fmr_create", "fmr_destroy", "fmr_last_error", "fmr_version", "fmr_resampler_info", "fmr_process",
+    "fmr_process_blocks", "fmr_process_blocks_device", "fmr_synchronize", "fmr_resample", "fmr_get_status",
+    "fmr_get_pps_events", "fmr_get_multipath_coefficients", "fmr_debug_read", "fmr_get_kernel_times",
+    "fmr_enable_kernel_timing", "fmr_filter_table",
+]
+
+
+class FmrError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int), ("n_streams", C.c_int), ("mode", C.c_int), ("input_rate", C.c_double),
+        ("enable_resampler", C.c_int), ("enable_fourth_down", C.c_int), ("fmfilter_enable", C.c_int),
+        ("filter_coeff", C.POINTER(C.c_float)), ("n_filter_coeff", C.c_int), ("stereo", C.c_int),
+        ("deemphasis_us", C.c_double), ("pilot_shift", C.c_int), ("multipath_stages", C.c_uint),
+        ("max_block_len", C.c_size_t), ("max_blocks", C.c_int),
+    ]
+
+
+class Status(C.Structure):
+    _fields_ = [
+        ("if_rms", C.c_float), ("baseband_mean", C.c_float), ("baseband_level", C.c_float),
+        ("pilot_level", C.c_double), ("stereo_detected", C.c_int), ("if_agc_gain", C.c_float),
+        ("af_agc_gain", C.c_double), ("multipath_error", C.c_double), ("pll_freq_err", C.c_double),
+        ("multipath_resets", C.c_uint32),
+    ]
+
+
+class PpsEvent(C.Structure):
+    _fields_ = [("pps_index", C.c_uint64), ("sample_index", C.c_uint64), ("block_position", C.c_double),
+                ("block", C.c_uint32), ("stream", C.c_uint32)]
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    deps = [SRC] + [os.path.join(_DIR, "csrc", f) for f in ("kernels.hpp", "design.hpp", "filter_tables.inc")]
+    deps.append(os.path.join(os.path.dirname(_DIR), "include", "fmradion_amd.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FmrError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32p, fp, dp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_double)
+    L.fmr_create.restype = C.c_int
+    L.fmr_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.fmr_destroy.restype = None
+    L.fmr_destroy.argtypes = [vp]
+    L.fmr_last_error.restype = C.c_char_p
+    L.fmr_version.restype = C.c_char_p
+    L.fmr_resampler_info.restype = C.c_longlong
+    L.fmr_resampler_info.argtypes = [vp, C.c_int]
+    L.fmr_process.restype = C.c_int
+    L.fmr_process.argtypes = [vp, fp, C.c_size_t, dp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.fmr_process_blocks.restype = C.c_int
+    L.fmr_process_blocks.argtypes = [vp, fp, C.c_size_t, u32p, C.c_int, dp, C.c_size_t, u32p]
+    L.fmr_process_blocks_device.restype = C.c_int
+    L.fmr_process_blocks_device.argtypes = [vp, vp, C.c_size_t, u32p, C.c_int, vp, C.c_size_t, u32p, C.c_int]
+    L.fmr_synchronize.restype = C.c_int
+    L.fmr_synchronize.argtypes = [vp]
+    L.fmr_resample.restype = C.c_int
+    L.fmr_resample.argtypes = [vp, fp, C.c_size_t, fp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.fmr_get_status.restype = C.c_int
+    L.fmr_get_status.argtypes = [vp, C.c_int, C.POINTER(Status)]
+    L.fmr_get_pps_events.restype = C.c_int
+    L.fmr_get_pps_events.argtypes = [vp, C.c_int, C.POINTER(PpsEvent), C.c_int]
+    L.fmr_get_multipath_coefficients.restype = C.c_int
+    L.fmr_get_multipath_coefficients.argtypes = [vp, C.c_int, fp, C.c_int]
+    L.fmr_debug_read.restype = C.c_longlong
+    L.fmr_debug_read.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+    L.fmr_get_kernel_times.restype = C.c_int
+    L.fmr_get_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), fp, C.c_int]
+    L.fmr_enable_kernel_timing.restype = None
+    L.fmr_enable_kernel_timing.argtypes = [vp, C.c_int]
+    L.fmr_filter_table.restype = C.c_int
+    L.fmr_filter_table.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def filter_table(name):
+    """FilterParameters::<name> (include/FilterParameters.h:31-49) as a numpy array."""
+    p, dbl = C.c_void_p(), C.c_int()
+    n = lib().fmr_filter_table(name.encode(), C.byref(p), C.byref(dbl))
+    if n < 0:
+        raise FmrError(f"unknown filter table {name}")
+    ct = C.c_double if dbl.value else C.c_float
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).copy()
+
+
+DELAY_3TAPS = np.array([0.0, 1.0, 0.0], dtype=np.float32)  # FilterParameters::delay_3taps_only_iq
+
+
+class Chain:
+    """One decoder chain (fmr_chain) for n_streams independent IQ streams."""
+
+    def __init__(self, mode=MODE_FM, input_rate=384000.0, enable_resampler=False, fourth_down=False,
+                 fmfilter_enable=False, filter_coeff=None, stereo=True, deemphasis_us=50.0, pilot_shift=False,
+                 multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0):
+        coeff = np.ascontiguousarray(DELAY_3TAPS if filter_coeff is None else filter_coeff, dtype=np.float32)
+        self._coeff = coeff
+        cfg = Config()
+        cfg.device, cfg.n_streams, cfg.mode, cfg.input_rate = device, n_streams, mode, float(input_rate)
+        cfg.enable_resampler, cfg.enable_fourth_down = int(enable_resampler), int(fourth_down)
+        cfg.fmfilter_enable = int(fmfilter_enable)
+        cfg.filter_coeff = coeff.ctypes.data_as(C.POINTER(C.c_float))
+        cfg.n_filter_coeff = len(coeff)
+        cfg.stereo, cfg.deemphasis_us, cfg.pilot_shift = int(stereo), float(deemphasis_us), int(pilot_shift)
+        cfg.multipath_stages = int(multipath_stages)
+        cfg.max_block_len, cfg.max_blocks = int(max_block_len), int(max_blocks)
+        self.n_streams, self.mode, self.stereo = n_streams, mode, bool(stereo) and mode == MODE_FM
+        self.h = C.c_void_p()
+        rc = lib().fmr_create(C.byref(cfg), C.byref(self.h))
+        if rc != OK:
+            self.h = None
+            raise FmrError(f"fmr_create failed ({rc}): {lib().fmr_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fmr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise FmrError(f"fmradion_amd error {rc}: {lib().fmr_last_error().decode()}")
+        return rc
+
+    def resampler_info(self):
+        return {k: lib().fmr_resampler_info(self.h, i) for i, k in enumerate(["D", "NA", "LB", "MB", "TB"])}
+
+    # --- host-buffer API ---------------------------------------------------------
+    def process(self, iq):
+        """FmDecoder::process / AmDecoder::process shape: one block in, audio doubles out."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        out = np.empty(2 * (len(iq) + 64), dtype=np.float64)
+        n = C.c_size_t()
+        self._chk(lib().fmr_process(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), len(iq),
+                                    out.ctypes.data_as(C.POINTER(C.c_double)), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def process_blocks(self, iq, block_len):
+        """iq: (n_streams, N) complex64; block_len: consecutive block lengths. Returns (audio[S][total], audio_len)."""
+        iq = np.ascontiguousarray(np.atleast_2d(iq), dtype=np.complex64)
+        assert iq.shape[0] == self.n_streams
+        bl = np.ascontiguousarray(block_len, dtype=np.uint32)
+        assert int(bl.sum()) <= iq.shape[1]
+        acap = 2 * (int(bl.sum()) + 64 * len(bl))
+        audio = np.zeros((self.n_streams, acap), dtype=np.float64)
+        alen = np.zeros(len(bl), dtype=np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        self._chk(lib().fmr_process_blocks(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), iq.shape[1],
+                                           bl.ctypes.data_as(u32p), len(bl),
+                                           audio.ctypes.data_as(C.POINTER(C.c_double)), acap,
+                                           alen.ctypes.data_as(u32p)))
+        return audio[:, :int(alen.sum())].copy(), alen
+
+    def resample(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        out = np.empty(len(iq) + 64, dtype=np.complex64)
+        n = C.c_size_t()
+        self._chk(lib().fmr_resample(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), len(iq),
+                                     out.ctypes.data_as(C.POINTER(C.c_float)), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    # --- device-buffer API (pointers are raw device addresses, e.g. torch .data_ptr()) -------------
+    def process_blocks_device(self, d_iq_ptr, stream_stride, block_len, d_audio_ptr, audio_stride, sync=False):
+        bl = np.ascontiguousarray(block_len, dtype=np.uint32)
+        alen = np.zeros(len(bl), dtype=np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        self._chk(lib().fmr_process_blocks_device(self.h, C.c_void_p(d_iq_ptr), stream_stride,
+                                                  bl.ctypes.data_as(u32p), len(bl), C.c_void_p(d_audio_ptr),
+                                                  audio_stride, alen.ctypes.data_as(u32p), int(sync)))
+        return alen
+
+    def synchronize(self):
+        self._chk(lib().fmr_synchronize(self.h))
+
+    # --- getters -----------------------------------------------------------------------
+    def status(self, stream=0):
+        st = Status()
+        self._chk(lib().fmr_get_status(self.h, stream, C.byref(st)))
+        return st
+
+    def pps_events(self, stream=0):
+        ev = (PpsEvent * 64)()
+        n = self._chk(lib().fmr_get_pps_events(self.h, stream, ev, 64))
+        return [(e.pps_index, e.sample_index, e.block_position, e.block) for e in ev[:min(n, 64)]]
+
+    def multipath_coefficients(self, stream=0):
+        buf = np.empty(2 * 1300, dtype=np.float32)
+        n = self._chk(lib().fmr_get_multipath_coefficients(self.h, stream, buf.ctypes.data_as(C.POINTER(C.c_float)), len(buf)))
+        return buf[:2 * n].view(np.complex64).copy()
+
+    def debug_read(self, which, stream=0, cap=1 << 24):
+        dt = {0: np.complex64, 1: np.float32, 2: np.float64, 3: np.float64, 4: np.float32}[which]
+        buf = np.empty(cap, dtype=dt)
+        n = self._chk(lib().fmr_debug_read(self.h, stream, which, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+        return buf[:n].copy()
+
+    def enable_kernel_timing(self, on=True):
+        lib().fmr_enable_kernel_timing(self.h, int(on))
+
+    def kernel_times(self):
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        n = self._chk(lib().fmr_get_kernel_times(self.h, names, ms, 64))
+        return [(names[i].decode(), ms[i]) for i in range(min(n, 64))]

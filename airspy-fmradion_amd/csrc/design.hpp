@@ -1,0 +1,178 @@
+// design.hpp -- host-side design arithmetic of the MI355X FM/AM chain.
+//
+// * ResamplerDesign: the product's implementation of the resampler
+//   specification of DESIGN.md ("Resampler specification"): integer
+//   pre-decimation by D (Kaiser FIR, NA taps) followed by an LB/MB polyphase
+//   stage (TB taps per phase).  It replaces r8b::CDSPResampler24 /
+//   r8b::CDSPResampler as used at sfmbase/IfResampler.cpp:26-29 and
+//   sfmbase/AudioResampler.cpp:28-29 (r8brain is absent from the reference
+//   tree: the spec is ours and stated in DESIGN.md).
+// * ResamplerCounter: the deterministic output-count law (how many outputs a
+//   call emits), integer arithmetic only; the host uses it to lay out the
+//   per-block offset tables before any kernel runs.
+// * IIR coefficient formulas of sfmbase/Filter.cpp:186-188 (LowPassFilterRC)
+//   and :254-290 (HighPassFilterIir).
+#pragma once
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace fmr {
+
+inline double bessel_i0(double x) {
+  double sum = 1.0, term = 1.0;
+  const double q = x * x * 0.25;
+  for (int k = 1; k < 1000; k++) {
+    term *= q / (double(k) * double(k));
+    sum += term;
+    if (term < 1e-21 * sum) break;
+  }
+  return sum;
+}
+
+inline double sinc_pi(double x) {
+  if (std::fabs(x) < 1e-12) return 1.0;
+  return std::sin(M_PI * x) / (M_PI * x);
+}
+
+inline long long gcd_ll(long long a, long long b) {
+  while (b) { long long t = a % b; a = b; b = t; }
+  return a < 0 ? -a : a;
+}
+
+struct ResamplerDesign {
+  double in_rate = 0, out_rate = 0, atten = 0;
+  long long L = 1, M = 1;
+  int D = 1, NA = 0;
+  long long LB = 1, MB = 1;
+  int TB = 2;
+  std::vector<double> hA;  // [NA]
+  std::vector<double> hB;  // [LB][TB]
+
+  bool design(double in_r, double out_r, double atten_db) {
+    in_rate = in_r; out_rate = out_r; atten = atten_db;
+    const double A = atten_db;
+    const double beta = 0.1102 * (A - 8.7);
+    const double i0b = bessel_i0(beta);
+    const double fpass = 0.885 * out_rate * 0.5;
+    const double fstop = out_rate - fpass;
+    const long long in_i = llround(in_rate), out_i = llround(out_rate);
+    if (in_i <= 0 || out_i <= 0 || std::fabs(in_rate - in_i) > 1e-6 || std::fabs(out_rate - out_i) > 1e-6) return false;
+    const long long g = gcd_ll(in_i, out_i);
+    L = out_i / g; M = in_i / g;
+    D = (int)std::floor(in_rate / (2.6 * out_rate));
+    if (D < 1) D = 1;
+    const double mid = in_rate / D;
+    hA.clear();
+    NA = 0;
+    if (D > 1) {
+      const double f1 = fpass, f2 = mid - fstop;
+      const double dw = 2.0 * M_PI * (f2 - f1) / in_rate;
+      int N = (int)std::ceil((A - 7.95) / (2.285 * dw)) + 1;
+      if ((N & 1) == 0) N++;
+      NA = N;
+      hA.resize(N);
+      const double fc = 0.5 * (f1 + f2) / in_rate;
+      const double c = 0.5 * (N - 1);
+      double sum = 0;
+      for (int k = 0; k < N; k++) {
+        const double t = k - c, r = t / c;
+        const double w = bessel_i0(beta * std::sqrt(std::fmax(0.0, 1.0 - r * r))) / i0b;
+        hA[k] = 2.0 * fc * sinc_pi(2.0 * fc * t) * w;
+        sum += hA[k];
+      }
+      for (int k = 0; k < N; k++) hA[k] /= sum;
+    }
+    const long long num = L * D, den = M;
+    const long long g2 = gcd_ll(num, den);
+    LB = num / g2; MB = den / g2;
+    const double dw = 2.0 * M_PI * (fstop - fpass) / (double(LB) * mid);
+    const double nproto = (A - 7.95) / (2.285 * dw) + 1.0;
+    int T = (int)std::ceil(nproto / double(LB));
+    if (T & 1) T++;
+    if (T < 2) T = 2;
+    TB = T;
+    if (LB * (long long)T > (1ll << 22)) return false;  // table too large: unsupported ratio
+    hB.resize(size_t(LB) * T);
+    const double W = 0.5 * T;
+    const double fc = 0.5 * out_rate / mid;
+    double sum = 0;
+    for (long long p = 0; p < LB; p++)
+      for (int j = 0; j < T; j++) {
+        const double t = double(p) / double(LB) + W - 1.0 - j, r = t / W;
+        const double w = bessel_i0(beta * std::sqrt(std::fmax(0.0, 1.0 - r * r))) / i0b;
+        const double v = 2.0 * fc * sinc_pi(2.0 * fc * t) * w;
+        hB[size_t(p) * T + j] = v;
+        sum += v;
+      }
+    const double scale = double(LB) / sum;
+    for (auto &v : hB) v *= scale;
+    return true;
+  }
+  int ca() const { return NA ? (NA - 1) / 2 : 0; }
+  int W() const { return TB / 2; }
+};
+
+// Output-count law.  Stage A output m exists once input D*m + ca has arrived;
+// stage B output k once mid sample floor(k*MB/LB) + W has been produced.
+struct ResamplerCounter {
+  long long n_in = 0, mA = 0, kB = 0;
+  void reset() { n_in = mA = kB = 0; }
+  static long long mA_avail(const ResamplerDesign &d, long long n) {
+    if (d.D == 1) return n;
+    const int ca = d.ca();
+    return (n >= ca + 1) ? (n - 1 - ca) / d.D + 1 : 0;
+  }
+  static long long kB_avail(const ResamplerDesign &d, long long mA_) {
+    const int W = d.W();
+    if (mA_ < W + 1) return 0;
+    return ((mA_ - W) * d.LB + d.MB - 1) / d.MB;
+  }
+  // advance by n inputs; returns the number of new outputs
+  long long advance(const ResamplerDesign &d, long long n) {
+    n_in += n;
+    mA = mA_avail(d, n_in);
+    const long long k = kB_avail(d, mA);
+    const long long out = k - kB;
+    kB = k;
+    return out;
+  }
+};
+
+struct Iir1Coef { double b0, b1, a1; };
+struct BiquadCoef { double b0, b1, b2, a1, a2; };
+
+// LowPassFilterRC: sfmbase/Filter.cpp:186-188
+inline Iir1Coef lowpass_rc(double timeconst) {
+  const double a1 = -std::exp(-1 / timeconst);
+  return {1 + a1, 0.0, a1};
+}
+
+// HighPassFilterIir: sfmbase/Filter.cpp:254-290 (matched-Z 2-pole Butterworth)
+inline BiquadCoef highpass_iir(double cutoff) {
+  using C = std::complex<double>;
+  const double w = 2 * M_PI * cutoff;
+  const C p1s = w / std::exp((2 * 1 + 2 - 1) / double(2 * 2) * C(0, M_PI));
+  const C p1z = std::exp(p1s);
+  double b0 = 1, b1 = -2, b2 = 1;
+  const double a1 = -2 * std::real(p1z);
+  const double a2 = std::abs(p1z * p1z);
+  const double g = (b0 - b1 + b2) / (1 - a1 + a2);
+  return {b0 / g, b1 / g, b2 / g, a1, a2};
+}
+
+// fast_atan_table (include/Utility.h:165-217), regenerated: entry i is
+// float("%.6e" % atan(i/255)); entry 256 repeats entry 255.
+inline void make_fast_atan_table(float *tab /*257*/) {
+  char buf[64];
+  for (int i = 0; i < 256; i++) {
+    std::snprintf(buf, sizeof buf, "%.6e", std::atan(double(i) / 255.0));
+    tab[i] = (float)std::strtod(buf, nullptr);
+  }
+  tab[256] = tab[255];
+}
+
+}  // namespace fmr

@@ -1,0 +1,728 @@
+// fmradion_amd.hip -- host engine + C-ABI (include/fmradion_amd.h) of the
+// MI355X-native FM/AM demodulation chain.  One translation unit; the kernels
+// are in kernels.hpp.  No CPU fallback: without a HIP device fmr_create fails.
+//
+// A call processes n_blocks consecutive input blocks of n_streams streams with
+// the exact per-block semantics of n_blocks sequential calls of the reference
+// classes (block-head FIR path, per-block lock decision, per-block equaliser
+// cadence, ... SURVEY.md 8a hazards H1-H5): the time-invariant stages run over
+// the whole call at once, the block structure travels as small offset tables
+// the host derives from the resampler's integer output-count law.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/fmradion_amd.h"
+#include "design.hpp"
+#include "kernels.hpp"
+
+namespace {
+#include "filter_tables.inc"
+
+thread_local std::string g_err;
+
+void set_err(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+#define HIPCHK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return FMR_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)
+
+constexpr double kFmRate = 384000.0;   // FmDecoder::sample_rate_if   (FmDecode.h:38)
+constexpr double kPcmRate = 48000.0;   // FmDecoder::sample_rate_pcm  (FmDecode.h:40)
+constexpr double kAmRate = 48000.0;    // AmDecoder::internal_rate_pcm (AmDecode.h:36)
+constexpr double kIfAtten = 140.0;     // resampler spec, DESIGN.md
+constexpr double kAudioAtten = 180.0;
+constexpr int FMR_MODE_NONE = -1;
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    n = count ? count : 1;
+    HIPCHK(hipMalloc((void **)&p, n * sizeof(T)));
+    HIPCHK(hipMemset(p, 0, n * sizeof(T)));
+    return FMR_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
+struct KernelTime { const char *name; hipEvent_t a, b; };
+
+}  // namespace
+
+using namespace fmr;
+
+struct fmr_chain {
+  fmr_config cfg{};
+  int S = 1, mode = FMR_MODE_FM;
+  bool has_rs = false, has_dec = true, fir_enable = false, stereo = false, pilot_shift = false;
+  bool enable_mpf = false;
+  hipStream_t stream = nullptr;
+  // designs + counters
+  ResamplerDesign rs, ars;
+  ResamplerCounter rsc, arsc;
+  unsigned long long abs_in = 0;          // absolute input sample index (FourthConverter phase)
+  unsigned wait_multipath_blocks = 100;   // FmDecode.cpp:33
+  // capacities
+  size_t max_in = 0, max_mid = 0, max_if = 0, max_amid = 0, max_au = 0;
+  int max_blocks = 0;
+  int H_in = 0, H_mid = 0, H_if = 0, H_a = 0, H_am = 0, H_pc = 0;
+  int ntaps = 0, n_pilotcut = 0, mpf_N = 0, mpf_ref = 0;
+  // device buffers
+  DevBuf<float2> d_in, d_in_halo, d_mid, d_if, d_fir, d_mpf, d_mpf_coeff, d_mpf_state;
+  DevBuf<float> d_gain, d_dec, d_hA, d_hB, d_coeff, d_atan, d_if_rms_blk, d_bb_mean_blk, d_bb_rms_blk;
+  DevBuf<double> d_base, d_raw, d_am0, d_am1, d_a10, d_a11, d_pc0, d_pc1, d_audio, d_ahA, d_ahB, d_pilotcut;
+  DevBuf<int> d_tab, d_mpf_ok, d_stereo_blk;
+  DevBuf<StreamState> d_state;
+  // block tables: ring of pinned host slots + device slots so that queued
+  // asynchronous calls never overwrite a table that is still being copied
+  static constexpr int kTabSlots = 8;
+  int *h_tab_all = nullptr;  // pinned, kTabSlots * 5 * max_blocks
+  hipEvent_t tab_ev[kTabSlots] = {};
+  int tab_slot = 0;
+  std::vector<StreamState> h_state;
+  // constants
+  PllConst pllc{};
+  Iir1Coef deemph{}, am_deemph{};
+  BiquadCoef dcblock{}, am_dcblock{};
+  float agc_init = 1.f, agc_max = 1e5f, agc_rate = 1e-4f;
+  float disc_nf = 1.f, disc_bound = 1.f;
+  // last call
+  long long last_n_if = 0, last_n_au = 0;
+  int last_nb = 0;
+  bool timing = false;
+  std::vector<KernelTime> ktimes;
+
+  ~fmr_chain() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
+    d_in.release(); d_in_halo.release(); d_mid.release(); d_if.release(); d_fir.release();
+    d_mpf.release(); d_mpf_coeff.release(); d_mpf_state.release(); d_gain.release(); d_dec.release();
+    d_hA.release(); d_hB.release(); d_coeff.release(); d_atan.release(); d_if_rms_blk.release();
+    d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
+    d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
+    d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
+    d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    if (h_tab_all) (void)hipHostFree(h_tab_all);
+    for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  // ---- kernel launch with optional HIP-event timing on the chain's stream ----
+  template <class F>
+  void timed(const char *name, F &&launch) {
+    if (!timing) { launch(); return; }
+    KernelTime kt{name, nullptr, nullptr};
+    (void)hipEventCreate(&kt.a);
+    (void)hipEventCreate(&kt.b);
+    (void)hipEventRecord(kt.a, stream);
+    launch();
+    (void)hipEventRecord(kt.b, stream);
+    ktimes.push_back(kt);
+  }
+
+  int init(const fmr_config *c);
+  int run(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
+          size_t astride, uint32_t *audio_len);
+};
+
+template <class T>
+static int upload(DevBuf<T> &b, const T *src, size_t n) {
+  int rc = b.alloc(n);
+  if (rc) return rc;
+  if (n) HIPCHK(hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return FMR_OK;
+}
+
+int fmr_chain::init(const fmr_config *c) {
+  cfg = *c;
+  S = c->n_streams;
+  mode = c->mode;
+  if (S < 1 || c->max_block_len == 0 || c->max_blocks < 1) { set_err("bad capacity / n_streams"); return FMR_ERR_BAD_ARG; }
+  if (mode != FMR_MODE_FM && mode != FMR_MODE_AM && mode != FMR_MODE_DSB && mode != FMR_MODE_NONE) {
+    set_err("mode %d is not on the hot path (FM, AM, DSB only)", mode);
+    return FMR_ERR_UNSUPPORTED;
+  }
+  has_dec = (mode != FMR_MODE_NONE);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err("no HIP device"); return FMR_ERR_NO_DEVICE; }
+  if (c->device < 0 || c->device >= ndev) { set_err("device %d out of range (%d devices)", c->device, ndev); return FMR_ERR_BAD_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  const double dec_rate = (mode == FMR_MODE_FM || mode == FMR_MODE_NONE) ? kFmRate : kAmRate;
+  has_rs = c->enable_resampler != 0;
+  max_blocks = c->max_blocks;
+  max_in = c->max_block_len * (size_t)c->max_blocks;
+  if (has_rs) {
+    if (!rs.design(c->input_rate, dec_rate, kIfAtten)) {
+      set_err("resampling ratio %.9g -> %.9g is outside the supported design range", c->input_rate, dec_rate);
+      return FMR_ERR_UNSUPPORTED;
+    }
+    if (rs.D == 1) {  // stage A degenerates to a copy (one unit tap)
+      rs.NA = 1; rs.hA.assign(1, 1.0);
+    }
+    if (sizeof(float2) * ((size_t)64 * rs.D + rs.NA - 1) > 60000) {
+      set_err("decimation %d of the front end is outside the supported range", rs.D);
+      return FMR_ERR_UNSUPPORTED;
+    }
+    H_in = rs.NA - 1 + rs.D;
+    H_mid = rs.TB;
+    max_mid = max_in / rs.D + 2;
+    max_if = (size_t)((double)max_in * rs.L / rs.M) + 4;
+    std::vector<float> fa(rs.hA.begin(), rs.hA.end()), fb(rs.hB.begin(), rs.hB.end());
+    int rc;
+    if ((rc = upload(d_hA, fa.data(), fa.size()))) return rc;
+    if ((rc = upload(d_hB, fb.data(), fb.size()))) return rc;
+    if ((rc = d_in_halo.alloc((size_t)S * H_in))) return rc;
+    if ((rc = d_mid.alloc((size_t)S * (H_mid + max_mid)))) return rc;
+  } else {
+    max_if = max_in;
+  }
+  int rc;
+  if ((rc = d_in.alloc((size_t)S * max_in))) return rc;
+  ntaps = c->n_filter_coeff;
+  fir_enable = (mode == FMR_MODE_FM) ? (c->fmfilter_enable != 0) : (mode != FMR_MODE_NONE);
+  if (has_dec && (ntaps < 1 || !c->filter_coeff)) { set_err("filter_coeff missing"); return FMR_ERR_BAD_ARG; }
+  H_if = has_dec ? (ntaps > 1 ? ntaps - 1 : 1) : 1;
+  if ((rc = d_if.alloc((size_t)S * (H_if + max_if)))) return rc;
+  h_state.assign(S, StreamState{});
+  for (auto &st : h_state) {
+    st.agc_gain = 1.0f;
+    st.pll_freq = (19000.0 / kFmRate) * 2.0 * M_PI;   // PilotPhaseLock.cpp:40
+    st.af_gain = 1.0;
+  }
+  if ((rc = upload(d_state, h_state.data(), h_state.size()))) return rc;
+  HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * 5 * (size_t)max_blocks));
+  for (auto &e : tab_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if ((rc = d_tab.alloc((size_t)kTabSlots * 5 * (size_t)max_blocks))) return rc;
+  if (!has_dec) return FMR_OK;
+
+  if ((rc = upload(d_coeff, c->filter_coeff, (size_t)ntaps))) return rc;
+  if (fir_enable && (rc = d_fir.alloc((size_t)S * max_if))) return rc;
+  if ((rc = d_gain.alloc((size_t)S * max_if))) return rc;
+  if ((rc = d_dec.alloc((size_t)S * max_if))) return rc;
+  if ((rc = d_if_rms_blk.alloc((size_t)S * max_blocks))) return rc;
+  if ((rc = d_bb_mean_blk.alloc((size_t)S * max_blocks))) return rc;
+  if ((rc = d_bb_rms_blk.alloc((size_t)S * max_blocks))) return rc;
+  if ((rc = d_mpf_ok.alloc((size_t)S * max_blocks))) return rc;
+  if ((rc = d_stereo_blk.alloc((size_t)S * max_blocks))) return rc;
+
+  if (mode == FMR_MODE_FM) {
+    stereo = c->stereo != 0;
+    pilot_shift = c->pilot_shift != 0;
+    enable_mpf = c->multipath_stages > 0;
+    if (c->multipath_stages > 300) { set_err("multipath_stages > 300 unsupported"); return FMR_ERR_UNSUPPORTED; }
+    agc_init = 1.0f; agc_max = 100000.0f; agc_rate = 0.0001f;          // FmDecode.cpp:74
+    disc_nf = (float)((75000.0 / kFmRate) * 2.0 * M_PI);                 // PhaseDiscriminator.cpp:28
+    disc_bound = (float)(1.0 / ((75000.0 / kFmRate) * 2.0));             // :30
+    const double freq = 19000.0 / kFmRate, bw = 30 / kFmRate;           // PilotPhaseLock.h:31-35
+    pllc.minfreq = (freq - bw) * 2.0 * M_PI;
+    pllc.maxfreq = (freq + bw) * 2.0 * M_PI;
+    pllc.bq_b0 = 1.46974784e-06; pllc.bq_a1 = -1.99682419; pllc.bq_a2 = 0.996825659;  // PilotPhaseLock.cpp:48
+    pllc.lf_b0 = 0.000304341788; pllc.lf_b1 = -0.000304324564;                          // :51
+    pllc.lock_delay = int(15.0 / bw);
+    pllc.pilot_frequency = 19000;
+    pllc.minsignal = 0.001;
+    const double de = c->deemphasis_us;
+    deemph = lowpass_rc((de == 0) ? 1.0 : (de * kFmRate * 1.0e-6));      // FmDecode.cpp:67-70
+    dcblock = highpass_iir(0.0001);                                       // FmDecode.cpp:62
+    if (!ars.design(kFmRate, kPcmRate, kAudioAtten)) { set_err("audio resampler design failed"); return FMR_ERR_UNSUPPORTED; }
+    if (ars.D == 1) { ars.NA = 1; ars.hA.assign(1, 1.0); }
+    H_a = ars.NA - 1 + ars.D;
+    H_am = ars.TB;
+    n_pilotcut = 127;
+    H_pc = n_pilotcut - 1;
+    max_amid = max_if / ars.D + 2;
+    max_au = (size_t)((double)max_if * ars.L / ars.M) + 4;
+    if ((rc = upload(d_ahA, ars.hA.data(), ars.hA.size()))) return rc;
+    if ((rc = upload(d_ahB, ars.hB.data(), ars.hB.size()))) return rc;
+    if ((rc = upload(d_pilotcut, k_jj1bdx_48khz_fmaudio, (size_t)127))) return rc;   // FmDecode.cpp:48-49
+    float tab[257];
+    make_fast_atan_table(tab);
+    if ((rc = upload(d_atan, tab, (size_t)257))) return rc;
+    if ((rc = d_base.alloc((size_t)S * (H_a + max_if)))) return rc;
+    if ((rc = d_raw.alloc((size_t)S * (H_a + max_if)))) return rc;
+    if ((rc = d_am0.alloc((size_t)S * (H_am + max_amid)))) return rc;
+    if ((rc = d_am1.alloc((size_t)S * (H_am + max_amid)))) return rc;
+    if ((rc = d_a10.alloc((size_t)S * (H_pc + max_au)))) return rc;
+    if ((rc = d_a11.alloc((size_t)S * (H_pc + max_au)))) return rc;
+    if ((rc = d_pc0.alloc((size_t)S * max_au))) return rc;
+    if ((rc = d_pc1.alloc((size_t)S * max_au))) return rc;
+    if ((rc = d_audio.alloc((size_t)S * 2 * max_au))) return rc;
+    // MultipathFilter(m_enable ? stages : 1)  (FmDecode.cpp:79)
+    const unsigned stages = enable_mpf ? c->multipath_stages : 1;
+    mpf_N = (int)(stages * 4 + 1);
+    mpf_ref = (int)(stages * 3 + 1);
+    std::vector<float2> cf((size_t)S * mpf_N, make_float2(0.f, 0.f));
+    for (int s = 0; s < S; s++) cf[(size_t)s * mpf_N + mpf_ref] = make_float2(1.f, 0.f);
+    if ((rc = upload(d_mpf_coeff, cf.data(), cf.size()))) return rc;
+    if ((rc = d_mpf_state.alloc((size_t)S * mpf_N))) return rc;
+    if (enable_mpf && (rc = d_mpf.alloc((size_t)S * max_if))) return rc;
+  } else {
+    agc_init = 1.0f; agc_max = 1000000.0f; agc_rate = 0.0003f;          // AmDecode.cpp:71-77
+    am_dcblock = highpass_iir(60 / kAmRate);                              // AmDecode.cpp:45
+    am_deemph = lowpass_rc(100 * kPcmRate * 1.0e-6);                      // AmDecode.cpp:49
+    max_au = max_if;
+    if ((rc = d_base.alloc((size_t)S * max_if))) return rc;
+    if ((rc = d_audio.alloc((size_t)S * max_au))) return rc;
+  }
+  return FMR_OK;
+}
+
+int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
+                   size_t astride, uint32_t *audio_len) {
+  if (nb < 1 || nb > max_blocks) { set_err("n_blocks %d outside 1..%d", nb, max_blocks); return FMR_ERR_CAPACITY; }
+  long long N_in = 0;
+  for (int b = 0; b < nb; b++) {
+    if (block_len[b] > cfg.max_block_len) { set_err("block %d longer than max_block_len", b); return FMR_ERR_CAPACITY; }
+    N_in += block_len[b];
+  }
+  HIPCHK(hipSetDevice(cfg.device));
+  for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
+  ktimes.clear();
+  const int slot = tab_slot;
+  tab_slot = (tab_slot + 1) % kTabSlots;
+  HIPCHK(hipEventSynchronize(tab_ev[slot]));   // slot free again (no-op if never recorded)
+  int *h_tab = h_tab_all + (size_t)slot * 5 * max_blocks;
+  int *d_tab_slot = d_tab.p + (size_t)slot * 5 * max_blocks;
+  int *t_if_off = h_tab, *t_if_len = h_tab + max_blocks, *t_au_off = h_tab + 2 * max_blocks,
+      *t_au_len = h_tab + 3 * max_blocks, *t_mpf = h_tab + 4 * max_blocks;
+  // ------------------------------------------------------------------ front end
+  long long N_if = 0, count_mid_call = 0;
+  if (has_rs) {
+    const long long mA_prev = rsc.mA, kB_prev = rsc.kB, n_prev = rsc.n_in;
+    for (int b = 0; b < nb; b++) {
+      t_if_off[b] = (int)N_if;
+      const long long k = rsc.advance(rs, block_len[b]);
+      t_if_len[b] = (int)k;
+      N_if += k;
+    }
+    const int count_mid = (int)(rsc.mA - mA_prev);
+    count_mid_call = count_mid;
+    if ((size_t)count_mid > max_mid || (size_t)N_if > max_if) { set_err("internal capacity exceeded"); return FMR_ERR_CAPACITY; }
+    if (count_mid > 0) {
+      const long long top0 = (long long)rs.D * mA_prev + rs.ca() - n_prev;
+      auto launch_decim = [&](auto bl_tag) {
+        constexpr int BL = decltype(bl_tag)::value;
+        const dim3 grid((count_mid + BL - 1) / BL, S);
+        const size_t lds = sizeof(float2) * ((size_t)BL * rs.D + rs.NA - 1);
+        hipLaunchKernelGGL(k_ifr_decim<BL>, grid, dim3(BL), lds, stream, d_iq, (long long)stride, N_in,
+                           d_in_halo.p, H_in, d_hA.p, rs.NA, rs.D, top0, count_mid, d_mid.p,
+                           (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), cfg.enable_fourth_down);
+      };
+      const size_t per_out = sizeof(float2) * (size_t)rs.D, tail = sizeof(float2) * (size_t)(rs.NA - 1);
+      timed("ifr_decim", [&] {
+        if (256 * per_out + tail <= 60000) launch_decim(std::integral_constant<int, 256>{});
+        else if (128 * per_out + tail <= 60000) launch_decim(std::integral_constant<int, 128>{});
+        else launch_decim(std::integral_constant<int, 64>{});
+      });
+    }
+    if (N_if > 0) {
+      constexpr int BL = 256;
+      const dim3 grid((unsigned)((N_if + BL - 1) / BL), S);
+      const int span = (int)(((unsigned long long)(BL - 1) * rs.MB) / rs.LB) + rs.TB + 2;
+      timed("ifr_poly", [&] {
+        hipLaunchKernelGGL(k_ifr_poly<BL>, grid, dim3(BL), sizeof(float2) * span, stream, d_mid.p,
+                           (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_hB.p, rs.TB,
+                           (unsigned)rs.LB, (unsigned)rs.MB, (unsigned long long)kB_prev * rs.MB, (int)N_if,
+                           d_if.p, (long long)(H_if + max_if), H_if);
+      });
+    }
+    if (N_in > 0) {
+      timed("in_halo", [&] {
+        hipLaunchKernelGGL(k_update_in_halo<256>, dim3(1, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq,
+                           (long long)stride, N_in);
+      });
+    }
+  } else {
+    for (int b = 0; b < nb; b++) { t_if_off[b] = (int)N_if; t_if_len[b] = (int)block_len[b]; N_if += block_len[b]; }
+    if (N_if > 0)
+      HIPCHK(hipMemcpy2DAsync(d_if.p + H_if, sizeof(float2) * (H_if + max_if), d_iq, sizeof(float2) * stride,
+                              sizeof(float2) * N_if, S, hipMemcpyDeviceToDevice, stream));
+  }
+  abs_in += (unsigned long long)N_in;
+  last_n_if = N_if; last_nb = nb; last_n_au = 0;
+  HaloTable ht{};
+  ht.n = 0;
+  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) {
+    if (H > 0 && N > 0) ht.d[ht.n++] = HaloDesc{(unsigned long long *)buf, stride_e, H, (int)N};
+  };
+  if (has_rs) add_halo(d_mid.p, H_mid + (long long)max_mid, H_mid, count_mid_call);
+  if (!has_dec || N_if == 0) {
+    if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = 0;
+    if (has_dec && fir_enable) add_halo(d_if.p, H_if + (long long)max_if, H_if, N_if);
+    if (ht.n) hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht);
+    HIPCHK(hipGetLastError());
+    return FMR_OK;
+  }
+  // --------------------------------------------------------------- block tables
+  long long N_au = 0;
+  bool any_mpf = false;
+  const long long amA_prev = arsc.mA, akB_prev = arsc.kB, an_prev = arsc.n_in;
+  for (int b = 0; b < nb; b++) {
+    t_mpf[b] = 0;
+    t_au_off[b] = (int)N_au;
+    t_au_len[b] = 0;
+    if (t_if_len[b] == 0) continue;          // the decoder is not called for an empty IF block (main.cpp:931-934)
+    if (mode == FMR_MODE_FM) {
+      if (wait_multipath_blocks > 0) wait_multipath_blocks--;     // FmDecode.cpp:107-110
+      else if (enable_mpf) { t_mpf[b] = 1; any_mpf = true; }
+      const long long k = arsc.advance(ars, t_if_len[b]);
+      t_au_len[b] = (int)k;
+      N_au += k;
+    } else {
+      t_au_len[b] = t_if_len[b];
+      N_au += t_if_len[b];
+    }
+  }
+  last_n_au = N_au;
+  HIPCHK(hipMemcpyAsync(d_tab_slot, h_tab, sizeof(int) * 5 * (size_t)max_blocks, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipEventRecord(tab_ev[slot], stream));
+  BlockTab bt{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
+              d_tab_slot + 4 * max_blocks, nb};
+  const long long if_stride = H_if + (long long)max_if;
+  // ------------------------------------------------------- decoder, IF-rate part
+  timed("fm_block", [&] {
+    hipLaunchKernelGGL(k_fm_block<256>, dim3(nb, S), dim3(256), 0, stream, d_if.p, if_stride, H_if, bt, d_coeff.p,
+                       ntaps, (int)fir_enable, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if,
+                       d_if_rms_blk.p);
+  });
+  const float2 *xin = fir_enable ? d_fir.p : d_if.p;
+  const long long x_stride = fir_enable ? (long long)max_if : if_stride;
+  const int x_off = fir_enable ? 0 : H_if;
+  timed("if_agc", [&] {
+    hipLaunchKernelGGL(k_if_agc, dim3((S + 63) / 64), dim3(64), 0, stream, xin, x_stride, x_off, (int)N_if, d_gain.p,
+                       (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate);
+  });
+  if (mode == FMR_MODE_FM) {
+    if (any_mpf) {
+      const size_t lds = sizeof(float2) * ((size_t)2 * mpf_N + FMR_MPF_CH);
+      timed("mpf", [&] {
+        hipLaunchKernelGGL(k_mpf, dim3(S), dim3(64), lds, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
+                           bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
+                           d_mpf_ok.p, d_state.p);
+      });
+    }
+    const long long base_stride = H_a + (long long)max_if;
+    timed("disc", [&] {
+      hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
+                         (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,
+                         disc_nf, disc_bound, d_dec.p, (long long)max_if, d_base.p, base_stride, H_a,
+                         d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);
+    });
+    timed("stats", [&] {
+      hipLaunchKernelGGL(k_stats, dim3((S + 63) / 64), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+                         d_bb_rms_blk.p, d_state.p, S, 1);
+    });
+    if (stereo) {
+      timed("pll", [&] {
+        hipLaunchKernelGGL(k_pll, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_a, bt, d_raw.p,
+                           base_stride, H_a, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p, S);
+      });
+    }
+    timed("deemph", [&] {
+      hipLaunchKernelGGL(k_deemph, dim3((2 * S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_a, d_raw.p,
+                         base_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1, (int)(stereo && !pilot_shift),
+                         d_state.p, S);
+    });
+    // ---------------------------------------------------- audio resampler + tail
+    const int nch = stereo ? 2 : 1;
+    const int count_am = (int)(arsc.mA - amA_prev);
+    const long long am_stride = H_am + (long long)max_amid;
+    const long long a1_stride = H_pc + (long long)max_au;
+    if ((size_t)count_am > max_amid || (size_t)N_au > max_au) { set_err("internal audio capacity exceeded"); return FMR_ERR_CAPACITY; }
+    if (count_am > 0) {
+      const long long top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
+      timed("aud_decim", [&] {
+        hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch), dim3(128), 0, stream, d_base.p,
+                           d_raw.p, base_stride, H_a, d_ahA.p, ars.NA, ars.D, top0, count_am, d_am0.p, d_am1.p,
+                           am_stride, H_am);
+      });
+    }
+    if (N_au > 0) {
+      timed("aud_poly", [&] {
+        hipLaunchKernelGGL(k_aud_poly<128>, dim3((unsigned)((N_au + 127) / 128), S, nch), dim3(128), 0, stream,
+                           d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB, (unsigned)ars.LB,
+                           (unsigned)ars.MB, (unsigned long long)akB_prev * ars.MB, (int)N_au, d_a10.p, d_a11.p,
+                           a1_stride, H_pc);
+      });
+      timed("pilotcut", [&] {
+        hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch), dim3(128), 0, stream, d_a10.p, d_a11.p, a1_stride, H_pc,
+                           bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
+      });
+      timed("fm_out", [&] {
+        hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
+                           dcblock.b0, dcblock.b1, dcblock.b2, dcblock.a1, dcblock.a2, (int)stereo, (int)pilot_shift,
+                           d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
+      });
+    }
+    if (fir_enable) add_halo(d_if.p, if_stride, H_if, N_if);
+    add_halo(d_base.p, base_stride, H_a, N_if);
+    if (stereo) add_halo(d_raw.p, base_stride, H_a, N_if);
+    add_halo(d_am0.p, am_stride, H_am, count_am);
+    if (stereo) add_halo(d_am1.p, am_stride, H_am, count_am);
+    add_halo(d_a10.p, a1_stride, H_pc, N_au);
+    if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
+    if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
+  } else {
+    timed("am_demod", [&] {
+      hipLaunchKernelGGL(k_am_demod<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
+                         (long long)max_if, bt, (int)(mode == FMR_MODE_DSB), d_dec.p, (long long)max_if, d_base.p,
+                         (long long)max_if, d_bb_mean_blk.p, d_bb_rms_blk.p);
+    });
+    timed("stats", [&] {
+      hipLaunchKernelGGL(k_stats, dim3((S + 63) / 64), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+                         d_bb_rms_blk.p, d_state.p, S, 0);
+    });
+    timed("am_tail", [&] {
+      hipLaunchKernelGGL(k_am_tail, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
+                         am_dcblock.b0, am_dcblock.b1, am_dcblock.b2, am_dcblock.a1, am_dcblock.a2, 1.0, 1.5, 0.6,
+                         0.001, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
+                         d_state.p, S);   // AfSimpleAgc(1.0, 1.5, 0.6, 0.001): AmDecode.cpp:54-66
+    });
+    add_halo(d_if.p, if_stride, H_if, N_if);
+    if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)t_au_len[b];
+  }
+  if (ht.n) {
+    timed("shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht); });
+  }
+  HIPCHK(hipGetLastError());
+  return FMR_OK;
+}
+
+// ============================================================================
+// C-ABI
+// ============================================================================
+extern "C" {
+
+const char *fmr_last_error(void) { return g_err.c_str(); }
+const char *fmr_version(void) { return "fmradion_amd 0.1 (gfx950)"; }
+
+int fmr_create(const fmr_config *cfg, fmr_chain **out) {
+  if (!cfg || !out) return FMR_ERR_BAD_ARG;
+  *out = nullptr;
+  fmr_chain *c = new fmr_chain();
+  const int rc = c->init(cfg);
+  if (rc != FMR_OK) { delete c; return rc; }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { delete c; return FMR_ERR_HIP; }
+  *out = c;
+  return FMR_OK;
+}
+
+void fmr_destroy(fmr_chain *c) { delete c; }
+
+long long fmr_resampler_info(const fmr_chain *c, int which) {
+  if (!c || !c->has_rs) return -1;
+  switch (which) {
+  case 0: return c->rs.D;
+  case 1: return c->rs.NA;
+  case 2: return c->rs.LB;
+  case 3: return c->rs.MB;
+  case 4: return c->rs.TB;
+  }
+  return -1;
+}
+
+int fmr_synchronize(fmr_chain *c) {
+  if (!c) return FMR_ERR_BAD_ARG;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return FMR_OK;
+}
+
+int fmr_process_blocks_device(fmr_chain *c, const float *d_iq, size_t stream_stride, const uint32_t *block_len,
+                              int n_blocks, double *d_audio, size_t audio_stride, uint32_t *audio_len, int sync) {
+  if (!c || !d_iq || !block_len) return FMR_ERR_BAD_ARG;
+  const int rc = c->run((const float2 *)d_iq, stream_stride, block_len, n_blocks, d_audio, audio_stride, audio_len);
+  if (rc) return rc;
+  if (sync) HIPCHK(hipStreamSynchronize(c->stream));
+  return FMR_OK;
+}
+
+int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, const uint32_t *block_len, int n_blocks,
+                       double *audio, size_t audio_stride, uint32_t *audio_len) {
+  if (!c || !iq || !block_len) return FMR_ERR_BAD_ARG;
+  size_t N_in = 0;
+  for (int b = 0; b < n_blocks; b++) N_in += block_len[b];
+  if (N_in > c->max_in) { set_err("input longer than max_block_len*max_blocks"); return FMR_ERR_CAPACITY; }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (N_in)
+    HIPCHK(hipMemcpy2DAsync(c->d_in.p, sizeof(float2) * c->max_in, iq, sizeof(float2) * stream_stride,
+                            sizeof(float2) * N_in, c->S, hipMemcpyHostToDevice, c->stream));
+  const size_t dstride = c->stereo ? 2 * c->max_au : c->max_au;
+  std::vector<uint32_t> alen(n_blocks, 0);
+  const int rc = c->run(c->d_in.p, c->max_in, block_len, n_blocks, c->d_audio.p, dstride, alen.data());
+  if (rc) return rc;
+  size_t total = 0;
+  for (int b = 0; b < n_blocks; b++) { total += alen[b]; if (audio_len) audio_len[b] = alen[b]; }
+  if (total > audio_stride && c->S > 1) { set_err("audio_stride too small"); return FMR_ERR_CAPACITY; }
+  if (total && audio) {
+    if (total > audio_stride) { set_err("audio capacity too small"); return FMR_ERR_CAPACITY; }
+    HIPCHK(hipMemcpy2DAsync(audio, sizeof(double) * audio_stride, c->d_audio.p, sizeof(double) * dstride,
+                            sizeof(double) * total, c->S, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return FMR_OK;
+}
+
+int fmr_process(fmr_chain *c, const float *iq, size_t n, double *audio, size_t audio_cap, size_t *n_audio) {
+  if (!c || !n_audio) return FMR_ERR_BAD_ARG;
+  *n_audio = 0;
+  if (n == 0) return FMR_OK;             // FmDecode.cpp:89-92
+  uint32_t bl = (uint32_t)n, al = 0;
+  const int rc = fmr_process_blocks(c, iq, n, &bl, 1, audio, audio_cap, &al);
+  if (rc) return rc;
+  *n_audio = al;
+  return FMR_OK;
+}
+
+int fmr_resample(fmr_chain *c, const float *iq, size_t n, float *out_iq, size_t out_cap, size_t *n_out) {
+  if (!c || !n_out || !c->has_rs) return FMR_ERR_BAD_ARG;
+  *n_out = 0;
+  if (c->has_dec) { set_err("fmr_resample needs a chain created with mode -1 (front end only)"); return FMR_ERR_BAD_ARG; }
+  if (n == 0) return FMR_OK;
+  if (n > c->max_in) return FMR_ERR_CAPACITY;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipMemcpyAsync(c->d_in.p, iq, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+  uint32_t bl = (uint32_t)n;
+  const int rc = c->run(c->d_in.p, c->max_in, &bl, 1, nullptr, 0, nullptr);
+  if (rc) return rc;
+  if ((size_t)c->last_n_if > out_cap) { set_err("out_cap too small"); return FMR_ERR_CAPACITY; }
+  if (c->last_n_if)
+    HIPCHK(hipMemcpyAsync(out_iq, c->d_if.p + c->H_if, sizeof(float2) * c->last_n_if, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *n_out = (size_t)c->last_n_if;
+  return FMR_OK;
+}
+
+static int fetch_state(fmr_chain *c) {
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(c->h_state.data(), c->d_state.p, sizeof(StreamState) * c->S, hipMemcpyDeviceToHost));
+  return FMR_OK;
+}
+
+int fmr_get_status(fmr_chain *c, int stream, fmr_status *st) {
+  if (!c || !st || stream < 0 || stream >= c->S) return FMR_ERR_BAD_ARG;
+  const int rc = fetch_state(c);
+  if (rc) return rc;
+  const StreamState &s = c->h_state[stream];
+  st->if_rms = s.if_rms;
+  st->baseband_mean = s.baseband_mean;
+  st->baseband_level = s.baseband_level;
+  st->pilot_level = 2 * s.pll_level;
+  st->stereo_detected = s.stereo_detected;
+  st->if_agc_gain = s.agc_gain;
+  st->af_agc_gain = s.af_gain;
+  st->multipath_error = s.mpf_error;
+  st->pll_freq_err = s.pll_freq_err;
+  st->multipath_resets = s.mpf_resets;
+  return FMR_OK;
+}
+
+int fmr_get_pps_events(fmr_chain *c, int stream, fmr_pps_event *ev, int cap) {
+  if (!c || stream < 0 || stream >= c->S) return FMR_ERR_BAD_ARG;
+  const int rc = fetch_state(c);
+  if (rc) return rc;
+  const StreamState &s = c->h_state[stream];
+  for (int i = 0; i < s.n_pps && i < cap; i++) {
+    ev[i].pps_index = s.pps[i].pps_index;
+    ev[i].sample_index = s.pps[i].sample_index;
+    ev[i].block_position = s.pps[i].block_position;
+    ev[i].block = s.pps[i].block;
+    ev[i].stream = (uint32_t)stream;
+  }
+  return s.n_pps;
+}
+
+int fmr_get_multipath_coefficients(fmr_chain *c, int stream, float *coeff, int cap) {
+  if (!c || stream < 0 || stream >= c->S || c->mpf_N == 0) return FMR_ERR_BAD_ARG;
+  if (cap < 2 * c->mpf_N) return FMR_ERR_CAPACITY;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(coeff, c->d_mpf_coeff.p + (size_t)stream * c->mpf_N, sizeof(float2) * c->mpf_N, hipMemcpyDeviceToHost));
+  return c->mpf_N;
+}
+
+long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t cap_bytes) {
+  if (!c || stream < 0 || stream >= c->S) return FMR_ERR_BAD_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const long long n = c->last_n_if;
+  const void *src = nullptr;
+  size_t esz = 0;
+  switch (which) {
+  case 0: src = c->d_if.p + (size_t)stream * (c->H_if + c->max_if) + c->H_if; esz = sizeof(float2); break;
+  case 1: src = c->d_dec.p ? c->d_dec.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
+  case 2: src = c->d_raw.p ? c->d_raw.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
+  case 3: src = c->d_base.p ? c->d_base.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
+  case 4: src = c->d_gain.p ? c->d_gain.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
+  default: return FMR_ERR_BAD_ARG;
+  }
+  if (!src) return FMR_ERR_BAD_ARG;
+  if ((size_t)n * esz > cap_bytes) return FMR_ERR_CAPACITY;
+  if (n) HIPCHK(hipMemcpy(out, src, (size_t)n * esz, hipMemcpyDeviceToHost));
+  return n;
+}
+
+void fmr_enable_kernel_timing(fmr_chain *c, int enable) { if (c) c->timing = enable != 0; }
+
+int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap) {
+  if (!c) return FMR_ERR_BAD_ARG;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int n = 0;
+  for (auto &k : c->ktimes) {
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, k.a, k.b);
+    if (n < cap) { names[n] = k.name; ms[n] = t; }
+    n++;
+  }
+  return n;
+}
+
+int fmr_filter_table(const char *name, const void **data, int *is_double) {
+  struct Ent { const char *name; const void *p; int n; int dbl; };
+  static const Ent tabs[] = {
+      {"jj1bdx_48khz_fmaudio", k_jj1bdx_48khz_fmaudio, 127, 1},
+      {"jj1bdx_48khz_nbfmaudio", k_jj1bdx_48khz_nbfmaudio, 63, 1},
+      {"jj1bdx_am_48khz_narrow", k_jj1bdx_am_48khz_narrow, 255, 0},
+      {"jj1bdx_am_48khz_medium", k_jj1bdx_am_48khz_medium, 255, 0},
+      {"jj1bdx_am_48khz_default", k_jj1bdx_am_48khz_default, 255, 0},
+      {"jj1bdx_am_48khz_wide", k_jj1bdx_am_48khz_wide, 127, 0},
+      {"jj1bdx_nbfm_48khz_default", k_jj1bdx_nbfm_48khz_default, 127, 0},
+      {"jj1bdx_nbfm_48khz_narrow", k_jj1bdx_nbfm_48khz_narrow, 127, 0},
+      {"jj1bdx_nbfm_48khz_medium", k_jj1bdx_nbfm_48khz_medium, 127, 0},
+      {"jj1bdx_nbfm_48khz_wide", k_jj1bdx_nbfm_48khz_wide, 127, 0},
+      {"jj1bdx_fm_384kHz_narrow", k_jj1bdx_fm_384kHz_narrow, 127, 0},
+      {"jj1bdx_fm_384kHz_medium", k_jj1bdx_fm_384kHz_medium, 127, 0},
+      {"jj1bdx_cw_48khz_500hz", k_jj1bdx_cw_48khz_500hz, 2049, 0},
+      {"jj1bdx_ssb_48khz_1500hz", k_jj1bdx_ssb_48khz_1500hz, 2049, 0},
+  };
+  if (!name) return FMR_ERR_BAD_ARG;
+  for (const auto &e : tabs)
+    if (std::strcmp(e.name, name) == 0) {
+      if (data) *data = e.p;
+      if (is_double) *is_double = e.dbl;
+      return e.n;
+    }
+  return FMR_ERR_BAD_ARG;
+}
+
+}  // extern "C"

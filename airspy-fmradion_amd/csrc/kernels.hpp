@@ -1,0 +1,892 @@
+// kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4) of the FM/AM chain.
+//
+// Compiled with -ffp-contract=off: every place that wants a fused multiply-add
+// says fmaf()/fma() explicitly; everything else keeps the reference's
+// separate-rounding arithmetic (x86-64 baseline build, CMakeLists.txt:193-199),
+// which is what makes most stages bit-comparable with the oracle.
+//
+// Buffer convention ("prefix halo"): a stage buffer is [halo H | data of this
+// call]; reads at local index -1..-H reach the samples of the previous call.
+// k_shift_halo re-seats the halos at the end of a call.
+//
+// Stream dimension: blockIdx.y (parallel kernels) or the thread index (serial
+// recurrence kernels, one lane per stream).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fmr {
+
+// ---------------------------------------------------------------------------
+// Per-stream state carried across launches ("per-stream PLL state carried
+// across launches" of the north star); initial values: SURVEY.md 8a table.
+// ---------------------------------------------------------------------------
+struct PpsEventDev {
+  unsigned long long pps_index, sample_index;
+  double block_position;
+  unsigned block, pad;
+};
+
+#define FMR_MAX_PPS 64
+
+struct StreamState {
+  // IfSimpleAgc (IfSimpleAgc.cpp:26-34)
+  float agc_gain;
+  // PhaseDiscriminator m_save_value (PhaseDiscriminator.cpp:30)
+  float disc_save, disc_save_next;
+  int disc_save_valid;
+  // FmDecoder / AmDecoder statistics (FmDecode.cpp:95,149-150)
+  float if_rms, baseband_mean, baseband_level;
+  int stereo_detected;
+  // PilotPhaseLock (PilotPhaseLock.cpp:37-51)
+  double pll_phase, pll_freq, pll_freq_err, pll_level;
+  double bq_i_x1, bq_i_x2, bq_q_x1, bq_q_x2, lf_x1;
+  int lock_cnt, pilot_periods;
+  unsigned long long pps_cnt, sample_cnt;
+  int n_pps, pad0;
+  PpsEventDev pps[FMR_MAX_PPS];
+  // LowPassFilterRC x2, HighPassFilterIir x2 (Filter.cpp:169,240)
+  double de_mono_x1, de_stereo_x1;
+  double dc_mono_x1, dc_mono_x2, dc_st_x1, dc_st_x2;
+  // MultipathFilter (MultipathFilter.cpp:59-75)
+  double mpf_error;
+  unsigned mpf_resets, pad1;
+  // AmDecoder: AfSimpleAgc gain, dc block, de-emphasis
+  double af_gain, am_dc_x1, am_dc_x2, am_de_x1;
+};
+
+struct PllConst {
+  double minfreq, maxfreq;
+  double bq_b0, bq_a1, bq_a2;   // PilotPhaseLock.cpp:48-49
+  double lf_b0, lf_b1;          // :51
+  int lock_delay;               // :43
+  int pilot_frequency;          // PilotPhaseLock.h:31
+  double minsignal;             // PilotPhaseLock.h:37
+};
+
+// ---------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ float block_sum(float v, float *scratch /* BLOCK/64 */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) scratch[w] = v;
+  __syncthreads();
+  float r = 0;
+#pragma unroll
+  for (int i = 0; i < BLOCK / 64; i++) r += scratch[i];
+  __syncthreads();
+  return r;
+}
+
+// FourthConverterIQ (include/FourthConverterIQ.h:45-79), down-conversion:
+// table index cycles 0,1,2,3 with the absolute sample index.
+__device__ __forceinline__ float2 fourth_rot(float2 v, unsigned idx) {
+  switch (idx & 3u) {
+  case 0: return v;
+  case 1: return make_float2(v.y, -v.x);
+  case 2: return make_float2(-v.x, -v.y);
+  default: return make_float2(-v.y, v.x);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K_A  ifr_decim : front-end stage A, integer decimation by D with an NA-tap
+// linear-phase FIR.  The only kernel that touches every input IQ sample:
+// HBM-read bound (8 B per input sample), see DESIGN.md.
+//   y[m] = sum_k hA[k] * x[D*m + ca - k]
+// v1 layout: one output per lane, input span staged in LDS with coalesced
+// float2 loads, taps through the scalar cache (wave-uniform index).
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ifr_decim(
+    const float2 *__restrict__ iq, long long iq_stride, long long n_valid,
+    const float2 *__restrict__ halo, int H, const float *__restrict__ hA, int NA, int D,
+    long long top0, int count, float2 *__restrict__ mid, long long mid_stride, int mid_off,
+    unsigned rot_base, int fourth) {
+  extern __shared__ float2 lds_a[];
+  const int s = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * BLOCK;
+  const int span = BLOCK * D + NA - 1;
+  const long long lo = top0 + (long long)m0 * D - (NA - 1);
+  const float2 *xs = iq + (long long)s * iq_stride;
+  const float2 *hs = halo + (long long)s * H;
+  for (int i = tid; i < span; i += BLOCK) {
+    const long long n = lo + i;
+    float2 v = make_float2(0.f, 0.f);
+    if (n < 0) {
+      if (n >= -(long long)H) v = hs[H + n];
+    } else if (n < n_valid) {
+      v = xs[n];
+    }
+    if (fourth) v = fourth_rot(v, (unsigned)((long long)rot_base + n));
+    lds_a[i] = v;
+  }
+  __syncthreads();
+  const int m = m0 + tid;
+  if (m < count) {
+    const float2 *xp = lds_a + tid * D + (NA - 1);
+    float ax = 0.f, ay = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < NA; k++) {
+      const float h = hA[k];
+      const float2 x = xp[-k];
+      ax = fmaf(h, x.x, ax);
+      ay = fmaf(h, x.y, ay);
+    }
+    mid[(long long)s * mid_stride + mid_off + m] = make_float2(ax, ay);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K_B  ifr_poly : front-end stage B, rational LB/MB polyphase resampler.
+//   y[k] = sum_j hB[p_k][j] * mid[n_k - W + 1 + j],  t = k*MB, n_k = t / LB, p_k = t % LB
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ifr_poly(
+    const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
+    const float *__restrict__ hB, int TB, unsigned LB, unsigned MB, unsigned long long t0,
+    int count, float2 *__restrict__ out, long long out_stride, int out_off) {
+  extern __shared__ float2 lds_b[];
+  const int s = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int W = TB >> 1;
+  const unsigned long long tk0 = t0 + (unsigned long long)(blockIdx.x * BLOCK) * MB;
+  const long long x_lo = (long long)(tk0 / LB) - W + 1 - mid_abs0;
+  const int span = (int)(((unsigned long long)(BLOCK - 1) * MB) / LB) + TB + 2;
+  const float2 *ms = mid + (long long)s * mid_stride;
+  for (int i = tid; i < span; i += BLOCK) {
+    const long long idx = x_lo + i;
+    float2 v = make_float2(0.f, 0.f);
+    if (idx >= 0 && idx < mid_valid) v = ms[idx];
+    lds_b[i] = v;
+  }
+  __syncthreads();
+  const int k = blockIdx.x * BLOCK + tid;
+  if (k < count) {
+    const unsigned long long t = t0 + (unsigned long long)k * MB;
+    const long long nk = (long long)(t / LB);
+    const unsigned p = (unsigned)(t % LB);
+    const int xi = (int)(nk - W + 1 - mid_abs0 - x_lo);
+    const float *h = hB + (size_t)p * TB;
+    const float2 *xp = lds_b + xi;
+    float ax = 0.f, ay = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < TB; j++) {
+      const float c = h[j];
+      const float2 x = xp[j];
+      ax = fmaf(c, x.x, ax);
+      ay = fmaf(c, x.y, ay);
+    }
+    out[(long long)s * out_stride + out_off + k] = make_float2(ax, ay);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_shift_halo : re-seat prefix halos at the end of a call.  All elements are
+// 8 bytes (float2 or double).  newhalo[i] = concat(halo,data)[i + N].
+// ---------------------------------------------------------------------------
+struct HaloDesc {
+  unsigned long long *buf;   // start of [halo | data] of stream 0
+  long long stride;          // elements between streams
+  int H;                     // halo length
+  int N;                     // data elements appended in this call
+};
+#define FMR_MAX_HALO 12
+struct HaloTable { HaloDesc d[FMR_MAX_HALO]; int n; };
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_shift_halo(HaloTable tab) {
+  const HaloDesc d = tab.d[blockIdx.x];
+  unsigned long long *b = d.buf + (long long)blockIdx.y * d.stride;
+  if (d.N <= 0) return;
+  for (int c = 0; c < d.H; c += BLOCK) {
+    const int i = c + threadIdx.x;
+    unsigned long long v = 0;
+    if (i < d.H) v = b[i + d.N];
+    __syncthreads();
+    if (i < d.H) b[i] = v;
+    __syncthreads();
+  }
+}
+
+// K_A's input halo lives in its own buffer because the caller owns the input:
+// newhalo[i] = concat(halo, iq[0..N))[i + N].
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_update_in_halo(
+    float2 *__restrict__ halo, int H, const float2 *__restrict__ iq, long long iq_stride, long long N) {
+  float2 *hs = halo + (long long)blockIdx.y * H;
+  const float2 *xs = iq + (long long)blockIdx.y * iq_stride;
+  for (int c = 0; c < H; c += BLOCK) {
+    const int i = c + threadIdx.x;
+    float2 v = make_float2(0.f, 0.f);
+    if (i < H) {
+      const long long j = (long long)i + N;  // index into concat(halo, iq)
+      v = (j < H) ? hs[j] : xs[j - H];
+    }
+    __syncthreads();
+    if (i < H) hs[i] = v;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Per-block tables (host-computed, identical for all streams)
+// ---------------------------------------------------------------------------
+struct BlockTab {
+  const int *if_off;     // [nb] offset of the block inside this call's IF samples
+  const int *if_len;     // [nb]
+  const int *au_off;     // [nb] offset at the audio rate (FM: 48 kHz; AM: = if_off)
+  const int *au_len;     // [nb]
+  const int *mpf_active; // [nb] 1 when the equaliser runs on this block
+  int nb;
+};
+
+// ---------------------------------------------------------------------------
+// K_blk  fm_block : per decoder block -- IF RMS (Utility.h:118-132) and the
+// optional LowPassFilterFirIQ (Filter.cpp:37-96) incl. the block-head path
+// (hazard H1).  FM: RMS of the block entering the decoder (FmDecode.cpp:95);
+// AM: RMS after the FIR (AmDecode.cpp:101,154).
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fm_block(
+    const float2 *__restrict__ ifb, long long if_stride, int if_halo, BlockTab bt,
+    const float *__restrict__ coeff, int ntaps, int fir_enable, int rms_after_fir,
+    float2 *__restrict__ firb, long long fir_stride, float *__restrict__ if_rms_blk) {
+  __shared__ float scratch[BLOCK / 64];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int n = bt.if_len[b];
+  if (n == 0) return;
+  const float2 *x = ifb + (long long)s * if_stride + if_halo + bt.if_off[b];
+  float2 *y = firb + (long long)s * fir_stride + bt.if_off[b];
+  const int order = ntaps - 1;
+  const int half_order = (order - 1) / 2;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += BLOCK) {
+    float2 v = x[i];
+    if (fir_enable) {
+      float yr = 0.f, yi = 0.f;
+      if (i < order) {
+        // head: lags 1..order, state part first then in-block part (Filter.cpp:59-68)
+        for (int j = i + 1; j <= order; j++) {
+          const float2 t = x[i - j];
+          const float c = coeff[j];
+          yr += t.x * c; yi += t.y * c;
+        }
+        for (int j = 1; j <= i; j++) {
+          const float2 t = x[i - j];
+          const float c = coeff[j];
+          yr += t.x * c; yi += t.y * c;
+        }
+      } else {
+        // body: folded symmetric form incl. lag 0 (Filter.cpp:73-82)
+        for (int k = 0; k <= half_order; k++) {
+          const float2 a = x[i - k], bb = x[i - (order - k)];
+          const float c = coeff[k];
+          yr += (a.x + bb.x) * c; yi += (a.y + bb.y) * c;
+        }
+        if ((order % 2) == 0) {
+          const float2 t = x[i - order / 2];
+          const float c = coeff[order / 2];
+          yr += t.x * c; yi += t.y * c;
+        }
+      }
+      const float2 o = make_float2(yr, yi);
+      y[i] = o;
+      if (rms_after_fir) v = o;
+    }
+    acc += v.x * v.x + v.y * v.y;
+  }
+  const float tot = block_sum<BLOCK>(acc, scratch);
+  if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);
+}
+
+// ---------------------------------------------------------------------------
+// K_agc : IfSimpleAgc (IfSimpleAgc.cpp:37-57), nonlinear serial recurrence,
+// one lane per stream.  Emits the gain applied to each sample; consumers form
+// x*g themselves (same two float multiplies as the reference).
+// ---------------------------------------------------------------------------
+__global__ void k_if_agc(const float2 *__restrict__ x, long long x_stride, int x_off, int n,
+                         float *__restrict__ gain, long long g_stride, StreamState *st, int n_streams,
+                         float initial_gain, float max_gain, float rate) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams) return;
+  const float2 *xs = x + (long long)s * x_stride + x_off;
+  float *gs = gain + (long long)s * g_stride;
+  float g = st[s].agc_gain;
+  const double r = (double)rate;
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const float2 v0 = xs[i], v1 = xs[i + 1], v2 = xs[i + 2], v3 = xs[i + 3];
+    const float2 vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      gs[i + u] = g;
+      const float xr = vv[u].x * g, xi = vv[u].y * g;
+      const float nrm = xr * xr + xi * xi;
+      const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
+      g *= z;
+      if (!isfinite(g)) g = initial_gain;
+      else if (g > max_gain) g = max_gain;
+    }
+  }
+  for (; i < n; i++) {
+    const float2 v = xs[i];
+    gs[i] = g;
+    const float xr = v.x * g, xi = v.y * g;
+    const float nrm = xr * xr + xi * xi;
+    const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
+    g *= z;
+    if (!isfinite(g)) g = initial_gain;
+    else if (g > max_gain) g = max_gain;
+  }
+  st[s].agc_gain = g;
+}
+
+// ---------------------------------------------------------------------------
+// K_mpf : MultipathFilter (MultipathFilter.cpp:92-197), constant-modulus NLMS.
+// One wave per stream; taps spread over the 64 lanes (tap i on lane i & 63),
+// coefficients and the sliding state window in LDS, cross-lane reduction with
+// shuffles.  Serial over samples (taps depend on previous outputs); the update
+// cadence restarts in every block (hazard H2).
+// LDS: coeff[N] | xw[N + CH]  (float2)
+// ---------------------------------------------------------------------------
+#define FMR_MPF_CH 2048
+__device__ __forceinline__ float2 wave_sum2(float2 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v.x += __shfl_xor(v.x, o, 64);
+    v.y += __shfl_xor(v.y, o, 64);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_mpf(
+    const float2 *__restrict__ xin, long long x_stride, int x_off,
+    const float *__restrict__ gain, long long g_stride, BlockTab bt,
+    float2 *__restrict__ out, long long out_stride, float2 *__restrict__ coeff_g,
+    float2 *__restrict__ state_g, int N, int ref, int *__restrict__ mpf_ok, StreamState *st) {
+  extern __shared__ float2 lds_m[];
+  float2 *c = lds_m;
+  float2 *xw = lds_m + N;
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float2 *xs = xin + (long long)s * x_stride + x_off;
+  const float *gs = gain + (long long)s * g_stride;
+  float2 *os = out + (long long)s * out_stride;
+  float2 *cg = coeff_g + (long long)s * N;
+  float2 *sg = state_g + (long long)s * N;
+  for (int i = lane; i < N; i += 64) c[i] = cg[i];
+  double err_last = st[s].mpf_error;
+  unsigned resets = st[s].mpf_resets;
+  __syncthreads();
+  for (int b = 0; b < bt.nb; b++) {
+    const int n = bt.if_len[b];
+    int ok = 1;
+    if (n == 0 || !bt.mpf_active[b]) {
+      if (lane == 0) mpf_ok[(long long)s * bt.nb + b] = 0;
+      continue;
+    }
+    const int off = bt.if_off[b];
+    for (int i = lane; i < N; i += 64) xw[i] = sg[i];
+    __syncthreads();
+    for (int c0 = 0; c0 < n && ok; c0 += FMR_MPF_CH) {
+      const int cn = min(FMR_MPF_CH, n - c0);
+      for (int i = lane; i < cn; i += 64) {
+        const float2 v = xs[off + c0 + i];
+        const float g = gs[off + c0 + i];
+        xw[N + i] = make_float2(v.x * g, v.y * g);
+      }
+      __syncthreads();
+      int pushed = 0;
+      for (int q = 0; q < cn; q++) {
+        // state after the push = xw[q+1 .. q+N]; y = sum state[i]*coeff[i] (V9)
+        float2 acc = make_float2(0.f, 0.f);
+        for (int i = lane; i < N; i += 64) {
+          const float2 sv = xw[q + 1 + i], cv = c[i];
+          acc.x = fmaf(sv.x, cv.x, acc.x); acc.x = fmaf(-sv.y, cv.y, acc.x);
+          acc.y = fmaf(sv.x, cv.y, acc.y); acc.y = fmaf(sv.y, cv.x, acc.y);
+        }
+        const float2 y = wave_sum2(acc);
+        pushed = q + 1;
+        if (!isfinite(y.x) || !isfinite(y.y)) { ok = 0; break; }   // :182-184
+        if (lane == 0) os[off + c0 + q] = y;
+        if ((((c0 + q) & 3) == 0)) {                                // :176,186
+          const double env = (double)(y.x * y.x + y.y * y.y);
+          const double error = 1.0 - env;
+          float ms = 0.f;
+          for (int i = lane; i < N; i += 64) {
+            const float2 sv = xw[q + 1 + i];
+            ms += sv.x * sv.x + sv.y * sv.y;
+          }
+          const float sum = wave_sum(ms);
+          const float mu = (float)(0.1 / ((double)sum + 1e-10));   // :130
+          const float factor = (float)(error * (double)mu);         // :133
+          const float fr = factor * y.x, fi = factor * y.y;
+          for (int i = lane; i < N; i += 64) {                       // V10
+            const float2 sv = xw[q + 1 + i];
+            float2 cv = c[i];
+            cv.x += sv.x * fr + sv.y * fi;
+            cv.y += sv.x * fi - sv.y * fr;
+            if (i == ref) cv = make_float2(1.f, 0.f);                // :158
+            c[i] = cv;
+          }
+          err_last = error;
+          __syncthreads();
+          if (!isfinite(error)) { ok = 0; break; }                   // :190-192
+        }
+      }
+      // new state = last N entries pushed so far
+      __syncthreads();
+      float2 tmp[20];
+      int cnt = 0;
+      for (int i = lane; i < N; i += 64) tmp[cnt++] = xw[pushed + i];
+      __syncthreads();
+      cnt = 0;
+      for (int i = lane; i < N; i += 64) xw[i] = tmp[cnt++];
+      __syncthreads();
+    }
+    for (int i = lane; i < N; i += 64) sg[i] = xw[i];
+    if (!ok) {
+      // FmDecode.cpp:117-123: re-initialise the taps, block falls back to the AGC output
+      for (int i = lane; i < N; i += 64) c[i] = make_float2(i == ref ? 1.f : 0.f, 0.f);
+      resets++;
+    }
+    if (lane == 0) mpf_ok[(long long)s * bt.nb + b] = ok;
+    __syncthreads();
+  }
+  for (int i = lane; i < N; i += 64) cg[i] = c[i];
+  if (lane == 0) { st[s].mpf_error = err_last; st[s].mpf_resets = resets; }
+}
+
+// ---------------------------------------------------------------------------
+// K_disc : PhaseDiscriminator (PhaseDiscriminator.cpp:33-46) per decoder block,
+// fused with the float->double widening (FmDecode.cpp:143) and the block
+// mean / rms of the MPX signal (Utility.h:135-152).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float2 disc_src(const float2 *xs, const float *gs, const float2 *ms, int use_mpf, int idx) {
+  if (use_mpf) return ms[idx];
+  const float2 v = xs[idx];
+  const float g = gs[idx];
+  return make_float2(v.x * g, v.y * g);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_disc(
+    const float2 *__restrict__ xin, long long x_stride, int x_off,
+    const float *__restrict__ gain, long long g_stride,
+    const float2 *__restrict__ mpfb, long long m_stride, const int *__restrict__ mpf_ok,
+    BlockTab bt, float nf, float bound, float *__restrict__ dec, long long dec_stride,
+    double *__restrict__ base, long long base_stride, int base_off,
+    float *__restrict__ bb_mean_blk, float *__restrict__ bb_rms_blk, StreamState *st) {
+  __shared__ float scratch[BLOCK / 64];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int n = bt.if_len[b];
+  if (n == 0) return;
+  const int off = bt.if_off[b];
+  const float2 *xs = xin + (long long)s * x_stride + x_off;
+  const float *gs = gain + (long long)s * g_stride;
+  const float2 *ms = mpfb ? mpfb + (long long)s * m_stride : nullptr;
+  const int use_mpf = mpfb ? mpf_ok[(long long)s * bt.nb + b] : 0;
+  float vsum = 0.f, vsq = 0.f;
+  for (int i = threadIdx.x; i < n; i += BLOCK) {
+    const float2 v = disc_src(xs, gs, ms, use_mpf, off + i);
+    const float ph = atan2f(v.y, v.x) / nf;                      // V4
+    float prev;
+    if (i > 0) {
+      const float2 p = disc_src(xs, gs, ms, use_mpf, off + i - 1);
+      prev = atan2f(p.y, p.x) / nf;
+    } else {
+      int pb = b - 1;
+      while (pb >= 0 && bt.if_len[pb] == 0) pb--;
+      if (pb < 0) {
+        prev = st[s].disc_save;
+      } else {
+        const int pu = mpfb ? mpf_ok[(long long)s * bt.nb + pb] : 0;
+        const float2 p = disc_src(xs, gs, ms, pu, bt.if_off[pb] + bt.if_len[pb] - 1);
+        prev = atan2f(p.y, p.x) / nf;
+      }
+    }
+    float d = ph - prev;                                          // V5
+    if (d > bound) d -= 2 * bound;
+    if (d < -bound) d += 2 * bound;
+    if (isnan(d)) d = 0.f;                                        // Utility.h:336-343
+    dec[(long long)s * dec_stride + off + i] = d;
+    base[(long long)s * base_stride + base_off + off + i] = (double)d;
+    vsum += d;
+    vsq += d * d;
+    if (i == n - 1) {
+      // is this the last non-empty block of the call?
+      int nb2 = b + 1;
+      while (nb2 < bt.nb && bt.if_len[nb2] == 0) nb2++;
+      if (nb2 >= bt.nb) { st[s].disc_save_next = ph; st[s].disc_save_valid = 1; }
+    }
+  }
+  const float ts = block_sum<BLOCK>(vsum, scratch);
+  const float tq = block_sum<BLOCK>(vsq, scratch);
+  if (threadIdx.x == 0) {
+    bb_mean_blk[(long long)s * bt.nb + b] = ts / (float)(unsigned)n;
+    bb_rms_blk[(long long)s * bt.nb + b] = sqrtf(tq / (float)(unsigned)n);
+  }
+}
+
+// AM: demodulate_am / demodulate_dsb (AmDecode.cpp:221-234) + widening (:190)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_am_demod(
+    const float2 *__restrict__ xin, long long x_stride, int x_off,
+    const float *__restrict__ gain, long long g_stride, BlockTab bt, int dsb,
+    float *__restrict__ dec, long long dec_stride, double *__restrict__ demod, long long demod_stride,
+    float *__restrict__ bb_mean_blk, float *__restrict__ bb_rms_blk) {
+  __shared__ float scratch[BLOCK / 64];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int n = bt.if_len[b];
+  if (n == 0) return;
+  const int off = bt.if_off[b];
+  const float2 *xs = xin + (long long)s * x_stride + x_off;
+  const float *gs = gain + (long long)s * g_stride;
+  float vsum = 0.f, vsq = 0.f;
+  for (int i = threadIdx.x; i < n; i += BLOCK) {
+    const float2 v = disc_src(xs, gs, nullptr, 0, off + i);
+    const float d = dsb ? v.x : sqrtf(v.x * v.x + v.y * v.y);    // V12 / V11
+    dec[(long long)s * dec_stride + off + i] = d;
+    demod[(long long)s * demod_stride + off + i] = (double)d;
+    vsum += d;
+    vsq += d * d;
+  }
+  const float ts = block_sum<BLOCK>(vsum, scratch);
+  const float tq = block_sum<BLOCK>(vsq, scratch);
+  if (threadIdx.x == 0) {
+    bb_mean_blk[(long long)s * bt.nb + b] = ts / (float)(unsigned)n;
+    bb_rms_blk[(long long)s * bt.nb + b] = sqrtf(tq / (float)(unsigned)n);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K_stats : per-block scalar bookkeeping, one lane per stream: if_rms of the
+// last block, the 0.95/0.05 EMAs (FmDecode.cpp:149-150, AmDecode.cpp:208-209),
+// commit of the discriminator's carried phase.
+// ---------------------------------------------------------------------------
+__global__ void k_stats(BlockTab bt, const float *__restrict__ if_rms_blk, const float *__restrict__ bb_mean_blk,
+                        const float *__restrict__ bb_rms_blk, StreamState *st, int n_streams, int has_disc) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams) return;
+  float m = st[s].baseband_mean, l = st[s].baseband_level, r = st[s].if_rms;
+  for (int b = 0; b < bt.nb; b++) {
+    if (bt.if_len[b] == 0) continue;
+    r = if_rms_blk[(long long)s * bt.nb + b];
+    m = (float)(0.95 * (double)m + 0.05 * (double)bb_mean_blk[(long long)s * bt.nb + b]);
+    l = (float)(0.95 * (double)l + 0.05 * (double)bb_rms_blk[(long long)s * bt.nb + b]);
+  }
+  st[s].baseband_mean = m; st[s].baseband_level = l; st[s].if_rms = r;
+  if (has_disc && st[s].disc_save_valid) { st[s].disc_save = st[s].disc_save_next; st[s].disc_save_valid = 0; }
+}
+
+// ---------------------------------------------------------------------------
+// K_pll : PilotPhaseLock (PilotPhaseLock.cpp:56-171) + demod_stereo
+// (FmDecode.cpp:224-239).  Nonlinear feedback loop: strictly serial per
+// stream, one lane per stream; FP64 with the float table-driven fast_atan2f.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2f_dev(float y, float x, const float *tab) {
+  const float y_abs = fabsf(y), x_abs = fabsf(x);
+  if (!((y_abs > 0.0f) || (x_abs > 0.0f))) return 0.0f;
+  float z = (y_abs < x_abs) ? (y_abs / x_abs) : (x_abs / y_abs);
+  float base_angle;
+  if ((double)z < 0.003921569) {
+    base_angle = z;
+  } else {
+    float alpha = z * 255.0f;
+    const int index = ((int)alpha) & 0xff;
+    alpha -= (float)index;
+    base_angle = tab[index];
+    base_angle += (tab[index + 1] - tab[index]) * alpha;
+  }
+  float angle;
+  if (x_abs > y_abs) {
+    if (x >= 0.0f) {
+      angle = (y >= 0.0f) ? base_angle : -base_angle;
+    } else {
+      angle = 3.14159265358979323846f;
+      if (y >= 0.0f) angle -= base_angle; else angle = base_angle - angle;
+    }
+  } else {
+    if (y >= 0.0f) {
+      angle = 1.57079632679489661923f;
+      if (x >= 0.0f) angle -= base_angle; else angle += base_angle;
+    } else {
+      angle = -1.57079632679489661923f;
+      if (x >= 0.0f) angle += base_angle; else angle -= base_angle;
+    }
+  }
+  return angle;
+}
+
+__global__ __launch_bounds__(64) void k_pll(
+    const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt,
+    double *__restrict__ raw, long long raw_stride, int raw_off, const float *__restrict__ atan_tab,
+    PllConst pc, int pilot_shift, int *__restrict__ stereo_blk, StreamState *st, int n_streams) {
+  __shared__ float tab[257];
+  for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
+  __syncthreads();
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams) return;
+  StreamState &S = st[s];
+  const double *xin = base + (long long)s * base_stride + base_off;
+  double *out = raw + (long long)s * raw_stride + raw_off;
+  double phase = S.pll_phase, freq = S.pll_freq, freq_err = S.pll_freq_err, level = S.pll_level;
+  double i1 = S.bq_i_x1, i2 = S.bq_i_x2, q1 = S.bq_q_x1, q2 = S.bq_q_x2, lf1 = S.lf_x1;
+  int lock_cnt = S.lock_cnt, pilot_periods = S.pilot_periods;
+  unsigned long long pps_cnt = S.pps_cnt, sample_cnt = S.sample_cnt;
+  int n_pps = 0;
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  for (int b = 0; b < bt.nb; b++) {
+    const int n = bt.if_len[b];
+    if (n == 0) { stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay); continue; }
+    const int off = bt.if_off[b];
+    const bool was_locked = (lock_cnt >= pc.lock_delay);
+    const int pps_blk_start = n_pps;
+    for (int i = 0; i < n; i++) {
+      double psin, pcos;
+      sincos(phase, &psin, &pcos);
+      const double x = xin[off + i];
+      const double carrier = pilot_shift ? (2 * pcos * pcos - 1) : (2 * psin * pcos);
+      out[off + i] = (carrier * x) * 2.0;                 // demod_stereo: V7 then adjust_gain
+      const double phasor_i = psin * x, phasor_q = pcos * x;
+      double w = phasor_i - (pc.bq_a1 * i1 + pc.bq_a2 * i2);
+      const double new_i = pc.bq_b0 * w; i2 = i1; i1 = w;
+      w = phasor_q - (pc.bq_a1 * q1 + pc.bq_a2 * q2);
+      const double new_q = pc.bq_b0 * w; q2 = q1; q1 = w;
+      const double phase_err = (double)fast_atan2f_dev((float)new_q, (float)new_i, tab);
+      level = sqrt((new_i * new_i) + (new_q * new_q));
+      const double new_err = pc.lf_b0 * phase_err + pc.lf_b1 * lf1;   // a1 == 0
+      lf1 = phase_err;
+      freq_err = new_err;
+      freq += freq_err;
+      freq = fmax(pc.minfreq, fmin(pc.maxfreq, freq));
+      phase += freq;
+      if (phase > two_pi) {
+        phase -= two_pi;
+        pilot_periods++;
+        if (pilot_periods == pc.pilot_frequency) {
+          pilot_periods = 0;
+          if (was_locked) {
+            if (n_pps < FMR_MAX_PPS) {
+              PpsEventDev &ev = S.pps[n_pps];
+              ev.pps_index = pps_cnt;
+              ev.sample_index = sample_cnt + (unsigned long long)i;
+              ev.block_position = (double)i / (double)n;
+              ev.block = (unsigned)b;
+            }
+            n_pps++;
+            pps_cnt++;
+          }
+        }
+      }
+    }
+    if (2 * level > pc.minsignal) {                       // :154-160
+      if (lock_cnt < pc.lock_delay) lock_cnt += n;
+    } else {
+      lock_cnt = 0;
+    }
+    if (lock_cnt < pc.lock_delay) {                       // :163-167
+      pilot_periods = 0;
+      pps_cnt = 0;
+      n_pps = pps_blk_start;  // m_pps_events.clear(): this block's events only
+    }
+    sample_cnt += (unsigned long long)n;
+    stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay);
+  }
+  S.pll_phase = phase; S.pll_freq = freq; S.pll_freq_err = freq_err; S.pll_level = level;
+  S.bq_i_x1 = i1; S.bq_i_x2 = i2; S.bq_q_x1 = q1; S.bq_q_x2 = q2; S.lf_x1 = lf1;
+  S.lock_cnt = lock_cnt; S.pilot_periods = pilot_periods; S.pps_cnt = pps_cnt; S.sample_cnt = sample_cnt;
+  S.n_pps = n_pps < FMR_MAX_PPS ? n_pps : FMR_MAX_PPS;
+  S.stereo_detected = (lock_cnt >= pc.lock_delay);
+}
+
+// ---------------------------------------------------------------------------
+// K_deemph : LowPassFilterRC::process_inplace (Filter.cpp:214-221) on the mono
+// and the L-R signals at 384 kHz.  Linear first-order recurrence, one lane per
+// (stream, channel).
+// ---------------------------------------------------------------------------
+__global__ void k_deemph(double *__restrict__ base, long long base_stride, int base_off,
+                         double *__restrict__ raw, long long raw_stride, int raw_off, int n,
+                         double b0, double a1, int do_mono, int do_stereo, StreamState *st, int n_streams) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = t >> 1, ch = t & 1;
+  if (s >= n_streams) return;
+  if ((ch == 0 && !do_mono) || (ch == 1 && !do_stereo)) return;
+  double *p = ch ? raw + (long long)s * raw_stride + raw_off : base + (long long)s * base_stride + base_off;
+  double x1 = ch ? st[s].de_stereo_x1 : st[s].de_mono_x1;
+  for (int i = 0; i < n; i++) {
+    const double x0 = p[i] - a1 * x1;
+    p[i] = b0 * x0;                  // b1 == 0
+    x1 = x0;
+  }
+  if (ch) st[s].de_stereo_x1 = x1; else st[s].de_mono_x1 = x1;
+}
+
+// ---------------------------------------------------------------------------
+// Audio resampler (AudioResampler.cpp:37-61 stand-in), FP64, two channels:
+// stage A integer decimation, stage B polyphase.  Sequential accumulation in
+// tap order (bit-comparable with the oracle).
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_aud_decim(
+    const double *__restrict__ x0, const double *__restrict__ x1, long long x_stride, int x_off,
+    const double *__restrict__ hA, int NA, int D, long long top0, int count,
+    double *__restrict__ y0, double *__restrict__ y1, long long y_stride, int y_off) {
+  const int s = blockIdx.y, ch = blockIdx.z;
+  const int m = blockIdx.x * BLOCK + threadIdx.x;
+  if (m >= count) return;
+  const double *x = (ch ? x1 : x0) + (long long)s * x_stride + x_off;
+  double *y = (ch ? y1 : y0) + (long long)s * y_stride + y_off;
+  const double *xp = x + top0 + (long long)m * D;
+  double acc = 0.0;
+  for (int k = 0; k < NA; k++) acc += hA[k] * xp[-k];
+  y[m] = acc;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_aud_poly(
+    const double *__restrict__ m0, const double *__restrict__ m1, long long m_stride, long long mid_abs0,
+    const double *__restrict__ hB, int TB, unsigned LB, unsigned MB, unsigned long long t0, int count,
+    double *__restrict__ y0, double *__restrict__ y1, long long y_stride, int y_off) {
+  const int s = blockIdx.y, ch = blockIdx.z;
+  const int k = blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= count) return;
+  const double *mid = (ch ? m1 : m0) + (long long)s * m_stride;
+  double *y = (ch ? y1 : y0) + (long long)s * y_stride + y_off;
+  const unsigned long long t = t0 + (unsigned long long)k * MB;
+  const long long nk = (long long)(t / LB);
+  const unsigned p = (unsigned)(t % LB);
+  const double *h = hB + (size_t)p * TB;
+  const double *xp = mid + (nk - (TB >> 1) + 1 - mid_abs0);
+  double acc = 0.0;
+  for (int j = 0; j < TB; j++) acc += h[j] * xp[j];
+  y[k] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// K_pcut : LowPassFilterFirAudio (Filter.cpp:107-163), the 19 kHz pilot-cut
+// FIR at 48 kHz, per audio block incl. the block-head path (hazard H1).
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_pilotcut(
+    const double *__restrict__ a0, const double *__restrict__ a1, long long a_stride, int a_halo,
+    BlockTab bt, const double *__restrict__ coeff, int ntaps,
+    double *__restrict__ p0, double *__restrict__ p1, long long p_stride) {
+  const int b = blockIdx.x, s = blockIdx.y, ch = blockIdx.z;
+  const int n = bt.au_len[b];
+  if (n == 0) return;
+  const double *x = (ch ? a1 : a0) + (long long)s * a_stride + a_halo + bt.au_off[b];
+  double *y = (ch ? p1 : p0) + (long long)s * p_stride + bt.au_off[b];
+  const int order = ntaps - 1, half_order = (order - 1) / 2;
+  for (int i = threadIdx.x; i < n; i += BLOCK) {
+    double acc = 0.0;
+    if (i < order) {
+      for (int j = i + 1; j <= order; j++) acc += x[i - j] * coeff[j];
+      for (int j = 1; j <= i; j++) acc += x[i - j] * coeff[j];
+    } else {
+      for (int k = 0; k <= half_order; k++) acc += (x[i - k] + x[i - (order - k)]) * coeff[k];
+      if ((order % 2) == 0) acc += x[i - order / 2] * coeff[order / 2];
+    }
+    y[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K_out : DC block (HighPassFilterIir, Filter.cpp:243-250,301-311) on mono and
+// L-R -- two serial lanes per stream -- then the output mux of
+// FmDecode.cpp:194-220,242-283 on all lanes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fm_out(
+    double *__restrict__ p0, double *__restrict__ p1, long long p_stride, BlockTab bt, int n_audio,
+    double b0, double b1, double b2, double a1, double a2, int stereo, int pilot_shift,
+    const int *__restrict__ stereo_blk, double *__restrict__ audio, long long audio_stride, StreamState *st) {
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
+  double *m = p0 + (long long)s * p_stride;
+  double *d = p1 + (long long)s * p_stride;
+  if (lane < (stereo ? 2 : 1)) {
+    double *p = lane ? d : m;
+    double x1 = lane ? st[s].dc_st_x1 : st[s].dc_mono_x1;
+    double x2 = lane ? st[s].dc_st_x2 : st[s].dc_mono_x2;
+    for (int i = 0; i < n_audio; i++) {
+      const double x0 = p[i] - (a1 * x1 + a2 * x2);
+      p[i] = b0 * x0 + b1 * x1 + b2 * x2;
+      x2 = x1; x1 = x0;
+    }
+    if (lane) { st[s].dc_st_x1 = x1; st[s].dc_st_x2 = x2; }
+    else { st[s].dc_mono_x1 = x1; st[s].dc_mono_x2 = x2; }
+  }
+  __syncthreads();
+  double *out = audio + (long long)s * audio_stride;
+  if (!stereo) {
+    for (int i = lane; i < n_audio; i += 64) out[i] = m[i];
+    return;
+  }
+  for (int b = 0; b < bt.nb; b++) {
+    const int n = bt.au_len[b], off = bt.au_off[b];
+    const int locked = stereo_blk[(long long)s * bt.nb + b];
+    for (int i = lane; i < n; i += 64) {
+      double l, r;
+      if (locked) {
+        if (pilot_shift) { l = r = d[off + i]; }
+        else {
+          const double mm = m[off + i];
+          const double ss = 1.017 * d[off + i];
+          l = mm + ss; r = mm - ss;
+        }
+      } else {
+        if (pilot_shift) { l = r = 0.0; }
+        else { l = r = m[off + i]; }
+      }
+      out[2 * (off + i)] = l;
+      out[2 * (off + i) + 1] = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K_am_tail : AmDecoder audio tail, serial per stream: DC block
+// (AmDecode.cpp:194) -> AfSimpleAgc (AfSimpleAgc.cpp:36-56) -> de-emphasis
+// (AmDecode.cpp:212-214, AM mode only).
+// ---------------------------------------------------------------------------
+__global__ void k_am_tail(const double *__restrict__ demod, long long d_stride, int n,
+                          double hb0, double hb1, double hb2, double ha1, double ha2,
+                          double af_init, double af_max, double af_ref, double af_rate,
+                          double de_b0, double de_a1, int do_deemph,
+                          double *__restrict__ audio, long long audio_stride, StreamState *st, int n_streams) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams) return;
+  const double *x = demod + (long long)s * d_stride;
+  double *out = audio + (long long)s * audio_stride;
+  double x1 = st[s].am_dc_x1, x2 = st[s].am_dc_x2, g = st[s].af_gain, e1 = st[s].am_de_x1;
+  for (int i = 0; i < n; i++) {
+    const double x0 = x[i] - (ha1 * x1 + ha2 * x2);
+    const double v = hb0 * x0 + hb1 * x1 + hb2 * x2;
+    x2 = x1; x1 = x0;
+    const double xg = v * g;
+    double o = xg * af_ref;
+    const double z = 1.0 + (af_rate * (1.0 - (xg * xg)));
+    g *= z;
+    if (!isfinite(g)) g = af_init;
+    else if (g > af_max) g = af_max;
+    if (do_deemph) {
+      const double w = o - de_a1 * e1;
+      o = de_b0 * w;
+      e1 = w;
+    }
+    out[i] = o;
+  }
+  st[s].am_dc_x1 = x1; st[s].am_dc_x2 = x2; st[s].af_gain = g; st[s].am_de_x1 = e1;
+}
+
+}  // namespace fmr

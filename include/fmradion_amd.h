@@ -1,0 +1,159 @@
+/*
+ * fmradion_amd.h -- C-ABI of the MI355X-native FM/AM demodulation hot path.
+ *
+ * Drop-in boundary: these entry points are what a
+ * binding of the reference's stream loop (main.cpp:879-1002) needs in order
+ * to replace
+ *     FourthConverterIQ::process   include/FourthConverterIQ.h:38   (main.cpp:916)
+ *     IfResampler::process         include/IfResampler.h:35-38      (main.cpp:923)
+ *     FmDecoder::process + getters include/FmDecode.h:63-105        (main.cpp:956-957)
+ *     AmDecoder::process + getters include/AmDecode.h:48-65         (main.cpp:971-972)
+ * Plain pointers and sizes only; no C++ or torch types.  The C++ facade with
+ * the reference's class names and signatures is
+ * airspy-fmradion_amd/host/fmradion_facade.hpp; the reference-side binding is
+ * shown in INTEGRATION.md.
+ *
+ * One object = one decoder chain for `n_streams` independent IQ streams that
+ * all see the same block lengths (batch dimension, config 5 of BASELINE.json).
+ * All compute runs in hand-written HIP kernels for gfx950; there is no CPU
+ * fallback: every call fails with FMR_ERR_NO_DEVICE when no GPU is present.
+ *
+ * Error convention: 0 = FMR_OK, negative = error; `*n_out == 0` is the
+ * reference's "nothing yet" (empty output vector, FmDecode.cpp:89-92,185-188).
+ */
+#ifndef FMRADION_AMD_H
+#define FMRADION_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  FMR_OK = 0,
+  FMR_ERR_NO_DEVICE = -1,     /* no HIP device / HIP runtime error at create */
+  FMR_ERR_BAD_ARG = -2,
+  FMR_ERR_UNSUPPORTED = -3,   /* e.g. resampling ratio outside the design range */
+  FMR_ERR_CAPACITY = -4,      /* output buffer or configured maximum too small */
+  FMR_ERR_HIP = -5            /* HIP runtime failure; see fmr_last_error() */
+};
+
+/* ModType values follow include/SoftFM.h:49 */
+enum { FMR_MODE_FM = 0, FMR_MODE_NBFM = 1, FMR_MODE_AM = 2, FMR_MODE_DSB = 3 };
+
+/* PilotPhaseLock::PpsEvent (include/PilotPhaseLock.h:40-44) + the index of the
+ * block (within the call) that produced it. */
+typedef struct {
+  uint64_t pps_index;
+  uint64_t sample_index;
+  double block_position;
+  uint32_t block;
+  uint32_t stream;
+} fmr_pps_event;
+
+/* Configuration of one chain.  Zero-initialise, then set fields. */
+typedef struct {
+  int device;                 /* HIP device ordinal */
+  int n_streams;              /* >= 1 independent IQ streams (batch) */
+  int mode;                   /* FMR_MODE_FM | FMR_MODE_AM | FMR_MODE_DSB */
+  double input_rate;          /* sample rate of the IQ handed to process */
+  /* Front end.  0 = the decoder is fed at its own rate (384 kHz FM / 48 kHz
+   * AM) and no IfResampler runs (main.cpp:778 enable_downsampling=false). */
+  int enable_resampler;
+  int enable_fourth_down;     /* FourthConverterIQ(false) before the resampler */
+  /* FmDecoder ctor arguments (include/FmDecode.h:63-64) */
+  int fmfilter_enable;
+  const float *filter_coeff;  /* FM IF filter / AM filter taps (caller-supplied, main.cpp:780-810) */
+  int n_filter_coeff;
+  int stereo;
+  double deemphasis_us;       /* 50 / 75 / 0 */
+  int pilot_shift;
+  unsigned multipath_stages;
+  /* capacity */
+  size_t max_block_len;       /* largest input block (samples) per call */
+  int max_blocks;             /* largest number of blocks per call */
+} fmr_config;
+
+/* Per-stream status after the most recent call (getters of FmDecode.h:77-105 /
+ * AmDecode.h:56-65). */
+typedef struct {
+  float if_rms;
+  float baseband_mean;        /* FM: get_tuning_offset() = baseband_mean * 75000 */
+  float baseband_level;
+  double pilot_level;         /* = 2 * m_pilot_level */
+  int stereo_detected;
+  float if_agc_gain;
+  double af_agc_gain;         /* AM only */
+  double multipath_error;
+  double pll_freq_err;
+  uint32_t multipath_resets;  /* blocks whose equaliser output was discarded */
+} fmr_status;
+
+typedef struct fmr_chain fmr_chain;
+
+int fmr_create(const fmr_config *cfg, fmr_chain **out);
+void fmr_destroy(fmr_chain *c);
+const char *fmr_last_error(void);
+const char *fmr_version(void);
+
+/* Design introspection of the resampler stand-in (DESIGN.md "Resampler
+ * specification").  which = 0:D 1:NA 2:LB 3:MB 4:TB ; -1 when no resampler. */
+long long fmr_resampler_info(const fmr_chain *c, int which);
+
+/* --- single block, host buffers: the shape of FmDecoder::process(IQSampleVector,
+ * SampleVector&) (FmDecode.h:74) for stream 0 of a 1-stream chain.
+ * iq: n interleaved complex float samples.  audio: doubles (interleaved L/R when
+ * stereo).  */
+int fmr_process(fmr_chain *c, const float *iq, size_t n, double *audio,
+                size_t audio_cap, size_t *n_audio);
+
+/* --- batched blocks, host buffers.  iq holds n_streams rows of `stream_stride`
+ * complex samples; block_len[0..n_blocks) are consecutive block lengths inside
+ * each row.  audio holds n_streams rows of audio_stride doubles;
+ * audio_len[b] receives the number of doubles block b produced (same for all
+ * streams).  Semantics = n_blocks sequential process() calls per stream. */
+int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride,
+                       const uint32_t *block_len, int n_blocks, double *audio,
+                       size_t audio_stride, uint32_t *audio_len);
+
+/* --- same with device-resident buffers (HBM in, HBM out); asynchronous on the
+ * chain's HIP stream unless sync != 0. */
+int fmr_process_blocks_device(fmr_chain *c, const float *d_iq,
+                              size_t stream_stride, const uint32_t *block_len,
+                              int n_blocks, double *d_audio, size_t audio_stride,
+                              uint32_t *audio_len, int sync);
+int fmr_synchronize(fmr_chain *c);
+
+/* --- front end only: IfResampler::process (IfResampler.h:35-38).  Valid on a
+ * chain created with enable_resampler; bypasses the decoder.  Host buffers. */
+int fmr_resample(fmr_chain *c, const float *iq, size_t n, float *out_iq,
+                 size_t out_cap, size_t *n_out);
+
+int fmr_get_status(fmr_chain *c, int stream, fmr_status *st);
+/* PPS events of the most recent call (FmDecode.h:92); returns the count. */
+int fmr_get_pps_events(fmr_chain *c, int stream, fmr_pps_event *ev, int cap);
+/* get_multipath_coefficients (FmDecode.h:103): interleaved re,im; returns order */
+int fmr_get_multipath_coefficients(fmr_chain *c, int stream, float *coeff, int cap);
+
+/* Debug taps for stage-level parity tests: copies an intermediate vector of the
+ * most recent call to the host.  which: 0 = IF samples entering the decoder
+ * (complex float, 2 floats each), 1 = discriminator output (float),
+ * 2 = stereo difference after demod+de-emphasis (double), 3 = mono after
+ * de-emphasis (double), 4 = AGC gain sequence (float).  Returns element count. */
+long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t cap_bytes);
+
+/* Kernel timing of the most recent call, measured with HIP events on the
+ * chain's stream: fills names/ms for up to cap kernels, returns the count. */
+int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap);
+void fmr_enable_kernel_timing(fmr_chain *c, int enable);
+
+/* Filter tables of FilterParameters (include/FilterParameters.h:31-49), by name
+ * e.g. "jj1bdx_fm_384kHz_medium"; returns the length, *is_double tells the type. */
+int fmr_filter_table(const char *name, const void **data, int *is_double);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,349 @@
+"""GPU parity tests: the HIP chain (through the C-ABI) against the CPU oracle on
+the same seeded inputs.  Tolerances (north star: audio within 1e-5 RMS):
+  * decoder fed identical IF samples: audio RMS error < 1e-6 (most stages are
+    arithmetic-identical; libm vs ocml atan2f / sincos differ in the last ulp)
+  * front end (fp32 FMA on the GPU vs fp64 accumulation in the oracle):
+    IF relative RMS error < 2e-6
+  * end to end from 10 MS/s IQ: audio RMS error < 1e-5 (measured ~1e-7)
+Run on the GPU box:  python -m pytest tests -m gpu
+"""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as ora
+import siggen
+from conftest import load_filter
+
+pytestmark = pytest.mark.gpu
+
+fmr = importlib.import_module("airspy-fmradion_amd")
+REPORT = {}
+
+
+def _report(key, **kw):
+    REPORT[key] = {k: (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in kw.items()}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1)
+
+
+def rms(a):
+    a = np.asarray(a)
+    return float(np.sqrt(np.mean(np.abs(a) ** 2))) if a.size else 0.0
+
+
+# ------------------------------------------------------------------ front end
+@pytest.mark.parametrize("fin,fout_mode,blk,nblk", [(10e6, "fm", 65536, 6), (1e6, "fm", 2048, 40), (384e3, "am", 2048, 40)])
+def test_if_resampler(fin, fout_mode, blk, nblk):
+    fout = 384e3 if fout_mode == "fm" else 48e3
+    x = siggen.fm_stereo_iq(blk * nblk, fin) if fout_mode == "fm" else siggen.am_iq(blk * nblk, fin)
+    # a front-end-only chain runs at the FM rate; for the AM ratio use an AM chain's front end via debug tap
+    if fout_mode == "fm":
+        ch = fmr.Chain(mode=fmr.MODE_NONE, input_rate=fin, enable_resampler=True, max_block_len=blk)
+        got = [ch.resample(b) for b in siggen.blocks(x, blk)]
+    else:
+        ch = fmr.Chain(mode=fmr.MODE_AM, input_rate=fin, enable_resampler=True, max_block_len=blk,
+                       filter_coeff=load_filter("jj1bdx_am_48khz_narrow"))
+        got = []
+        for b in siggen.blocks(x, blk):
+            ch.process(b)
+            got.append(ch.debug_read(0))
+    r = ora.IfResampler(fin, fout)
+    ref = [r.process(b) for b in siggen.blocks(x, blk)]
+    assert [len(g) for g in got] == [len(q) for q in ref]
+    g, q = np.concatenate(got), np.concatenate(ref)
+    rel = rms(g - q) / rms(q)
+    _report(f"if_resampler_{int(fin)}_{fout_mode}", n=len(q), rel_rms=rel, info=ch.resampler_info())
+    assert rel < 2e-6
+    ch.close()
+
+
+def test_fourth_converter_front_end():
+    blk, nblk = 16384, 4
+    x = siggen.fm_stereo_iq(blk * nblk, 1.536e6)
+    ch = fmr.Chain(mode=fmr.MODE_NONE, input_rate=1.536e6, enable_resampler=True, fourth_down=True, max_block_len=blk)
+    got = np.concatenate([ch.resample(b) for b in siggen.blocks(x, blk)])
+    f4, r = ora.FourthConverterIQ(False), ora.IfResampler(1.536e6, 384e3)
+    ref = np.concatenate([r.process(f4.process(b)) for b in siggen.blocks(x, blk)])
+    assert len(got) == len(ref)
+    rel = rms(got - ref) / rms(ref)
+    _report("fourth_front_end", rel_rms=rel)
+    assert rel < 2e-6
+    ch.close()
+
+
+# ------------------------------------------------------------ FM decoder at 384 kHz
+def _fm_case(name, x, blk, batch, *, fir=None, stereo=True, deemph=50.0, pilot_shift=False, stages=0,
+             tol=1e-6, pilotcut=None):
+    coeff = fmr.DELAY_3TAPS if fir is None else fir
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=384e3, enable_resampler=False, fmfilter_enable=fir is not None,
+                   filter_coeff=coeff, stereo=stereo, deemphasis_us=deemph, pilot_shift=pilot_shift,
+                   multipath_stages=stages, max_block_len=blk, max_blocks=batch)
+    fm = ora.FmDecoder(fir is not None, coeff, stereo, deemph, pilot_shift, stages, pilotcut)
+    nblk = len(x) // blk
+    got, ref = [], []
+    disc_err = base_err = raw_err = 0.0
+    for i in range(0, nblk, batch):
+        nb = min(batch, nblk - i)
+        seg = x[i * blk:(i + nb) * blk]
+        a, alen = ch.process_blocks(seg[None, :], [blk] * nb)
+        got.append(a[0])
+        rlen = []
+        for b in siggen.blocks(seg, blk):
+            r = fm.process(b)
+            ref.append(r)
+            rlen.append(len(r))
+        assert list(alen) == rlen
+        # stage taps of the last block of the batch
+        d_ref = fm.debug_vector(0, blk)
+        d_got = ch.debug_read(1)[-blk:]
+        disc_err = max(disc_err, rms(d_got - d_ref))
+        base_err = max(base_err, rms(ch.debug_read(3)[-blk:] - fm.debug_vector(2, blk)))
+        if stereo:
+            raw_err = max(raw_err, rms(ch.debug_read(2)[-blk:] - fm.debug_vector(1, blk)))
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    assert len(got) == len(ref)
+    err = rms(got - ref)
+    st = ch.status()
+    _report(name, n_audio=len(ref), audio_rms_err=err, audio_rms=rms(ref), disc_rms_err=disc_err,
+            mono384_rms_err=base_err, stereo384_rms_err=raw_err, if_rms=st.if_rms, ref_if_rms=fm.get_if_rms(),
+            pilot=st.pilot_level, ref_pilot=fm.get_pilot_level(), locked=st.stereo_detected,
+            ref_locked=int(fm.stereo_detected()), agc=st.if_agc_gain, ref_agc=fm.get_if_agc_gain(),
+            mpf_err=st.multipath_error, ref_mpf_err=fm.get_multipath_error(), mpf_resets=st.multipath_resets)
+    assert err < tol, (name, err)
+    assert st.stereo_detected == int(fm.stereo_detected())
+    assert st.if_rms == pytest.approx(fm.get_if_rms(), rel=1e-5)
+    assert st.baseband_level == pytest.approx(fm.get_baseband_level(), rel=1e-4, abs=1e-7)
+    assert st.baseband_mean * 75000.0 == pytest.approx(fm.get_tuning_offset(), rel=1e-3, abs=1e-2)
+    assert st.if_agc_gain == pytest.approx(fm.get_if_agc_gain(), rel=1e-5)
+    if stereo:
+        assert st.pilot_level == pytest.approx(fm.get_pilot_level(), rel=1e-6, abs=1e-9)
+    return ch, fm, got, ref
+
+
+def test_fm_stereo_decoder_384k(pilotcut):
+    x = siggen.fm_stereo_iq(120 * 2048, 384e3)
+    ch, fm, got, ref = _fm_case("fm_stereo_384k", x, 2048, 8, pilotcut=pilotcut)
+    assert fm.stereo_detected()
+    ch.close()
+
+
+def test_fm_stereo_single_block_calls_equal_batched(pilotcut):
+    x = siggen.fm_stereo_iq(24 * 2048, 384e3)
+    ch1 = fmr.Chain(mode=fmr.MODE_FM, input_rate=384e3, stereo=True, max_block_len=2048, max_blocks=1)
+    ch8 = fmr.Chain(mode=fmr.MODE_FM, input_rate=384e3, stereo=True, max_block_len=2048, max_blocks=8)
+    a1 = np.concatenate([ch1.process(b) for b in siggen.blocks(x, 2048)])
+    a8 = np.concatenate([ch8.process_blocks(x[None, i:i + 8 * 2048], [2048] * 8)[0][0] for i in range(0, len(x), 8 * 2048)])
+    np.testing.assert_array_equal(a1, a8)
+    ch1.close(); ch8.close()
+
+
+def test_fm_medium_filter(pilotcut, fm_medium):
+    x = siggen.fm_stereo_iq(60 * 2517, 384e3)
+    ch, *_ = _fm_case("fm_medium_filter_2517", x, 2517, 6, fir=fm_medium, pilotcut=pilotcut)
+    ch.close()
+
+
+def test_fm_mono_75us(pilotcut):
+    x = siggen.fm_mono_iq(40 * 2048, 384e3)
+    ch, *_ = _fm_case("fm_mono_75us", x, 2048, 5, stereo=False, deemph=75.0, pilotcut=pilotcut)
+    ch.close()
+
+
+def test_fm_pilot_shift(pilotcut):
+    x = siggen.fm_stereo_iq(110 * 2048, 384e3)
+    ch, *_ = _fm_case("fm_pilot_shift", x, 2048, 10, pilot_shift=True, pilotcut=pilotcut)
+    ch.close()
+
+
+def test_fm_ragged_and_tiny_blocks(pilotcut):
+    """Ragged block lengths incl. blocks shorter than the FIR order and the halos."""
+    x = siggen.fm_stereo_iq(30000, 384e3)
+    lens = [1, 7, 100, 2048, 3, 126, 127, 128, 5000, 64, 2517, 10, 4096]
+    lens = lens + [30000 - sum(lens)]
+    fir = load_filter("jj1bdx_fm_384kHz_narrow")
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=384e3, fmfilter_enable=True, filter_coeff=fir, stereo=True,
+                   max_block_len=30000, max_blocks=4)
+    fm = ora.FmDecoder(True, fir, True, 50.0, False, 0, pilotcut)
+    pos, got, ref = 0, [], []
+    for i in range(0, len(lens), 4):
+        ls = lens[i:i + 4]
+        seg = x[pos:pos + sum(ls)]
+        a, alen = ch.process_blocks(seg[None, :], ls)
+        got.append(a[0])
+        p = 0
+        rl = []
+        for l in ls:
+            r = fm.process(seg[p:p + l]); p += l
+            ref.append(r); rl.append(len(r))
+        assert list(alen) == rl
+        pos += sum(ls)
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    err = rms(got - ref)
+    _report("fm_ragged", audio_rms_err=err)
+    assert err < 1e-6
+    ch.close()
+
+
+def test_fm_multipath_config4(pilotcut):
+    """-E 64 on the 2-ray channel: 100 warm-up blocks then the equaliser (config 4 at the IF rate)."""
+    clean = siggen.fm_stereo_iq(150 * 2517, 384e3)
+    x = siggen.two_ray(clean, 20)
+    ch, fm, got, ref = _fm_case("fm_multipath_E64", x, 2517, 10, stages=64, tol=1e-5, pilotcut=pilotcut)
+    c_got, c_ref = ch.multipath_coefficients(), fm.get_multipath_coefficients()
+    cerr = rms(c_got - c_ref)
+    _report("fm_multipath_E64_coeff", coeff_rms_err=cerr, coeff_rms=rms(c_ref))
+    assert cerr < 1e-4
+    assert abs(ch.status().multipath_error) < 0.1
+    ch.close()
+
+
+def test_fm_multipath_nan_recovery(pilotcut):
+    """A NaN burst makes the equaliser fail; taps are re-initialised and the block falls back
+    to the un-equalised IF (FmDecode.cpp:116-123)."""
+    x = siggen.two_ray(siggen.fm_stereo_iq(112 * 2048, 384e3), 20).copy()
+    x[105 * 2048 + 77] = np.nan + 0j
+    coeff = fmr.DELAY_3TAPS
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=384e3, stereo=True, multipath_stages=8, max_block_len=2048, max_blocks=4)
+    fm = ora.FmDecoder(False, coeff, True, 50.0, False, 8, pilotcut)
+    got, ref = [], []
+    for i in range(0, 112, 4):
+        seg = x[i * 2048:(i + 4) * 2048]
+        got.append(ch.process_blocks(seg[None, :], [2048] * 4)[0][0])
+        ref += [fm.process(b) for b in siggen.blocks(seg, 2048)]
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), ok)
+    assert ch.status().multipath_resets >= 1
+    err = rms(got[ok] - ref[ok])
+    _report("fm_multipath_nan", audio_rms_err=err, resets=ch.status().multipath_resets)
+    assert err < 1e-5
+    ch.close()
+
+
+# ------------------------------------------------------------------------- AM
+@pytest.mark.parametrize("mode", ["am", "dsb"])
+def test_am_decoder_48k(mode, am_narrow):
+    m = fmr.MODE_AM if mode == "am" else fmr.MODE_DSB
+    x = siggen.am_iq(200 * 256, 48e3)
+    ch = fmr.Chain(mode=m, input_rate=48e3, filter_coeff=am_narrow, max_block_len=256, max_blocks=10)
+    am = ora.AmDecoder(am_narrow, ora.MODE_AM if mode == "am" else ora.MODE_DSB)
+    got, ref = [], []
+    for i in range(0, 200, 10):
+        seg = x[i * 256:(i + 10) * 256]
+        a, alen = ch.process_blocks(seg[None, :], [256] * 10)
+        got.append(a[0])
+        ref += [am.process(b) for b in siggen.blocks(seg, 256)]
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    err = rms(got - ref)
+    st = ch.status()
+    _report(f"{mode}_48k", audio_rms_err=err, audio_rms=rms(ref), if_agc=st.if_agc_gain, ref_if_agc=am.get_if_agc_current_gain(),
+            af_agc=st.af_agc_gain, ref_af_agc=am.get_af_agc_current_gain())
+    assert len(got) == len(ref) and err < 1e-6
+    assert st.if_agc_gain == pytest.approx(am.get_if_agc_current_gain(), rel=1e-5)
+    assert st.af_agc_gain == pytest.approx(am.get_af_agc_current_gain(), rel=1e-6)
+    assert st.if_rms == pytest.approx(am.get_if_rms(), rel=1e-5)
+    ch.close()
+
+
+def test_am_config3_full_chain(am_narrow):
+    """Config 3: 384 kS/s IQ -> IfResampler(48 k) -> AmDecoder narrow."""
+    x = siggen.am_iq(300 * 2048, 384e3)
+    ch = fmr.Chain(mode=fmr.MODE_AM, input_rate=384e3, enable_resampler=True, filter_coeff=am_narrow,
+                   max_block_len=2048, max_blocks=10)
+    r, am = ora.IfResampler(384e3, 48e3), ora.AmDecoder(am_narrow, ora.MODE_AM)
+    got, ref = [], []
+    for i in range(0, 300, 10):
+        seg = x[i * 2048:(i + 10) * 2048]
+        got.append(ch.process_blocks(seg[None, :], [2048] * 10)[0][0])
+        ref += [am.process(r.process(b)) for b in siggen.blocks(seg, 2048)]
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    assert len(got) == len(ref)
+    err = rms(got - ref)
+    _report("am_config3", audio_rms_err=err, audio_rms=rms(ref))
+    assert err < 1e-5
+    ch.close()
+
+
+# ------------------------------------------------------- full chains from raw IQ
+def test_fm_mono_config1(pilotcut):
+    """Config 1: 1 MS/s mono FM, FileSource block length 2048."""
+    x = siggen.fm_mono_iq(400 * 2048, 1e6)
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=1e6, enable_resampler=True, stereo=False, max_block_len=2048, max_blocks=20)
+    r = ora.IfResampler(1e6, 384e3)
+    fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, False, 50.0, False, 0, pilotcut)
+    got, ref = [], []
+    for i in range(0, 400, 20):
+        seg = x[i * 2048:(i + 20) * 2048]
+        a, alen = ch.process_blocks(seg[None, :], [2048] * 20)
+        got.append(a[0])
+        rr = [fm.process(r.process(b)) for b in siggen.blocks(seg, 2048)]
+        assert list(alen) == [len(q) for q in rr]
+        ref += rr
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    err = rms(got - ref)
+    _report("fm_mono_config1", audio_rms_err=err, audio_rms=rms(ref), n=len(ref))
+    assert err < 1e-5
+    ch.close()
+
+
+def test_fm_stereo_config2(pilotcut):
+    """Config 2: 10 MS/s FM stereo, 65536-sample blocks, PLL on; 0.85 s so that the lock happens."""
+    nblk, blk, batch = 130, 65536, 10
+    x = siggen.fm_stereo_iq(nblk * blk, 10e6)
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=batch)
+    r = ora.IfResampler(10e6, 384e3)
+    fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
+    got, ref = [], []
+    for i in range(0, nblk, batch):
+        seg = x[i * blk:(i + batch) * blk]
+        a, alen = ch.process_blocks(seg[None, :], [blk] * batch)
+        got.append(a[0])
+        rr = [fm.process(r.process(b)) for b in siggen.blocks(seg, blk)]
+        assert list(alen) == [len(q) for q in rr]
+        ref += rr
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    err = rms(got - ref)
+    tail = slice(len(ref) - 2 * 9600, len(ref))
+    st = ch.status()
+    _report("fm_stereo_config2", audio_rms_err=err, audio_rms_err_postlock=rms(got[tail] - ref[tail]),
+            audio_rms=rms(ref), n=len(ref), locked=st.stereo_detected, pilot=st.pilot_level)
+    assert fm.stereo_detected() and st.stereo_detected == 1
+    assert err < 1e-5
+    ch.close()
+
+
+def test_multi_stream_batch(pilotcut):
+    """Three independent streams in one chain (the sharding unit of config 5)."""
+    S, nblk, blk = 3, 12, 65536
+    xs = np.stack([siggen.fm_stereo_iq(nblk * blk, 10e6, stream_id=s) for s in range(S)])
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, n_streams=S,
+                   max_block_len=blk, max_blocks=4)
+    got = [[] for _ in range(S)]
+    for i in range(0, nblk, 4):
+        a, alen = ch.process_blocks(xs[:, i * blk:(i + 4) * blk], [blk] * 4)
+        for s in range(S):
+            got[s].append(a[s])
+    for s in range(S):
+        r = ora.IfResampler(10e6, 384e3)
+        fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
+        ref = np.concatenate([fm.process(r.process(b)) for b in siggen.blocks(xs[s], blk)])
+        g = np.concatenate(got[s])
+        assert len(g) == len(ref)
+        err = rms(g - ref)
+        _report(f"multi_stream_{s}", audio_rms_err=err)
+        assert err < 1e-5
+        assert ch.status(s).if_agc_gain == pytest.approx(fm.get_if_agc_gain(), rel=1e-4)
+    ch.close()
+
+
+def test_library_is_the_hip_path():
+    """The product never routes through the oracle: its shared object holds gfx950 code objects."""
+    data = open(fmr.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    assert b"ora_fm_process" not in data
