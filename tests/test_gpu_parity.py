@@ -65,7 +65,9 @@ def test_if_resampler(fin, fout_mode, blk, nblk):
 
 def test_fourth_converter_front_end():
     blk, nblk = 16384, 4
+    # zero-IF receivers deliver the station at +fs/4 (main.cpp:912-919): put it there
     x = siggen.fm_stereo_iq(blk * nblk, 1.536e6)
+    x = (x * (1j ** (np.arange(len(x)) % 4))).astype(np.complex64)
     ch = fmr.Chain(mode=fmr.MODE_NONE, input_rate=1.536e6, enable_resampler=True, fourth_down=True, max_block_len=blk)
     got = np.concatenate([ch.resample(b) for b in siggen.blocks(x, blk)])
     f4, r = ora.FourthConverterIQ(False), ora.IfResampler(1.536e6, 384e3)
