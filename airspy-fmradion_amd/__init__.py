@@ -50,6 +50,10 @@ class Status(C.Structure):
         ("pilot_level", C.c_double), ("stereo_detected", C.c_int), ("if_agc_gain", C.c_float),
         ("af_agc_gain", C.c_double), ("multipath_error", C.c_double), ("pll_freq_err", C.c_double),
         ("multipath_resets", C.c_uint32),
+        ("agc_iterations", C.c_int), ("pll_iterations", C.c_int), ("agc_fallback", C.c_int),
+        ("pll_fallback", C.c_int), ("pll_residual", C.c_double),
+        ("agc_residual_history", C.c_float * 16), ("pll_residual_history", C.c_double * 16),
+        ("pll_residual_components", C.c_double * 8),
     ]
 
 
@@ -156,9 +160,9 @@ class Chain:
             raise FmrError(f"fmr_create failed ({rc}): {lib().fmr_last_error().decode()}")
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().fmr_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.fmr_destroy(self.h)
+        self.h = None
 
     def __del__(self):
         self.close()

@@ -12,6 +12,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -20,6 +22,7 @@
 #include "../../include/fmradion_amd.h"
 #include "design.hpp"
 #include "kernels.hpp"
+#include "kernels_par.hpp"
 
 namespace {
 #include "filter_tables.inc"
@@ -50,6 +53,9 @@ constexpr double kAmRate = 48000.0;    // AmDecoder::internal_rate_pcm (AmDecode
 constexpr double kIfAtten = 140.0;     // resampler spec, DESIGN.md
 constexpr double kAudioAtten = 180.0;
 constexpr int FMR_MODE_NONE = -1;
+// chunk lengths of the time-parallel recurrences (kernels_par.hpp)
+constexpr int C_AGC = 256, C_PLL = 512, C_DC = 64, C_DE = 512;
+constexpr int K_AGC_ITERS = 10, K_PLL_ITERS = 10;
 
 template <class T>
 struct DevBuf {
@@ -92,10 +98,20 @@ struct fmr_chain {
   DevBuf<double> d_base, d_raw, d_am0, d_am1, d_a10, d_a11, d_pc0, d_pc1, d_audio, d_ahA, d_ahB, d_pilotcut;
   DevBuf<int> d_tab, d_mpf_ok, d_stereo_blk;
   DevBuf<StreamState> d_state;
+  // time-parallel recurrences
+  bool serial_mode = false;            // FMR_SERIAL=1: plain serial kernels (A/B, debugging)
+  int H_b = 0;                         // halo of the pre-de-emphasis buffers (>= warm-up)
+  size_t max_ck = 0, max_agc_nc = 0, max_dc_nc = 0;
+  DevBuf<double> d_base_de, d_raw_de, d_pll_nodes, d_pll_G, d_pll_M, d_ck_level, d_agc_M, d_dc_G, d_dc_start;
+  DevBuf<float> d_agc_nodes, d_agc_G;
+  DevBuf<int> d_ck_wraps;
+  DevBuf<IterFlags> d_flags;
+  std::vector<IterFlags> h_flags;
   // block tables: ring of pinned host slots + device slots so that queued
   // asynchronous calls never overwrite a table that is still being copied
   static constexpr int kTabSlots = 8;
-  int *h_tab_all = nullptr;  // pinned, kTabSlots * 5 * max_blocks
+  int *h_tab_all = nullptr;  // pinned, kTabSlots * tab_ints
+  size_t tab_ints = 0;       // 5*max_blocks block table + 3*max_ck chunk table + (max_blocks+1) first-chunk table
   hipEvent_t tab_ev[kTabSlots] = {};
   int tab_slot = 0;
   std::vector<StreamState> h_state;
@@ -103,6 +119,7 @@ struct fmr_chain {
   PllConst pllc{};
   Iir1Coef deemph{}, am_deemph{};
   BiquadCoef dcblock{}, am_dcblock{};
+  double dc_ac[4] = {1, 0, 0, 1};       // A^C_DC of the DC-block biquad (state transition over one chunk)
   float agc_init = 1.f, agc_max = 1e5f, agc_rate = 1e-4f;
   float disc_nf = 1.f, disc_bound = 1.f;
   // last call
@@ -121,6 +138,9 @@ struct fmr_chain {
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
+    d_ck_level.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -210,9 +230,23 @@ int fmr_chain::init(const fmr_config *c) {
     st.af_gain = 1.0;
   }
   if ((rc = upload(d_state, h_state.data(), h_state.size()))) return rc;
-  HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * 5 * (size_t)max_blocks));
+  max_ck = max_if / C_PLL + (size_t)max_blocks + 2;
+  tab_ints = 5 * (size_t)max_blocks + 3 * max_ck + (size_t)max_blocks + 1;
+  HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * tab_ints));
   for (auto &e : tab_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  if ((rc = d_tab.alloc((size_t)kTabSlots * 5 * (size_t)max_blocks))) return rc;
+  if ((rc = d_tab.alloc((size_t)kTabSlots * tab_ints))) return rc;
+  h_flags.assign(S, IterFlags{});
+  if ((rc = d_flags.alloc((size_t)S))) return rc;
+  {
+    const char *e = getenv("FMR_SERIAL");
+    serial_mode = (e && e[0] == '1');
+  }
+  max_agc_nc = max_if / C_AGC + 2;
+  if (has_dec) {
+    if ((rc = d_agc_nodes.alloc((size_t)S * (max_agc_nc + 1)))) return rc;
+    if ((rc = d_agc_G.alloc((size_t)S * max_agc_nc))) return rc;
+    if ((rc = d_agc_M.alloc((size_t)S * max_agc_nc))) return rc;
+  }
   if (!has_dec) return FMR_OK;
 
   if ((rc = upload(d_coeff, c->filter_coeff, (size_t)ntaps))) return rc;
@@ -244,6 +278,16 @@ int fmr_chain::init(const fmr_config *c) {
     const double de = c->deemphasis_us;
     deemph = lowpass_rc((de == 0) ? 1.0 : (de * kFmRate * 1.0e-6));      // FmDecode.cpp:67-70
     dcblock = highpass_iir(0.0001);                                       // FmDecode.cpp:62
+    {
+      // A = [[-a1, -a2], [1, 0]] acts on (w[n-1], w[n-2]); A^C by repeated multiplication
+      double a[4] = {-dcblock.a1, -dcblock.a2, 1.0, 0.0}, r[4] = {1, 0, 0, 1};
+      for (int i = 0; i < C_DC; i++) {
+        const double t[4] = {a[0] * r[0] + a[1] * r[2], a[0] * r[1] + a[1] * r[3], a[2] * r[0] + a[3] * r[2],
+                             a[2] * r[1] + a[3] * r[3]};
+        for (int j = 0; j < 4; j++) r[j] = t[j];
+      }
+      for (int j = 0; j < 4; j++) dc_ac[j] = r[j];
+    }
     if (!ars.design(kFmRate, kPcmRate, kAudioAtten)) { set_err("audio resampler design failed"); return FMR_ERR_UNSUPPORTED; }
     if (ars.D == 1) { ars.NA = 1; ars.hA.assign(1, 1.0); }
     H_a = ars.NA - 1 + ars.D;
@@ -258,8 +302,19 @@ int fmr_chain::init(const fmr_config *c) {
     float tab[257];
     make_fast_atan_table(tab);
     if ((rc = upload(d_atan, tab, (size_t)257))) return rc;
-    if ((rc = d_base.alloc((size_t)S * (H_a + max_if)))) return rc;
-    if ((rc = d_raw.alloc((size_t)S * (H_a + max_if)))) return rc;
+    H_b = std::max(H_a, FMR_DE_WARMUP);
+    if ((rc = d_base.alloc((size_t)S * (H_b + max_if)))) return rc;
+    if ((rc = d_raw.alloc((size_t)S * (H_b + max_if)))) return rc;
+    if ((rc = d_base_de.alloc((size_t)S * (H_a + max_if)))) return rc;
+    if ((rc = d_raw_de.alloc((size_t)S * (H_a + max_if)))) return rc;
+    if ((rc = d_pll_nodes.alloc((size_t)S * (max_ck + 1) * 7))) return rc;
+    if ((rc = d_pll_G.alloc((size_t)S * max_ck * 9))) return rc;
+    if ((rc = d_pll_M.alloc((size_t)S * max_ck * 49))) return rc;
+    if ((rc = d_ck_wraps.alloc((size_t)S * max_ck))) return rc;
+    if ((rc = d_ck_level.alloc((size_t)S * max_ck))) return rc;
+    max_dc_nc = max_au / C_DC + 2;
+    if ((rc = d_dc_G.alloc((size_t)S * 2 * max_dc_nc * 2))) return rc;
+    if ((rc = d_dc_start.alloc((size_t)S * 2 * max_dc_nc * 2))) return rc;
     if ((rc = d_am0.alloc((size_t)S * (H_am + max_amid)))) return rc;
     if ((rc = d_am1.alloc((size_t)S * (H_am + max_amid)))) return rc;
     if ((rc = d_a10.alloc((size_t)S * (H_pc + max_au)))) return rc;
@@ -301,8 +356,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   const int slot = tab_slot;
   tab_slot = (tab_slot + 1) % kTabSlots;
   HIPCHK(hipEventSynchronize(tab_ev[slot]));   // slot free again (no-op if never recorded)
-  int *h_tab = h_tab_all + (size_t)slot * 5 * max_blocks;
-  int *d_tab_slot = d_tab.p + (size_t)slot * 5 * max_blocks;
+  int *h_tab = h_tab_all + (size_t)slot * tab_ints;
+  int *d_tab_slot = d_tab.p + (size_t)slot * tab_ints;
   int *t_if_off = h_tab, *t_if_len = h_tab + max_blocks, *t_au_off = h_tab + 2 * max_blocks,
       *t_au_len = h_tab + 3 * max_blocks, *t_mpf = h_tab + 4 * max_blocks;
   // ------------------------------------------------------------------ front end
@@ -394,7 +449,23 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     }
   }
   last_n_au = N_au;
-  HIPCHK(hipMemcpyAsync(d_tab_slot, h_tab, sizeof(int) * 5 * (size_t)max_blocks, hipMemcpyHostToDevice, stream));
+  // PLL chunk table: every decoder block is cut into chunks of <= C_PLL samples
+  int *t_ck_off = h_tab + 5 * (size_t)max_blocks, *t_ck_len = t_ck_off + max_ck, *t_ck_blk = t_ck_len + max_ck,
+      *t_first = t_ck_blk + max_ck;
+  int nck = 0;
+  for (int b = 0; b < nb; b++) {
+    t_first[b] = nck;
+    for (int o = 0; o < t_if_len[b]; o += C_PLL) {
+      t_ck_off[nck] = t_if_off[b] + o;
+      t_ck_len[nck] = std::min(C_PLL, t_if_len[b] - o);
+      t_ck_blk[nck] = b;
+      nck++;
+    }
+  }
+  t_first[nb] = nck;
+  HIPCHK(hipMemcpyAsync(d_tab_slot, h_tab, sizeof(int) * tab_ints, hipMemcpyHostToDevice, stream));
+  int *d_ck = d_tab_slot + 5 * (size_t)max_blocks;
+  ChunkTab ct{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_ck + 3 * max_ck, nck};
   HIPCHK(hipEventRecord(tab_ev[slot], stream));
   BlockTab bt{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
               d_tab_slot + 4 * max_blocks, nb};
@@ -408,10 +479,31 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   const float2 *xin = fir_enable ? d_fir.p : d_if.p;
   const long long x_stride = fir_enable ? (long long)max_if : if_stride;
   const int x_off = fir_enable ? 0 : H_if;
-  timed("if_agc", [&] {
-    hipLaunchKernelGGL(k_if_agc, dim3((S + 63) / 64), dim3(64), 0, stream, xin, x_stride, x_off, (int)N_if, d_gain.p,
-                       (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate);
-  });
+  // ---- IF AGC: Newton multiple shooting over chunks of C_AGC samples (kernels_par.hpp)
+  const int agc_nc = (int)((N_if + C_AGC - 1) / C_AGC);
+  hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, stream, d_flags.p,
+                     (serial_mode || enable_mpf) ? (float *)nullptr : d_agc_nodes.p,
+                     agc_nc, d_state.p, S);
+  // With the equaliser on, the AGC'd amplitude feeds the constant-modulus error, and
+  // the equaliser kernel is the serial bottleneck anyway: use the exact serial AGC.
+  if (serial_mode || enable_mpf) {
+    timed("if_agc", [&] {
+      hipLaunchKernelGGL(k_if_agc, dim3((S + 63) / 64), dim3(64), 0, stream, xin, x_stride, x_off, (int)N_if, d_gain.p,
+                         (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate);
+    });
+  } else {
+    timed("if_agc", [&] {
+      for (int it = 0; it < K_AGC_ITERS; it++) {
+        hipLaunchKernelGGL(k_agc_shoot<C_AGC>, dim3((agc_nc + 63) / 64, S), dim3(64), 0, stream, xin, x_stride, x_off,
+                           (int)N_if, d_gain.p, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
+                           agc_init, agc_max, agc_rate, d_flags.p);
+        hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64), 0, stream, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
+                           d_state.p, d_flags.p);
+      }
+      hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, xin, x_stride, x_off, (int)N_if,
+                         d_gain.p, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
+    });
+  }
   if (mode == FMR_MODE_FM) {
     if (any_mpf) {
       const size_t lds = sizeof(float2) * ((size_t)2 * mpf_N + FMR_MPF_CH);
@@ -421,11 +513,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                            d_mpf_ok.p, d_state.p);
       });
     }
-    const long long base_stride = H_a + (long long)max_if;
+    const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
+    const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
     timed("disc", [&] {
       hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
                          (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,
-                         disc_nf, disc_bound, d_dec.p, (long long)max_if, d_base.p, base_stride, H_a,
+                         disc_nf, disc_bound, d_dec.p, (long long)max_if, d_base.p, base_stride, H_b,
                          d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);
     });
     timed("stats", [&] {
@@ -433,18 +526,41 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          d_bb_rms_blk.p, d_state.p, S, 1);
     });
     if (stereo) {
-      timed("pll", [&] {
-        hipLaunchKernelGGL(k_pll, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_a, bt, d_raw.p,
-                           base_stride, H_a, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p, S);
-      });
+      if (serial_mode) {
+        timed("pll", [&] {
+          hipLaunchKernelGGL(k_pll, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt, d_raw.p,
+                             base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p, S);
+        });
+      } else {
+        // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
+        timed("pll", [&] {
+          hipLaunchKernelGGL(k_pll_begin, dim3((nck + 1 + 63) / 64, S), dim3(64), 0, stream, d_pll_nodes.p, ct,
+                             d_state.p, pllc);
+          for (int it = 0; it < K_PLL_ITERS; it++) {
+            hipLaunchKernelGGL(k_pll_shoot, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p, base_stride, H_b,
+                               ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p,
+                               d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_level.p, d_flags.p);
+            hipLaunchKernelGGL(k_pll_nodes, dim3(S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
+                               d_flags.p, 1.0, pllc.minfreq, pllc.maxfreq);
+          }
+          hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
+                             d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
+                             S, d_flags.p);
+          hipLaunchKernelGGL(k_pll_finish, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
+                             ct, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p,
+                             d_stereo_blk.p, d_state.p, S, d_flags.p);
+        });
+      }
     }
+    // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
+    const int nch = stereo ? 2 : 1;
     timed("deemph", [&] {
-      hipLaunchKernelGGL(k_deemph, dim3((2 * S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_a, d_raw.p,
-                         base_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1, (int)(stereo && !pilot_shift),
-                         d_state.p, S);
+      const int nt = (int)((N_if + C_DE - 1) / C_DE);
+      hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch), dim3(64), 0, stream, d_base.p, d_raw.p,
+                         base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
+                         (int)(stereo && !pilot_shift));
     });
     // ---------------------------------------------------- audio resampler + tail
-    const int nch = stereo ? 2 : 1;
     const int count_am = (int)(arsc.mA - amA_prev);
     const long long am_stride = H_am + (long long)max_amid;
     const long long a1_stride = H_pc + (long long)max_au;
@@ -452,8 +568,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if (count_am > 0) {
       const long long top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
       timed("aud_decim", [&] {
-        hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch), dim3(128), 0, stream, d_base.p,
-                           d_raw.p, base_stride, H_a, d_ahA.p, ars.NA, ars.D, top0, count_am, d_am0.p, d_am1.p,
+        hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch), dim3(128), 0, stream, d_base_de.p,
+                           d_raw_de.p, de_stride, H_a, d_ahA.p, ars.NA, ars.D, top0, count_am, d_am0.p, d_am1.p,
                            am_stride, H_am);
       });
     }
@@ -468,15 +584,32 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch), dim3(128), 0, stream, d_a10.p, d_a11.p, a1_stride, H_pc,
                            bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
       });
-      timed("fm_out", [&] {
-        hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
-                           dcblock.b0, dcblock.b1, dcblock.b2, dcblock.a1, dcblock.a2, (int)stereo, (int)pilot_shift,
-                           d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
-      });
+      if (serial_mode) {
+        timed("fm_out", [&] {
+          hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
+                             dcblock.b0, dcblock.b1, dcblock.b2, dcblock.a1, dcblock.a2, (int)stereo, (int)pilot_shift,
+                             d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
+        });
+      } else {
+        // ---- DC block by linear multiple shooting + output mux
+        const int dc_nc = (int)((N_au + C_DC - 1) / C_DC);
+        DcCoef dk{dcblock.b0, dcblock.b1, dcblock.b2, dcblock.a1, dcblock.a2, {dc_ac[0], dc_ac[1], dc_ac[2], dc_ac[3]}};
+        timed("fm_out", [&] {
+          hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
+                             (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc);
+          hipLaunchKernelGGL(k_dc_nodes, dim3((S * nch + 63) / 64), dim3(64), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc,
+                             dk, d_state.p, S, nch);
+          hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
+                             (long long)max_au, bt, (int)N_au, dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,
+                             d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
+        });
+      }
     }
     if (fir_enable) add_halo(d_if.p, if_stride, H_if, N_if);
-    add_halo(d_base.p, base_stride, H_a, N_if);
-    if (stereo) add_halo(d_raw.p, base_stride, H_a, N_if);
+    add_halo(d_base.p, base_stride, H_b, N_if);
+    if (stereo) add_halo(d_raw.p, base_stride, H_b, N_if);
+    add_halo(d_base_de.p, de_stride, H_a, N_if);
+    if (stereo) add_halo(d_raw_de.p, de_stride, H_a, N_if);
     add_halo(d_am0.p, am_stride, H_am, count_am);
     if (stereo) add_halo(d_am1.p, am_stride, H_am, count_am);
     add_halo(d_a10.p, a1_stride, H_pc, N_au);
@@ -616,6 +749,7 @@ static int fetch_state(fmr_chain *c) {
   HIPCHK(hipSetDevice(c->cfg.device));
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(c->h_state.data(), c->d_state.p, sizeof(StreamState) * c->S, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(c->h_flags.data(), c->d_flags.p, sizeof(IterFlags) * c->S, hipMemcpyDeviceToHost));
   return FMR_OK;
 }
 
@@ -634,6 +768,14 @@ int fmr_get_status(fmr_chain *c, int stream, fmr_status *st) {
   st->multipath_error = s.mpf_error;
   st->pll_freq_err = s.pll_freq_err;
   st->multipath_resets = s.mpf_resets;
+  const IterFlags &f = c->h_flags[stream];
+  st->agc_iterations = f.agc_iters;
+  st->pll_iterations = f.pll_iters;
+  st->agc_fallback = f.agc_fallback;
+  st->pll_fallback = f.pll_fallback;
+  st->pll_residual = f.pll_resid;
+  for (int i = 0; i < 16; i++) { st->agc_residual_history[i] = f.agc_hist[i]; st->pll_residual_history[i] = f.pll_hist[i]; }
+  for (int i = 0; i < 8; i++) st->pll_residual_components[i] = f.pll_comp[i];
   return FMR_OK;
 }
 
@@ -671,8 +813,8 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
   switch (which) {
   case 0: src = c->d_if.p + (size_t)stream * (c->H_if + c->max_if) + c->H_if; esz = sizeof(float2); break;
   case 1: src = c->d_dec.p ? c->d_dec.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
-  case 2: src = c->d_raw.p ? c->d_raw.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
-  case 3: src = c->d_base.p ? c->d_base.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
+  case 2: src = c->d_raw_de.p ? c->d_raw_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
+  case 3: src = c->d_base_de.p ? c->d_base_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 4: src = c->d_gain.p ? c->d_gain.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
   default: return FMR_ERR_BAD_ARG;
   }

@@ -53,6 +53,10 @@ struct StreamState {
   unsigned mpf_resets, pad1;
   // AmDecoder: AfSimpleAgc gain, dc block, de-emphasis
   double af_gain, am_dc_x1, am_dc_x2, am_de_x1;
+  // mean PLL phase increment over the previous call (= pilot frequency estimate);
+  // seeds the initial trajectory guess of the time-parallel PLL (kernels_par.hpp)
+  double pll_favg;
+  int pll_favg_valid, pad2;
 };
 
 struct PllConst {

@@ -1,0 +1,674 @@
+// kernels_par.hpp -- time-parallel forms of the sample-serial recurrences.
+//
+// The reference runs five recurrences one sample at a time: IF AGC
+// (IfSimpleAgc.cpp:42-56), pilot PLL (PilotPhaseLock.cpp:73-151), two
+// de-emphasis IIRs (Filter.cpp:172-178) and two DC-block biquads
+// (Filter.cpp:243-250).  A GPU lane runs such a loop no faster than a CPU core,
+// so a single stream would be bound by one lane.  These kernels restructure the
+// recurrences along time instead (MI355X-first: thousands of chunks in flight):
+//
+//  * de-emphasis: first-order, pole 0.949 -> its memory is < 768 samples at
+//    double precision.  Every chunk simply starts 768 samples early from zero
+//    state ("warm-up"), no communication.
+//  * DC block: linear, long memory -> multiple shooting.  Pass 1 integrates
+//    every chunk from zero state, a node pass propagates s' = G + A^C s through
+//    the chunk boundaries, pass 2 re-runs every chunk from its true start.
+//    Exact for a linear system after one round.
+//  * AGC and PLL: nonlinear but contractive -> multiple shooting with Newton
+//    updates of the chunk-boundary states.  Every chunk is integrated with
+//    exactly the reference's per-sample arithmetic from its current start-state
+//    guess, together with the sensitivity dS_end/dS_start; the node pass solves
+//    the linearised boundary conditions; iterate until the boundary mismatch is
+//    below tolerance (quadratic convergence, 2-6 rounds).  At convergence the
+//    trajectory inside a chunk IS the reference's serial arithmetic; only the
+//    chunk start states carry the (<= tolerance) iteration residual.  If the
+//    iteration does not converge the serial kernels of kernels.hpp run instead.
+#pragma once
+#include "kernels.hpp"
+
+namespace fmr {
+
+struct IterFlags {
+  int agc_converged, agc_iters, agc_fallback, pll_converged, pll_iters, pll_fallback;
+  float agc_resid; int pad;
+  double pll_resid;
+  float agc_hist[16];     // residual after each Newton round (diagnostics)
+  double pll_hist[16];
+  double pll_comp[8];     // last round: residual per state component
+};
+
+// ---------------------------------------------------------------------------
+// De-emphasis by warm-up (LowPassFilterRC::process_inplace, Filter.cpp:214-221)
+// ---------------------------------------------------------------------------
+#define FMR_DE_WARMUP 768
+template <int C>
+__global__ void k_deemph_par(const double *__restrict__ in0, const double *__restrict__ in1, long long in_stride,
+                             int in_off, double *__restrict__ out0, double *__restrict__ out1, long long out_stride,
+                             int out_off, int n, double b0, double a1, int filt0, int filt1) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y, ch = blockIdx.z;
+  const int start = t * C;
+  if (start >= n) return;
+  const double *x = (ch ? in1 : in0) + (long long)s * in_stride + in_off;
+  double *y = (ch ? out1 : out0) + (long long)s * out_stride + out_off;
+  const int end = min(start + C, n);
+  if (!(ch ? filt1 : filt0)) {
+    for (int i = start; i < end; i++) y[i] = x[i];
+    return;
+  }
+  double w = 0.0;
+  for (int i = start - FMR_DE_WARMUP; i < start; i++) w = x[i] - a1 * w;
+  for (int i = start; i < end; i++) {
+    w = x[i] - a1 * w;
+    y[i] = b0 * w;      // b1 == 0
+  }
+}
+
+// ---------------------------------------------------------------------------
+// DC block (HighPassFilterIir) by linear multiple shooting + output mux
+// (FmDecode.cpp:194-220,242-283).
+// ---------------------------------------------------------------------------
+struct DcCoef { double b0, b1, b2, a1, a2; double ac[4]; /* A^C row-major */ };
+
+template <int C>
+__global__ void k_dc_pass1(const double *__restrict__ p0, const double *__restrict__ p1, long long p_stride, int n,
+                           DcCoef k, double *__restrict__ G, int nc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y, ch = blockIdx.z;
+  if (c >= nc) return;
+  const double *p = (ch ? p1 : p0) + (long long)s * p_stride;
+  const int start = c * C, end = min(start + C, n);
+  double x1 = 0.0, x2 = 0.0;
+  for (int i = start; i < end; i++) {
+    const double x0 = p[i] - (k.a1 * x1 + k.a2 * x2);
+    x2 = x1; x1 = x0;
+  }
+  double *g = G + (((long long)s * 2 + ch) * nc + c) * 2;
+  g[0] = x1; g[1] = x2;
+}
+
+// node pass: start[c+1] = G[c] + A^C start[c]; one lane per (stream, channel)
+__global__ void k_dc_nodes(const double *__restrict__ G, double *__restrict__ start, int nc, DcCoef k,
+                           StreamState *st, int n_streams, int nch) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = t / nch, ch = t % nch;
+  if (s >= n_streams) return;
+  const double *g = G + (((long long)s * 2 + ch) * nc) * 2;
+  double *o = start + (((long long)s * 2 + ch) * nc) * 2;
+  double x1 = ch ? st[s].dc_st_x1 : st[s].dc_mono_x1;
+  double x2 = ch ? st[s].dc_st_x2 : st[s].dc_mono_x2;
+  for (int c = 0; c < nc; c++) {
+    o[2 * c] = x1; o[2 * c + 1] = x2;
+    const double n1 = g[2 * c] + (k.ac[0] * x1 + k.ac[1] * x2);
+    const double n2 = g[2 * c + 1] + (k.ac[2] * x1 + k.ac[3] * x2);
+    x1 = n1; x2 = n2;
+  }
+}
+
+template <int C>
+__global__ void k_dc_pass2_mux(const double *__restrict__ p0, const double *__restrict__ p1, long long p_stride,
+                               BlockTab bt, int n, DcCoef k, const double *__restrict__ start, int nc, int stereo,
+                               int pilot_shift, const int *__restrict__ stereo_blk, double *__restrict__ audio,
+                               long long audio_stride, StreamState *st) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (c >= nc) return;
+  const double *m = p0 + (long long)s * p_stride;
+  const double *d = p1 + (long long)s * p_stride;
+  double *out = audio + (long long)s * audio_stride;
+  const int i0 = c * C, i1 = min(i0 + C, n);
+  const double *sm = start + (((long long)s * 2 + 0) * nc + c) * 2;
+  const double *sd = start + (((long long)s * 2 + 1) * nc + c) * 2;
+  double m1 = sm[0], m2 = sm[1], d1 = 0.0, d2 = 0.0;
+  if (stereo) { d1 = sd[0]; d2 = sd[1]; }
+  // audio block that holds sample i0
+  int b = 0;
+  if (stereo) {
+    int lo = 0, hi = bt.nb - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (bt.au_off[mid] <= i0) lo = mid; else hi = mid - 1;
+    }
+    b = lo;
+    while (b < bt.nb - 1 && bt.au_len[b] == 0) b++;
+  }
+  int bend = stereo ? bt.au_off[b] + bt.au_len[b] : n;
+  int locked = stereo ? stereo_blk[(long long)s * bt.nb + b] : 0;
+  for (int i = i0; i < i1; i++) {
+    double x0 = m[i] - (k.a1 * m1 + k.a2 * m2);
+    const double mm = k.b0 * x0 + k.b1 * m1 + k.b2 * m2;
+    m2 = m1; m1 = x0;
+    if (!stereo) { out[i] = mm; continue; }
+    x0 = d[i] - (k.a1 * d1 + k.a2 * d2);
+    const double dd = k.b0 * x0 + k.b1 * d1 + k.b2 * d2;
+    d2 = d1; d1 = x0;
+    while (i >= bend && b < bt.nb - 1) {
+      b++;
+      bend = bt.au_off[b] + bt.au_len[b];
+      locked = stereo_blk[(long long)s * bt.nb + b];
+    }
+    double l, r;
+    if (locked) {
+      if (pilot_shift) { l = r = dd; }
+      else { const double ss = 1.017 * dd; l = mm + ss; r = mm - ss; }
+    } else {
+      if (pilot_shift) { l = r = 0.0; } else { l = r = mm; }
+    }
+    out[2 * i] = l; out[2 * i + 1] = r;
+  }
+  if (c == nc - 1) {
+    st[s].dc_mono_x1 = m1; st[s].dc_mono_x2 = m2;
+    if (stereo) { st[s].dc_st_x1 = d1; st[s].dc_st_x2 = d2; }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// IF AGC by Newton multiple shooting.  nodes[c] = gain at the start of chunk c.
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ void k_agc_shoot(const float2 *__restrict__ x, long long x_stride, int x_off, int n,
+                            float *__restrict__ gain, long long g_stride, const float *__restrict__ nodes,
+                            float *__restrict__ G, double *__restrict__ M, int nc, float initial_gain, float max_gain,
+                            float rate, const IterFlags *__restrict__ fl) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (c >= nc || fl[s].agc_converged) return;
+  const float2 *xs = x + (long long)s * x_stride + x_off;
+  float *gs = gain + (long long)s * g_stride;
+  const int i0 = c * C, i1 = min(i0 + C, n);
+  float g = nodes[(long long)s * (nc + 1) + c];
+  double dg = 1.0;
+  const double r = (double)rate;
+  for (int i = i0; i < i1; i++) {
+    const float2 v = xs[i];
+    gs[i] = g;
+    const float xr = v.x * g, xi = v.y * g;
+    const float nrm = xr * xr + xi * xi;
+    const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
+    const float gn = g * z;
+    // d(g z)/dg = z + g dz/dg = z - 2 r nrm   (nrm ~ g^2)
+    dg *= ((double)z - 2.0 * r * (double)nrm);
+    g = gn;
+    if (!isfinite(g)) { g = initial_gain; dg = 0.0; }
+    else if (g > max_gain) { g = max_gain; dg = 0.0; }
+  }
+  G[(long long)s * nc + c] = g;
+  M[(long long)s * nc + c] = dg;
+}
+
+// node pass: v[c+1] = G[c] + M[c] (v[c] - old[c]); wave-parallel affine scan.
+__global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, const float *__restrict__ G,
+                                                  const double *__restrict__ M, int nc, StreamState *st,
+                                                  IterFlags *fl) {
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (fl[s].agc_converged) return;
+  float *nd = nodes + (long long)s * (nc + 1);
+  const float *g = G + (long long)s * nc;
+  const double *m = M + (long long)s * nc;
+  double carry = (double)nd[0];   // v[0] is the carried state, fixed
+  float old_first = nd[0];        // OLD value of nd[c0] (the previous step overwrote nd[c0])
+  float maxrel = 0.f;
+  for (int c0 = 0; c0 < nc; c0 += 64) {
+    const int c = c0 + lane;
+    double a = 1.0, b = 0.0;
+    float old_next = 0.f;
+    if (c < nc) {
+      const float old_c = (lane == 0) ? old_first : nd[c];
+      old_next = nd[c + 1];
+      a = m[c];
+      b = (double)g[c] - a * (double)old_c;
+    }
+    // inclusive scan of affine maps: (a,b) o (pa,pb) = (a*pa, a*pb + b)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double pa = __shfl_up(a, o, 64), pb = __shfl_up(b, o, 64);
+      if (lane >= o) { b = a * pb + b; a = a * pa; }
+    }
+    const float vf = (float)(a * carry + b);       // v[c+1]
+    if (c < nc) {
+      nd[c + 1] = vf;
+      maxrel = fmaxf(maxrel, fabsf(vf - old_next) / fmaxf(fabsf(vf), 1e-30f));
+    }
+    carry = (double)__shfl(vf, 63, 64);            // lanes past nc hold identity maps
+    old_first = __shfl(old_next, 63, 64);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxrel = fmaxf(maxrel, __shfl_xor(maxrel, o, 64));
+  if (lane == 0) {
+    if (fl[s].agc_iters < 16) fl[s].agc_hist[fl[s].agc_iters] = maxrel;
+    fl[s].agc_iters++;
+    fl[s].agc_resid = maxrel;
+    // Float state: the Newton map is only defined up to a few ulp of rounding noise
+    // (each chunk re-rounds 256 times), so "converged" = node changes <= 8 ulp.
+    // Two regimes.  Amplitude-modulated input (AM): z moves by many ulps per sample,
+    // the map is smooth and Newton reaches <= 1e-6 in 2-4 rounds.  Constant-envelope
+    // input (FM): |r (1 - |x g|^2)| < ulp(1)/2 most of the time, so z == 1.0f exactly
+    // and the reference's gain only random-walks inside a dead zone ~3e-4 wide; there
+    // the chunk map has no usable slope and the rounds stagnate at a few 1e-5.  That
+    // is also the level at which the reference's own gain depends on FMA contraction
+    // (hazard H7), and atan2 is invariant to it: accept <= 5e-5 after 4 rounds.
+    if (maxrel <= 1.0e-6f || (fl[s].agc_iters >= 4 && maxrel <= 5.0e-5f)) {   // gains of the last shoot pass stand
+      fl[s].agc_converged = 1;
+      st[s].agc_gain = nd[nc];
+    }
+  }
+}
+
+__global__ void k_iter_begin(IterFlags *fl, float *__restrict__ agc_nodes, int agc_nc, const StreamState *st,
+                             int n_streams) {
+  const int s = blockIdx.x;
+  if (s >= n_streams) return;
+  if (threadIdx.x == 0) {
+    fl[s] = IterFlags{};
+    if (agc_nodes) agc_nodes[(long long)s * (agc_nc + 1)] = st[s].agc_gain;
+  }
+  // initial guess: the carried gain everywhere
+  if (agc_nodes) {
+    const float g0 = st[s].agc_gain;
+    for (int c = 1 + threadIdx.x; c <= agc_nc; c += blockDim.x) agc_nodes[(long long)s * (agc_nc + 1) + c] = g0;
+  }
+}
+
+// serial fallback wrapper: only when the iteration did not converge
+__global__ void k_if_agc_fallback(const float2 *__restrict__ x, long long x_stride, int x_off, int n,
+                                  float *__restrict__ gain, long long g_stride, StreamState *st, int n_streams,
+                                  float initial_gain, float max_gain, float rate, IterFlags *fl) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams || fl[s].agc_converged) return;
+  fl[s].agc_fallback = 1;
+  const float2 *xs = x + (long long)s * x_stride + x_off;
+  float *gs = gain + (long long)s * g_stride;
+  float g = st[s].agc_gain;
+  const double r = (double)rate;
+  for (int i = 0; i < n; i++) {
+    const float2 v = xs[i];
+    gs[i] = g;
+    const float xr = v.x * g, xi = v.y * g;
+    const float nrm = xr * xr + xi * xi;
+    const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
+    g *= z;
+    if (!isfinite(g)) g = initial_gain;
+    else if (g > max_gain) g = max_gain;
+  }
+  st[s].agc_gain = g;
+}
+
+// ---------------------------------------------------------------------------
+// Pilot PLL by Newton multiple shooting.
+// State vector: 0 phase, 1 freq, 2 loop-filter delay (previous phase error),
+// 3,4 biquad-I delays, 5,6 biquad-Q delays.
+// ---------------------------------------------------------------------------
+struct PllRegs { double v[7]; double level, freq_err; };
+
+struct ChunkTab {
+  const int *off;   // [nck] IF-sample offset of the chunk inside the call
+  const int *len;   // [nck]
+  const int *blk;   // [nck] block it belongs to
+  const int *first; // [nb+1] first chunk of each block
+  int nck;
+};
+
+__device__ __forceinline__ double wrap_pm_pi(double d) {
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  if (d > 3.14159265358979323846) d -= two_pi;
+  if (d < -3.14159265358979323846) d += two_pi;
+  return d;
+}
+
+// One PLL sample step, the reference's arithmetic (PilotPhaseLock.cpp:73-151);
+// JAC: also advance the 7x7 sensitivity Mx = d state / d start-state.
+template <bool JAC>
+__device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc, const float *tab, int pilot_shift,
+                                        double &out, double (*Mx)[7]) {
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  double psin, pcos;
+  sincos(S.v[0], &psin, &pcos);
+  const double carrier = pilot_shift ? (2 * pcos * pcos - 1) : (2 * psin * pcos);
+  out = (carrier * x) * 2.0;
+  const double phasor_i = psin * x, phasor_q = pcos * x;
+  const double wi0 = phasor_i - (pc.bq_a1 * S.v[3] + pc.bq_a2 * S.v[4]);
+  const double wq0 = phasor_q - (pc.bq_a1 * S.v[5] + pc.bq_a2 * S.v[6]);
+  const double new_i = pc.bq_b0 * wi0, new_q = pc.bq_b0 * wq0;
+  const double e = (double)fast_atan2f_dev((float)new_q, (float)new_i, tab);
+  S.level = sqrt((new_i * new_i) + (new_q * new_q));
+  const double y = pc.lf_b0 * e + pc.lf_b1 * S.v[2];
+  S.freq_err = y;
+  const double f_un = S.v[1] + y;
+  const double f_new = fmax(pc.minfreq, fmin(pc.maxfreq, f_un));
+  if (JAC) {
+    const double den = wi0 * wi0 + wq0 * wq0;
+    const double eI = den > 0.0 ? -wq0 / den : 0.0, eQ = den > 0.0 ? wi0 / den : 0.0;
+    const double cI = x * pcos, cQ = -x * psin;
+    const double mask = (f_un >= pc.minfreq && f_un <= pc.maxfreq) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const double rwi = cI * Mx[0][k] - pc.bq_a1 * Mx[3][k] - pc.bq_a2 * Mx[4][k];
+      const double rwq = cQ * Mx[0][k] - pc.bq_a1 * Mx[5][k] - pc.bq_a2 * Mx[6][k];
+      const double re = eI * rwi + eQ * rwq;
+      const double rf = mask * (Mx[1][k] + pc.lf_b1 * Mx[2][k] + pc.lf_b0 * re);
+      Mx[0][k] = Mx[0][k] + rf;
+      Mx[1][k] = rf;
+      Mx[2][k] = re;
+      Mx[4][k] = Mx[3][k];
+      Mx[3][k] = rwi;
+      Mx[6][k] = Mx[5][k];
+      Mx[5][k] = rwq;
+    }
+  }
+  S.v[2] = e;
+  S.v[4] = S.v[3]; S.v[3] = wi0;
+  S.v[6] = S.v[5]; S.v[5] = wq0;
+  S.v[1] = f_new;
+  double ph = S.v[0] + f_new;
+  int wrapped = 0;
+  if (ph > two_pi) { ph -= two_pi; wrapped = 1; }
+  S.v[0] = ph;
+  return wrapped;
+}
+
+__global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ base, long long base_stride, int base_off, ChunkTab ct,
+                            double *__restrict__ raw, long long raw_stride, int raw_off,
+                            const float *__restrict__ atan_tab, PllConst pc, int pilot_shift,
+                            const double *__restrict__ nodes, double *__restrict__ G, double *__restrict__ M,
+                            int *__restrict__ ck_wraps, double *__restrict__ ck_level,
+                            const IterFlags *__restrict__ fl) {
+  __shared__ float tab[257];
+  for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
+  __syncthreads();
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (c >= ct.nck || fl[s].pll_converged) return;
+  const double *xin = base + (long long)s * base_stride + base_off + ct.off[c];
+  double *out = raw + (long long)s * raw_stride + raw_off + ct.off[c];
+  const int n = ct.len[c];
+  PllRegs S;
+  const double *nd = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
+#pragma unroll
+  for (int k = 0; k < 7; k++) S.v[k] = nd[k];
+  S.level = 0.0; S.freq_err = 0.0;
+  double Mx[7][7];
+#pragma unroll
+  for (int r = 0; r < 7; r++)
+#pragma unroll
+    for (int k = 0; k < 7; k++) Mx[r][k] = (r == k) ? 1.0 : 0.0;
+  int wraps = 0;
+  for (int i = 0; i < n; i++) {
+    double o;
+    wraps += pll_step<true>(S, xin[i], pc, tab, pilot_shift, o, Mx);
+    out[i] = o;
+  }
+  double *g = G + ((long long)s * ct.nck + c) * 9;
+#pragma unroll
+  for (int k = 0; k < 7; k++) g[k] = S.v[k];
+  g[7] = S.level; g[8] = S.freq_err;
+  double *m = M + ((long long)s * ct.nck + c) * 49;
+#pragma unroll
+  for (int r = 0; r < 7; r++)
+#pragma unroll
+    for (int k = 0; k < 7; k++) m[r * 7 + k] = Mx[r][k];
+  ck_wraps[(long long)s * ct.nck + c] = wraps;
+  ck_level[(long long)s * ct.nck + c] = S.level;
+}
+
+// node pass: new[c+1] = G[c] + M[c] (new[c] - old[c]), one wave per stream; lane
+// (r*8 + k) holds M[r][k].  Updates nodes in place (old values are read first).
+// Loads run two groups of 8 chunks ahead of the dependent shuffle chain.
+// Convergence scales: the phase error e is a FLOAT (fast_atan2f), so the chunk
+// map has rounding discontinuities of one float ulp of e (<= 2.4e-7 while the loop
+// acquires, ~1e-9 in lock), i.e. ~7e-11 in freq per flip; scales sit just above
+// that floor: phase 1e-7 rad, freq 1e-9, phase error 1e-5, biquad delays 1e-7 rel.
+#define FMR_PLL_GRP 8
+__global__ __launch_bounds__(64) void k_pll_nodes(double *__restrict__ nodes, const double *__restrict__ G,
+                                                  const double *__restrict__ M, int nck, IterFlags *fl, double tol,
+                                                  double minfreq, double maxfreq) {
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (fl[s].pll_converged) return;
+  const int r = lane >> 3, k = lane & 7;
+  const bool act = (r < 7 && k < 7);
+  double *nd = nodes + (long long)s * (nck + 1) * 7;
+  const double *g = G + (long long)s * nck * 9;
+  const double *m = M + (long long)s * nck * 49;
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  const int src = (k < 7 ? k : 0) * 8;
+  double delta_k = 0.0;     // (new[c] - old[c])[k] on lane (r,k); zero for c == 0 (fixed start)
+  double resid = 0.0;
+  double mvA[FMR_PLL_GRP], gvA[FMR_PLL_GRP], ovA[FMR_PLL_GRP], wmA[FMR_PLL_GRP];
+  double mvB[FMR_PLL_GRP], gvB[FMR_PLL_GRP], ovB[FMR_PLL_GRP], wmB[FMR_PLL_GRP];
+  auto load = [&](int c0, double *mv, double *gv, double *ov, double *wm) {
+#pragma unroll
+    for (int j = 0; j < FMR_PLL_GRP; j++) {
+      const int c = c0 + j;
+      const bool ok = c < nck;
+      mv[j] = (ok && act) ? m[(long long)c * 49 + r * 7 + k] : 0.0;
+      gv[j] = (ok && r < 7) ? g[(long long)c * 9 + r] : 0.0;
+      ov[j] = (ok && r < 7) ? nd[(long long)(c + 1) * 7 + r] : 0.0;
+      wm[j] = ok ? fabs(g[(long long)c * 9 + 3]) + fabs(g[(long long)c * 9 + 5]) : 0.0;
+    }
+  };
+  auto run = [&](int c0, const double *mv, const double *gv, const double *ov, const double *wm) {
+#pragma unroll
+    for (int j = 0; j < FMR_PLL_GRP; j++) {
+      const int c = c0 + j;
+      if (c >= nck) break;
+      double p = mv[j] * delta_k;
+      p += __shfl_xor(p, 1, 64);
+      p += __shfl_xor(p, 2, 64);
+      p += __shfl_xor(p, 4, 64);      // (M delta)[r] on every lane of group r
+      double nv = gv[j] + p;
+      if (r == 0) {                   // keep the phase inside (0, 2 pi] like the reference
+        nv -= two_pi * floor(nv / two_pi);
+        if (nv <= 0.0) nv += two_pi;
+      }
+      if (r == 1) nv = fmax(minfreq, fmin(maxfreq, nv));   // the true freq never leaves the clamp range
+      double d = nv - ov[j];
+      if (r == 0) d = wrap_pm_pi(d);
+      if (r < 7 && k == 0) nd[(long long)(c + 1) * 7 + r] = nv;
+      // biquad delays: relative to the size of the (I,Q) delay pair, whose large component
+      // is ~level/b0 ~ 3e4; the small (quadrature) one carries no more precision than that
+      double scale = 1e-9 * (wm[j] + 1.0);
+      if (r == 0) scale = 1e-7; else if (r == 1) scale = 1e-9; else if (r == 2) scale = 1e-5;
+      if (r < 7) resid = fmax(resid, fabs(d) / scale);   // per lane: the residual of component r
+      delta_k = __shfl(d, src, 64);
+    }
+  };
+  load(0, mvA, gvA, ovA, wmA);
+  for (int c0 = 0; c0 < nck; c0 += 2 * FMR_PLL_GRP) {
+    load(c0 + FMR_PLL_GRP, mvB, gvB, ovB, wmB);
+    run(c0, mvA, gvA, ovA, wmA);
+    load(c0 + 2 * FMR_PLL_GRP, mvA, gvA, ovA, wmA);
+    run(c0 + FMR_PLL_GRP, mvB, gvB, ovB, wmB);
+  }
+  if (k == 0 && r < 7) fl[s].pll_comp[r] = resid;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) resid = fmax(resid, __shfl_xor(resid, o, 64));
+  if (lane == 0) {
+    if (fl[s].pll_iters < 16) fl[s].pll_hist[fl[s].pll_iters] = resid;
+    fl[s].pll_iters++;
+    fl[s].pll_resid = resid;
+    if (resid <= tol) fl[s].pll_converged = 1;
+  }
+}
+
+// initial node guess: nominal ramp from the carried state
+__global__ void k_pll_begin(double *__restrict__ nodes, ChunkTab ct, const StreamState *st, PllConst pc) {
+  const int s = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > ct.nck) return;
+  const StreamState &S = st[s];
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  double *nd = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
+  long long n0 = 0;
+  if (c < ct.nck) n0 = ct.off[c]; else if (ct.nck > 0) n0 = (long long)ct.off[ct.nck - 1] + ct.len[ct.nck - 1];
+  // ramp with the mean increment of the previous call: the instantaneous freq carries
+  // ~1e-7 rad/sample of loop jitter, which would walk the guess off by ~0.1 rad per 1e6 samples
+  const double framp = S.pll_favg_valid ? S.pll_favg : S.pll_freq;
+  double ph = S.pll_phase + (double)n0 * framp;
+  ph -= two_pi * floor(ph / two_pi);
+  if (ph <= 0.0) ph += two_pi;
+  if (c == 0) ph = S.pll_phase;
+  nd[0] = ph; nd[1] = S.pll_freq; nd[2] = S.lf_x1;
+  nd[3] = S.bq_i_x1; nd[4] = S.bq_i_x2; nd[5] = S.bq_q_x1; nd[6] = S.bq_q_x2;
+}
+
+// After convergence: per-block lock logic (PilotPhaseLock.cpp:154-167), PPS
+// events (:133-150) and the state commit.  One lane per stream.
+__global__ void k_pll_finish(const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt,
+                             ChunkTab ct, const float *__restrict__ atan_tab, PllConst pc, int pilot_shift,
+                             const double *__restrict__ nodes, const double *__restrict__ G,
+                             const int *__restrict__ ck_wraps, int *__restrict__ stereo_blk, StreamState *st,
+                             int n_streams, const IterFlags *__restrict__ fl) {
+  __shared__ float tab[257];
+  for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
+  __syncthreads();
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams || !fl[s].pll_converged || fl[s].pll_fallback) return;
+  StreamState &S = st[s];
+  int lock_cnt = S.lock_cnt, pilot_periods = S.pilot_periods;
+  unsigned long long pps_cnt = S.pps_cnt, sample_cnt = S.sample_cnt;
+  int n_pps = 0;
+  double level = S.pll_level;
+  for (int b = 0; b < bt.nb; b++) {
+    const int n = bt.if_len[b];
+    if (n == 0) { stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay); continue; }
+    const bool was_locked = (lock_cnt >= pc.lock_delay);
+    const int pps_blk_start = n_pps;
+    for (int c = ct.first[b]; c < ct.first[b + 1]; c++) {
+      const int w = ck_wraps[(long long)s * ct.nck + c];
+      if (pilot_periods + w >= pc.pilot_frequency) {
+        // the 19000th period ends inside this chunk: re-integrate it to find the sample
+        PllRegs R;
+        const double *nd = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
+        for (int k = 0; k < 7; k++) R.v[k] = nd[k];
+        const double *xin = base + (long long)s * base_stride + base_off + ct.off[c];
+        for (int i = 0; i < ct.len[c]; i++) {
+          double o;
+          if (pll_step<false>(R, xin[i], pc, tab, pilot_shift, o, nullptr)) {
+            pilot_periods++;
+            if (pilot_periods == pc.pilot_frequency) {
+              pilot_periods = 0;
+              if (was_locked) {
+                const int ib = ct.off[c] - bt.if_off[b] + i;   // index inside the block
+                if (n_pps < FMR_MAX_PPS) {
+                  PpsEventDev &ev = S.pps[n_pps];
+                  ev.pps_index = pps_cnt;
+                  ev.sample_index = sample_cnt + (unsigned long long)ib;
+                  ev.block_position = (double)ib / (double)n;
+                  ev.block = (unsigned)b;
+                }
+                n_pps++;
+                pps_cnt++;
+              }
+            }
+          }
+        }
+      } else {
+        pilot_periods += w;
+      }
+    }
+    level = G[((long long)s * ct.nck + (ct.first[b + 1] - 1)) * 9 + 7];
+    if (2 * level > pc.minsignal) {
+      if (lock_cnt < pc.lock_delay) lock_cnt += n;
+    } else {
+      lock_cnt = 0;
+    }
+    if (lock_cnt < pc.lock_delay) {
+      pilot_periods = 0;
+      pps_cnt = 0;
+      n_pps = pps_blk_start;
+    }
+    sample_cnt += (unsigned long long)n;
+    stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay);
+  }
+  if (ct.nck > 0) {
+    const double *g = G + ((long long)s * ct.nck + (ct.nck - 1)) * 9;
+    long long wr = 0, ns = 0;
+    for (int c = 0; c < ct.nck; c++) { wr += ck_wraps[(long long)s * ct.nck + c]; ns += ct.len[c]; }
+    if (ns >= 65536) {
+      S.pll_favg = ((double)wr * 2.0 * 3.14159265358979323846 + (g[0] - S.pll_phase)) / (double)ns;
+      S.pll_favg_valid = (S.lock_cnt >= pc.lock_delay) ? 1 : 0;
+    }
+    S.pll_phase = g[0]; S.pll_freq = g[1]; S.lf_x1 = g[2];
+    S.bq_i_x1 = g[3]; S.bq_i_x2 = g[4]; S.bq_q_x1 = g[5]; S.bq_q_x2 = g[6];
+    S.pll_level = g[7]; S.pll_freq_err = g[8];
+  }
+  S.lock_cnt = lock_cnt; S.pilot_periods = pilot_periods; S.pps_cnt = pps_cnt; S.sample_cnt = sample_cnt;
+  S.n_pps = n_pps < FMR_MAX_PPS ? n_pps : FMR_MAX_PPS;
+  S.stereo_detected = (lock_cnt >= pc.lock_delay);
+}
+
+// serial fallback: the plain k_pll when the shooting iteration did not converge
+__global__ __launch_bounds__(64) void k_pll_fallback(
+    const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt,
+    double *__restrict__ raw, long long raw_stride, int raw_off, const float *__restrict__ atan_tab,
+    PllConst pc, int pilot_shift, int *__restrict__ stereo_blk, StreamState *st, int n_streams, IterFlags *fl) {
+  __shared__ float tab[257];
+  for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
+  __syncthreads();
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams || fl[s].pll_converged) return;
+  fl[s].pll_fallback = 1;
+  StreamState &S = st[s];
+  PllRegs R;
+  R.v[0] = S.pll_phase; R.v[1] = S.pll_freq; R.v[2] = S.lf_x1;
+  R.v[3] = S.bq_i_x1; R.v[4] = S.bq_i_x2; R.v[5] = S.bq_q_x1; R.v[6] = S.bq_q_x2;
+  R.level = S.pll_level; R.freq_err = S.pll_freq_err;
+  int lock_cnt = S.lock_cnt, pilot_periods = S.pilot_periods;
+  unsigned long long pps_cnt = S.pps_cnt, sample_cnt = S.sample_cnt;
+  int n_pps = 0;
+  long long wr = 0, ns = 0;
+  const double ph_start = S.pll_phase;
+  const double *xin = base + (long long)s * base_stride + base_off;
+  double *out = raw + (long long)s * raw_stride + raw_off;
+  for (int b = 0; b < bt.nb; b++) {
+    const int n = bt.if_len[b];
+    if (n == 0) { stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay); continue; }
+    const int off = bt.if_off[b];
+    const bool was_locked = (lock_cnt >= pc.lock_delay);
+    const int pps_blk_start = n_pps;
+    for (int i = 0; i < n; i++) {
+      double o;
+      if (pll_step<false>(R, xin[off + i], pc, tab, pilot_shift, o, nullptr)) {
+        pilot_periods++;
+        wr++;
+        if (pilot_periods == pc.pilot_frequency) {
+          pilot_periods = 0;
+          if (was_locked) {
+            if (n_pps < FMR_MAX_PPS) {
+              PpsEventDev &ev = S.pps[n_pps];
+              ev.pps_index = pps_cnt;
+              ev.sample_index = sample_cnt + (unsigned long long)i;
+              ev.block_position = (double)i / (double)n;
+              ev.block = (unsigned)b;
+            }
+            n_pps++;
+            pps_cnt++;
+          }
+        }
+      }
+      out[off + i] = o;
+    }
+    if (2 * R.level > pc.minsignal) {
+      if (lock_cnt < pc.lock_delay) lock_cnt += n;
+    } else {
+      lock_cnt = 0;
+    }
+    if (lock_cnt < pc.lock_delay) { pilot_periods = 0; pps_cnt = 0; n_pps = pps_blk_start; }
+    sample_cnt += (unsigned long long)n;
+    ns += n;
+    stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay);
+  }
+  if (ns >= 65536) {
+    S.pll_favg = ((double)wr * 2.0 * 3.14159265358979323846 + (R.v[0] - ph_start)) / (double)ns;
+    S.pll_favg_valid = (lock_cnt >= pc.lock_delay) ? 1 : 0;
+  }
+  S.pll_phase = R.v[0]; S.pll_freq = R.v[1]; S.lf_x1 = R.v[2];
+  S.bq_i_x1 = R.v[3]; S.bq_i_x2 = R.v[4]; S.bq_q_x1 = R.v[5]; S.bq_q_x2 = R.v[6];
+  S.pll_level = R.level; S.pll_freq_err = R.freq_err;
+  S.lock_cnt = lock_cnt; S.pilot_periods = pilot_periods; S.pps_cnt = pps_cnt; S.sample_cnt = sample_cnt;
+  S.n_pps = n_pps < FMR_MAX_PPS ? n_pps : FMR_MAX_PPS;
+  S.stereo_detected = (lock_cnt >= pc.lock_delay);
+}
+
+}  // namespace fmr

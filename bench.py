@@ -32,13 +32,21 @@ FS = 10e6
 
 
 def synth_fm_stereo_torch(n, fs, stream_id, device):
-    """S-FMst generated on the GPU; same formula as tests/siggen.py."""
+    """S-FMst generated on the GPU; same formula as tests/siggen.py, except that
+    every tone is snapped to an integer number of cycles in the n-sample buffer, so that replaying
+    the buffer step after step is one continuous stream (no pilot-phase jump at the seam)."""
     import torch
+    T = n / fs
+
+    def snap(f):
+        return round(f * T) / T
+
     t = torch.arange(n, dtype=torch.float64, device=device) / fs
-    fl, fr = 1000.0 + 10.0 * stream_id, 400.0 + 10.0 * stream_id
+    fl, fr, fp = snap(1000.0 + 10.0 * stream_id), snap(400.0 + 10.0 * stream_id), snap(19000.0)
     left, right = torch.sin(2 * np.pi * fl * t), torch.sin(2 * np.pi * fr * t)
-    th = 2 * np.pi * 19000.0 * t
+    th = 2 * np.pi * fp * t
     mpx = 0.45 * (left + right) + 0.10 * torch.sin(th) + 0.45 * (left - right) * torch.sin(2 * th)
+    mpx = mpx - mpx.mean()                      # exact zero mean: the FM phase closes on itself
     ph = 2 * np.pi * 75000.0 / fs * torch.cumsum(mpx, 0)
     g = torch.Generator(device=device)
     g.manual_seed(1 + stream_id)
@@ -59,7 +67,7 @@ def cpu_baseline(target_seconds=12.0):
     for b in siggen.blocks(x[:8 * BLK], BLK):
         fm.process(ifr.process(b))
     rate = 8 * BLK / (time.perf_counter() - t0)
-    reps = int(max(1, min(40, round(target_seconds * rate / len(x)))))
+    reps = int(max(1, min(400, round(target_seconds * rate / len(x)))))
     nblk = 64 * reps
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -162,6 +170,8 @@ def main():
                          "avg_launch_ms": round(dec_ms, 5), "algorithmic_bytes_per_launch": bytes_per_launch},
             "kernel_ms_per_step": {k: round(v, 5) for k, v in kavg.items()},
             "audio_check": {"stereo_locked": int(st.stereo_detected), "pilot_level": round(st.pilot_level, 6)},
+            "recurrences": {"agc_newton_rounds": st.agc_iterations, "pll_newton_rounds": st.pll_iterations,
+                            "agc_serial_fallback": st.agc_fallback, "pll_serial_fallback": st.pll_fallback},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -89,6 +89,13 @@ typedef struct {
   double multipath_error;
   double pll_freq_err;
   uint32_t multipath_resets;  /* blocks whose equaliser output was discarded */
+  /* time-parallel recurrences of the most recent call: Newton
+   * rounds used, and whether the serial fallback kernel had to run */
+  int agc_iterations, pll_iterations, agc_fallback, pll_fallback;
+  double pll_residual;
+  float agc_residual_history[16];   /* residual after each Newton round */
+  double pll_residual_history[16];
+  double pll_residual_components[8];
 } fmr_status;
 
 typedef struct fmr_chain fmr_chain;

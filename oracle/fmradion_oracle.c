@@ -654,6 +654,16 @@ void ora_pll_process(ora_pll *p, const double *in, int n_, double *out, int pilo
   }
   p->sample_cnt += n;
 }
+/* test hooks: the 7 continuous state variables (phase, freq, loop-filter delay,
+ * biquad I delays x1,x2, biquad Q delays x1,x2) */
+void ora_pll_get_state(const ora_pll *p, double *s) {
+  s[0] = p->phase; s[1] = p->freq; s[2] = p->lf.x1;
+  s[3] = p->bq_i.x1; s[4] = p->bq_i.x2; s[5] = p->bq_q.x1; s[6] = p->bq_q.x2;
+}
+void ora_pll_set_state(ora_pll *p, const double *s) {
+  p->phase = s[0]; p->freq = s[1]; p->lf.x1 = s[2];
+  p->bq_i.x1 = s[3]; p->bq_i.x2 = s[4]; p->bq_q.x1 = s[5]; p->bq_q.x2 = s[6];
+}
 int ora_pll_locked(const ora_pll *p) { return p->lock_cnt >= p->lock_delay; }
 double ora_pll_pilot_level(const ora_pll *p) { return 2 * p->pilot_level; }
 double ora_pll_freq_err(const ora_pll *p) { return p->freq_err; }

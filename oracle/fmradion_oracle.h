@@ -116,6 +116,8 @@ ora_pll *ora_pll_create(double freq);
 void ora_pll_destroy(ora_pll *p);
 void ora_pll_process(ora_pll *p, const double *in, int n, double *out,
                      int pilot_shift);
+void ora_pll_get_state(const ora_pll *p, double *s7);
+void ora_pll_set_state(ora_pll *p, const double *s7);
 int ora_pll_locked(const ora_pll *p);
 double ora_pll_pilot_level(const ora_pll *p); /* = 2*m_pilot_level */
 double ora_pll_freq_err(const ora_pll *p);

@@ -116,7 +116,10 @@ def _fm_case(name, x, blk, batch, *, fir=None, stereo=True, deemph=50.0, pilot_s
             mono384_rms_err=base_err, stereo384_rms_err=raw_err, if_rms=st.if_rms, ref_if_rms=fm.get_if_rms(),
             pilot=st.pilot_level, ref_pilot=fm.get_pilot_level(), locked=st.stereo_detected,
             ref_locked=int(fm.stereo_detected()), agc=st.if_agc_gain, ref_agc=fm.get_if_agc_gain(),
-            mpf_err=st.multipath_error, ref_mpf_err=fm.get_multipath_error(), mpf_resets=st.multipath_resets)
+            mpf_err=st.multipath_error, ref_mpf_err=fm.get_multipath_error(), mpf_resets=st.multipath_resets,
+            agc_iters=st.agc_iterations, pll_iters=st.pll_iterations, agc_fallback=st.agc_fallback,
+            pll_fallback=st.pll_fallback, pll_resid=st.pll_residual)
+    assert st.agc_fallback == 0 and st.pll_fallback == 0
     assert err < tol, (name, err)
     assert st.stereo_detected == int(fm.stereo_detected())
     assert st.if_rms == pytest.approx(fm.get_if_rms(), rel=1e-5)
@@ -141,7 +144,9 @@ def test_fm_stereo_single_block_calls_equal_batched(pilotcut):
     ch8 = fmr.Chain(mode=fmr.MODE_FM, input_rate=384e3, stereo=True, max_block_len=2048, max_blocks=8)
     a1 = np.concatenate([ch1.process(b) for b in siggen.blocks(x, 2048)])
     a8 = np.concatenate([ch8.process_blocks(x[None, i:i + 8 * 2048], [2048] * 8)[0][0] for i in range(0, len(x), 8 * 2048)])
-    np.testing.assert_array_equal(a1, a8)
+    # the time-parallel PLL/AGC converge to a tolerance, so different call partitions
+    # agree to that tolerance, not bit for bit
+    assert rms(a1 - a8) < 1e-7
     ch1.close(); ch8.close()
 
 
@@ -314,7 +319,12 @@ def test_fm_stereo_config2(pilotcut):
     tail = slice(len(ref) - 2 * 9600, len(ref))
     st = ch.status()
     _report("fm_stereo_config2", audio_rms_err=err, audio_rms_err_postlock=rms(got[tail] - ref[tail]),
-            audio_rms=rms(ref), n=len(ref), locked=st.stereo_detected, pilot=st.pilot_level)
+            audio_rms=rms(ref), n=len(ref), locked=st.stereo_detected, pilot=st.pilot_level,
+            agc_iters=st.agc_iterations, pll_iters=st.pll_iterations, agc_fallback=st.agc_fallback,
+            pll_fallback=st.pll_fallback, pll_resid=st.pll_residual,
+            agc_hist=[float(v) for v in st.agc_residual_history[:st.agc_iterations]],
+            pll_hist=[float(v) for v in st.pll_residual_history[:st.pll_iterations]])
+    assert st.agc_fallback == 0 and st.pll_fallback == 0
     assert fm.stereo_detected() and st.stereo_detected == 1
     assert err < 1e-5
     ch.close()
