@@ -54,8 +54,9 @@ constexpr double kIfAtten = 140.0;     // resampler spec, DESIGN.md
 constexpr double kAudioAtten = 180.0;
 constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
-constexpr int C_AGC = 256, C_PLL = 512, C_DC = 64, C_DE = 512;
-constexpr int K_AGC_ITERS = 10, K_PLL_ITERS = 10;
+constexpr int C_AGC = 256, C_DC = 1024, C_DE = 512;
+constexpr int C_PLL_MIN = 128;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
+constexpr int K_AGC_ITERS = 8, K_PLL_ITERS = 6;
 
 template <class T>
 struct DevBuf {
@@ -100,11 +101,13 @@ struct fmr_chain {
   DevBuf<StreamState> d_state;
   // time-parallel recurrences
   bool serial_mode = false;            // FMR_SERIAL=1: plain serial kernels (A/B, debugging)
+  int c_pll = 128;                     // PLL chunk length (env FMR_C_PLL, >= C_PLL_MIN)
   int H_b = 0;                         // halo of the pre-de-emphasis buffers (>= warm-up)
   size_t max_ck = 0, max_agc_nc = 0, max_dc_nc = 0;
-  DevBuf<double> d_base_de, d_raw_de, d_pll_nodes, d_pll_G, d_pll_M, d_ck_level, d_agc_M, d_dc_G, d_dc_start;
+  DevBuf<double> d_base_de, d_raw_de, d_pll_nodes, d_pll_G, d_pll_M, d_pll_PQ, d_pll_dstart, d_blk_level, d_agc_M,
+      d_dc_G, d_dc_start;
   DevBuf<float> d_agc_nodes, d_agc_G;
-  DevBuf<int> d_ck_wraps;
+  DevBuf<int> d_ck_wraps, d_blk_wraps;
   DevBuf<IterFlags> d_flags;
   std::vector<IterFlags> h_flags;
   // block tables: ring of pinned host slots + device slots so that queued
@@ -139,7 +142,7 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_ck_level.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
@@ -230,7 +233,7 @@ int fmr_chain::init(const fmr_config *c) {
     st.af_gain = 1.0;
   }
   if ((rc = upload(d_state, h_state.data(), h_state.size()))) return rc;
-  max_ck = max_if / C_PLL + (size_t)max_blocks + 2;
+  max_ck = max_if / C_PLL_MIN + (size_t)max_blocks + 2;
   tab_ints = 5 * (size_t)max_blocks + 3 * max_ck + (size_t)max_blocks + 1;
   HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * tab_ints));
   for (auto &e : tab_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -240,6 +243,8 @@ int fmr_chain::init(const fmr_config *c) {
   {
     const char *e = getenv("FMR_SERIAL");
     serial_mode = (e && e[0] == '1');
+    const char *cp = getenv("FMR_C_PLL");
+    if (cp && atoi(cp) >= C_PLL_MIN) c_pll = atoi(cp);
   }
   max_agc_nc = max_if / C_AGC + 2;
   if (has_dec) {
@@ -311,7 +316,13 @@ int fmr_chain::init(const fmr_config *c) {
     if ((rc = d_pll_G.alloc((size_t)S * max_ck * 9))) return rc;
     if ((rc = d_pll_M.alloc((size_t)S * max_ck * 49))) return rc;
     if ((rc = d_ck_wraps.alloc((size_t)S * max_ck))) return rc;
-    if ((rc = d_ck_level.alloc((size_t)S * max_ck))) return rc;
+    {
+      const size_t max_grp = max_ck / FMR_NODE_GRP + 2;
+      if ((rc = d_pll_PQ.alloc((size_t)S * max_grp * 56))) return rc;
+      if ((rc = d_pll_dstart.alloc((size_t)S * max_grp * 7))) return rc;
+    }
+    if ((rc = d_blk_wraps.alloc((size_t)S * max_blocks))) return rc;
+    if ((rc = d_blk_level.alloc((size_t)S * max_blocks))) return rc;
     max_dc_nc = max_au / C_DC + 2;
     if ((rc = d_dc_G.alloc((size_t)S * 2 * max_dc_nc * 2))) return rc;
     if ((rc = d_dc_start.alloc((size_t)S * 2 * max_dc_nc * 2))) return rc;
@@ -455,9 +466,9 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   int nck = 0;
   for (int b = 0; b < nb; b++) {
     t_first[b] = nck;
-    for (int o = 0; o < t_if_len[b]; o += C_PLL) {
+    for (int o = 0; o < t_if_len[b]; o += c_pll) {
       t_ck_off[nck] = t_if_off[b] + o;
-      t_ck_len[nck] = std::min(C_PLL, t_if_len[b] - o);
+      t_ck_len[nck] = std::min(c_pll, t_if_len[b] - o);
       t_ck_blk[nck] = b;
       nck++;
     }
@@ -536,19 +547,33 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         timed("pll", [&] {
           hipLaunchKernelGGL(k_pll_begin, dim3((nck + 1 + 63) / 64, S), dim3(64), 0, stream, d_pll_nodes.p, ct,
                              d_state.p, pllc);
+          const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
           for (int it = 0; it < K_PLL_ITERS; it++) {
-            hipLaunchKernelGGL(k_pll_shoot, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p, base_stride, H_b,
-                               ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p,
-                               d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_level.p, d_flags.p);
-            hipLaunchKernelGGL(k_pll_nodes, dim3(S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
-                               d_flags.p, 1.0, pllc.minfreq, pllc.maxfreq);
+            // rounds 0,1 integrate the sensitivities too; later rounds reuse them (chord Newton)
+            if (it < 2)
+              hipLaunchKernelGGL(k_pll_shoot<true>, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p,
+                                 base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
+                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_flags.p);
+            else
+              hipLaunchKernelGGL(k_pll_shoot<false>, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p,
+                                 base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
+                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_flags.p);
+            hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
+                               nck, d_pll_PQ.p, d_flags.p);
+            hipLaunchKernelGGL(k_pll_nodes_b, dim3(S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_dstart.p,
+                               d_flags.p);
+            hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
+                               nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq);
+            hipLaunchKernelGGL(k_pll_check, dim3((S + 63) / 64), dim3(64), 0, stream, d_flags.p, S, 1.0);
           }
           hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
                              d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
                              S, d_flags.p);
-          hipLaunchKernelGGL(k_pll_finish, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
-                             ct, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p,
-                             d_stereo_blk.p, d_state.p, S, d_flags.p);
+          hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, stream, bt, ct, d_pll_G.p,
+                             d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
+          hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt, ct, d_atan.p,
+                             pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_blk_wraps.p,
+                             d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
         });
       }
     }

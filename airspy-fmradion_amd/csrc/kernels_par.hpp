@@ -35,6 +35,7 @@ struct IterFlags {
   float agc_hist[16];     // residual after each Newton round (diagnostics)
   double pll_hist[16];
   double pll_comp[8];     // last round: residual per state component
+  unsigned long long pll_resid_bits, pll_comp_bits[8];   // atomicMax accumulators of the running round
 };
 
 // ---------------------------------------------------------------------------
@@ -299,7 +300,8 @@ __global__ void k_if_agc_fallback(const float2 *__restrict__ x, long long x_stri
 // State vector: 0 phase, 1 freq, 2 loop-filter delay (previous phase error),
 // 3,4 biquad-I delays, 5,6 biquad-Q delays.
 // ---------------------------------------------------------------------------
-struct PllRegs { double v[7]; double level, freq_err; };
+struct PllRegs { double v[7]; double li, lq, freq_err; };   // li,lq: biquad outputs of the last sample
+__device__ __forceinline__ double pll_level(const PllRegs &S) { return sqrt((S.li * S.li) + (S.lq * S.lq)); }  // PilotPhaseLock.cpp:106
 
 struct ChunkTab {
   const int *off;   // [nck] IF-sample offset of the chunk inside the call
@@ -331,7 +333,7 @@ __device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc
   const double wq0 = phasor_q - (pc.bq_a1 * S.v[5] + pc.bq_a2 * S.v[6]);
   const double new_i = pc.bq_b0 * wi0, new_q = pc.bq_b0 * wq0;
   const double e = (double)fast_atan2f_dev((float)new_q, (float)new_i, tab);
-  S.level = sqrt((new_i * new_i) + (new_q * new_q));
+  S.li = new_i; S.lq = new_q;   // m_pilot_level = sqrt(i*i + q*q) is only consumed after a block's last sample
   const double y = pc.lf_b0 * e + pc.lf_b1 * S.v[2];
   S.freq_err = y;
   const double f_un = S.v[1] + y;
@@ -367,11 +369,12 @@ __device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc
   return wrapped;
 }
 
+template <bool JAC>
 __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ base, long long base_stride, int base_off, ChunkTab ct,
                             double *__restrict__ raw, long long raw_stride, int raw_off,
                             const float *__restrict__ atan_tab, PllConst pc, int pilot_shift,
                             const double *__restrict__ nodes, double *__restrict__ G, double *__restrict__ M,
-                            int *__restrict__ ck_wraps, double *__restrict__ ck_level,
+                            int *__restrict__ ck_wraps,
                             const IterFlags *__restrict__ fl) {
   __shared__ float tab[257];
   for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
   const double *nd = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
 #pragma unroll
   for (int k = 0; k < 7; k++) S.v[k] = nd[k];
-  S.level = 0.0; S.freq_err = 0.0;
+  S.li = 0.0; S.lq = 0.0; S.freq_err = 0.0;
   double Mx[7][7];
 #pragma unroll
   for (int r = 0; r < 7; r++)
@@ -395,100 +398,167 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
   int wraps = 0;
   for (int i = 0; i < n; i++) {
     double o;
-    wraps += pll_step<true>(S, xin[i], pc, tab, pilot_shift, o, Mx);
+    wraps += pll_step<JAC>(S, xin[i], pc, tab, pilot_shift, o, Mx);
     out[i] = o;
   }
   double *g = G + ((long long)s * ct.nck + c) * 9;
 #pragma unroll
   for (int k = 0; k < 7; k++) g[k] = S.v[k];
-  g[7] = S.level; g[8] = S.freq_err;
-  double *m = M + ((long long)s * ct.nck + c) * 49;
+  g[7] = pll_level(S); g[8] = S.freq_err;
+  if (JAC) {   // JAC == false: frozen-Jacobian round, the stored M of the last JAC round stands
+    double *m = M + ((long long)s * ct.nck + c) * 49;
 #pragma unroll
-  for (int r = 0; r < 7; r++)
+    for (int r = 0; r < 7; r++)
 #pragma unroll
-    for (int k = 0; k < 7; k++) m[r * 7 + k] = Mx[r][k];
+      for (int k = 0; k < 7; k++) m[r * 7 + k] = Mx[r][k];
+  }
   ck_wraps[(long long)s * ct.nck + c] = wraps;
-  ck_level[(long long)s * ct.nck + c] = S.level;
 }
 
-// node pass: new[c+1] = G[c] + M[c] (new[c] - old[c]), one wave per stream; lane
-// (r*8 + k) holds M[r][k].  Updates nodes in place (old values are read first).
-// Loads run two groups of 8 chunks ahead of the dependent shuffle chain.
-// Convergence scales: the phase error e is a FLOAT (fast_atan2f), so the chunk
-// map has rounding discontinuities of one float ulp of e (<= 2.4e-7 while the loop
-// acquires, ~1e-9 in lock), i.e. ~7e-11 in freq per flip; scales sit just above
-// that floor: phase 1e-7 rad, freq 1e-9, phase error 1e-5, biquad delays 1e-7 rel.
-#define FMR_PLL_GRP 8
-__global__ __launch_bounds__(64) void k_pll_nodes(double *__restrict__ nodes, const double *__restrict__ G,
-                                                  const double *__restrict__ M, int nck, IterFlags *fl, double tol,
-                                                  double minfreq, double maxfreq) {
-  const int s = blockIdx.x;
-  const int lane = threadIdx.x;
+// ---------------------------------------------------------------------------
+// Node pass as a three-phase parallel scan of 7-dimensional affine maps.
+// With d[c] = new[c] - old[c] and the boundary mismatch r[c] = G[c] - old[c+1]
+// (phase component wrapped), the Newton update is the linear recurrence
+//     d[c+1] = M[c] d[c] + r[c],   d[0] = 0.
+//   A: every group of FMR_NODE_GRP chunks composes its maps into one (P | q)   (parallel)
+//   B: one wave walks the group maps: start delta of every group               (short serial)
+//   C: every group propagates its deltas, updates the nodes, records residuals  (parallel)
+// Convergence scales: the phase error e is a FLOAT (fast_atan2f), so the chunk map has
+// rounding discontinuities of one float ulp of e (<= 2.4e-7 while the loop acquires,
+// ~1e-9 in lock), i.e. ~7e-11 in freq per flip; scales sit above that floor:
+// phase 1e-7 rad, freq 1e-9, phase error 1e-5, biquad delays 1e-7 of the (I,Q) pair.
+// ---------------------------------------------------------------------------
+#define FMR_NODE_GRP 32
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// mismatch r[c][i] = G[c][i] - old[c+1][i]
+__device__ __forceinline__ double pll_mismatch(const double *g, const double *nd, int c, int i) {
+  double v = g[(long long)c * 9 + i] - nd[(long long)(c + 1) * 7 + i];
+  if (i == 0) v = wrap_pm_pi(v);
+  return v;
+}
+
+// Phase A: lane (i*8 + k): k < 7 -> P[i][k], k == 7 -> q[i].  [P|q] <- [M P | M q + r]
+__global__ __launch_bounds__(64) void k_pll_nodes_a(const double *__restrict__ nodes, const double *__restrict__ G,
+                                                    const double *__restrict__ M, int nck,
+                                                    double *__restrict__ PQ, const IterFlags *__restrict__ fl) {
+  __shared__ double sh[64];
+  const int s = blockIdx.y, grp = blockIdx.x;
   if (fl[s].pll_converged) return;
-  const int r = lane >> 3, k = lane & 7;
-  const bool act = (r < 7 && k < 7);
+  const int lane = threadIdx.x, i = lane >> 3, k = lane & 7;
+  const bool act = i < 7;
+  const int ii = act ? i : 0;
+  const double *nd = nodes + (long long)s * (nck + 1) * 7;
+  const double *g = G + (long long)s * nck * 9;
+  const double *m = M + (long long)s * nck * 49;
+  const int c0 = grp * FMR_NODE_GRP, c1 = min(c0 + FMR_NODE_GRP, nck);
+  double val = (act && i == k) ? 1.0 : 0.0;   // P = I, q = 0
+  for (int c = c0; c < c1; c++) {
+    double mr[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) mr[j] = m[(long long)c * 49 + ii * 7 + j];
+    const double rr = (k == 7) ? pll_mismatch(g, nd, c, ii) : 0.0;
+    sh[lane] = val;
+    __syncthreads();                      // one wave per block: just orders the LDS write
+    double acc = rr;
+#pragma unroll
+    for (int j = 0; j < 7; j++) acc = fma(mr[j], sh[j * 8 + k], acc);
+    __syncthreads();
+    val = acc;
+  }
+  if (act) PQ[(((long long)s * gridDim.x + grp) * 7 + i) * 8 + k] = val;
+}
+
+// Phase B: delta at the start of every group (one wave per stream, lane i = component i)
+__global__ __launch_bounds__(64) void k_pll_nodes_b(const double *__restrict__ PQ, int ngrp,
+                                                    double *__restrict__ dstart, const IterFlags *__restrict__ fl) {
+  const int s = blockIdx.x, i = threadIdx.x;
+  if (fl[s].pll_converged) return;
+  const bool act = i < 7;
+  const int ii = act ? i : 0;
+  const double *pq = PQ + (long long)s * ngrp * 56;
+  double *ds = dstart + (long long)s * ngrp * 7;
+  double d = 0.0;
+  for (int gq = 0; gq < ngrp; gq++) {
+    if (act) ds[(long long)gq * 7 + i] = d;
+    double row[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) row[k] = pq[((long long)gq * 7 + ii) * 8 + k];
+    const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2 = readlane_d(d, 2), d3 = readlane_d(d, 3),
+                 d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
+    const double p0 = fma(row[0], d0, fma(row[1], d1, row[7]));
+    const double p1 = fma(row[2], d2, row[3] * d3);
+    const double p2 = fma(row[4], d4, fma(row[5], d5, row[6] * d6));
+    d = p0 + (p1 + p2);
+  }
+}
+
+// Phase C: propagate inside every group, update the nodes, record the scaled residual
+__global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, const double *__restrict__ G,
+                                                    const double *__restrict__ M, int nck,
+                                                    const double *__restrict__ dstart, IterFlags *fl,
+                                                    double minfreq, double maxfreq) {
+  const int s = blockIdx.y, grp = blockIdx.x;
+  if (fl[s].pll_converged) return;
+  const int i = threadIdx.x;
+  const bool act = i < 7;
+  const int ii = act ? i : 0;
   double *nd = nodes + (long long)s * (nck + 1) * 7;
   const double *g = G + (long long)s * nck * 9;
   const double *m = M + (long long)s * nck * 49;
-  const double two_pi = 2.0 * 3.14159265358979323846;
-  const int src = (k < 7 ? k : 0) * 8;
-  double delta_k = 0.0;     // (new[c] - old[c])[k] on lane (r,k); zero for c == 0 (fixed start)
+  const double two_pi = 2.0 * 3.14159265358979323846, inv_two_pi = 1.0 / two_pi;
+  const int c0 = grp * FMR_NODE_GRP, c1 = min(c0 + FMR_NODE_GRP, nck);
+  double d = dstart[((long long)s * gridDim.x + grp) * 7 + ii];
+  // scale of the biquad delays: size of the (I,Q) delay pair at the group start
+  const double wm = fabs(g[(long long)c0 * 9 + 3]) + fabs(g[(long long)c0 * 9 + 5]);
+  double inv_scale = 1.0 / (1e-7 * (wm + 1.0));
+  if (i == 0) inv_scale = 1e7; else if (i == 1) inv_scale = 1e9; else if (i == 2) inv_scale = 1e5;
   double resid = 0.0;
-  double mvA[FMR_PLL_GRP], gvA[FMR_PLL_GRP], ovA[FMR_PLL_GRP], wmA[FMR_PLL_GRP];
-  double mvB[FMR_PLL_GRP], gvB[FMR_PLL_GRP], ovB[FMR_PLL_GRP], wmB[FMR_PLL_GRP];
-  auto load = [&](int c0, double *mv, double *gv, double *ov, double *wm) {
+  for (int c = c0; c < c1; c++) {
+    double mr[7];
 #pragma unroll
-    for (int j = 0; j < FMR_PLL_GRP; j++) {
-      const int c = c0 + j;
-      const bool ok = c < nck;
-      mv[j] = (ok && act) ? m[(long long)c * 49 + r * 7 + k] : 0.0;
-      gv[j] = (ok && r < 7) ? g[(long long)c * 9 + r] : 0.0;
-      ov[j] = (ok && r < 7) ? nd[(long long)(c + 1) * 7 + r] : 0.0;
-      wm[j] = ok ? fabs(g[(long long)c * 9 + 3]) + fabs(g[(long long)c * 9 + 5]) : 0.0;
+    for (int j = 0; j < 7; j++) mr[j] = m[(long long)c * 49 + ii * 7 + j];
+    const double old_next = nd[(long long)(c + 1) * 7 + ii];
+    const double rr = pll_mismatch(g, nd, c, ii);
+    const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2 = readlane_d(d, 2), d3 = readlane_d(d, 3),
+                 d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
+    const double p0 = fma(mr[0], d0, fma(mr[1], d1, rr));
+    const double p1 = fma(mr[2], d2, mr[3] * d3);
+    const double p2 = fma(mr[4], d4, fma(mr[5], d5, mr[6] * d6));
+    d = p0 + (p1 + p2);                       // delta of node c+1
+    double nv = old_next + d;
+    if (i == 0) {                             // keep the phase inside (0, 2 pi] like the reference
+      nv -= two_pi * floor(nv * inv_two_pi);
+      if (nv <= 0.0) nv += two_pi;
     }
-  };
-  auto run = [&](int c0, const double *mv, const double *gv, const double *ov, const double *wm) {
-#pragma unroll
-    for (int j = 0; j < FMR_PLL_GRP; j++) {
-      const int c = c0 + j;
-      if (c >= nck) break;
-      double p = mv[j] * delta_k;
-      p += __shfl_xor(p, 1, 64);
-      p += __shfl_xor(p, 2, 64);
-      p += __shfl_xor(p, 4, 64);      // (M delta)[r] on every lane of group r
-      double nv = gv[j] + p;
-      if (r == 0) {                   // keep the phase inside (0, 2 pi] like the reference
-        nv -= two_pi * floor(nv / two_pi);
-        if (nv <= 0.0) nv += two_pi;
-      }
-      if (r == 1) nv = fmax(minfreq, fmin(maxfreq, nv));   // the true freq never leaves the clamp range
-      double d = nv - ov[j];
-      if (r == 0) d = wrap_pm_pi(d);
-      if (r < 7 && k == 0) nd[(long long)(c + 1) * 7 + r] = nv;
-      // biquad delays: relative to the size of the (I,Q) delay pair, whose large component
-      // is ~level/b0 ~ 3e4; the small (quadrature) one carries no more precision than that
-      double scale = 1e-9 * (wm[j] + 1.0);
-      if (r == 0) scale = 1e-7; else if (r == 1) scale = 1e-9; else if (r == 2) scale = 1e-5;
-      if (r < 7) resid = fmax(resid, fabs(d) / scale);   // per lane: the residual of component r
-      delta_k = __shfl(d, src, 64);
+    if (i == 1) nv = fmax(minfreq, fmin(maxfreq, nv));   // the true freq never leaves the clamp range
+    if (act) {
+      nd[(long long)(c + 1) * 7 + i] = nv;
+      resid = fmax(resid, fabs(d) * inv_scale);
     }
-  };
-  load(0, mvA, gvA, ovA, wmA);
-  for (int c0 = 0; c0 < nck; c0 += 2 * FMR_PLL_GRP) {
-    load(c0 + FMR_PLL_GRP, mvB, gvB, ovB, wmB);
-    run(c0, mvA, gvA, ovA, wmA);
-    load(c0 + 2 * FMR_PLL_GRP, mvA, gvA, ovA, wmA);
-    run(c0 + FMR_PLL_GRP, mvB, gvB, ovB, wmB);
   }
-  if (k == 0 && r < 7) fl[s].pll_comp[r] = resid;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) resid = fmax(resid, __shfl_xor(resid, o, 64));
-  if (lane == 0) {
-    if (fl[s].pll_iters < 16) fl[s].pll_hist[fl[s].pll_iters] = resid;
-    fl[s].pll_iters++;
-    fl[s].pll_resid = resid;
-    if (resid <= tol) fl[s].pll_converged = 1;
+  if (act) {
+    // positive doubles order like their bit patterns: one atomicMax per lane
+    atomicMax((unsigned long long *)&fl[s].pll_resid_bits, (unsigned long long)__double_as_longlong(resid));
+    atomicMax((unsigned long long *)&fl[s].pll_comp_bits[i], (unsigned long long)__double_as_longlong(resid));
   }
+}
+
+// round bookkeeping: one thread per stream
+__global__ void k_pll_check(IterFlags *fl, int n_streams, double tol) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams || fl[s].pll_converged) return;
+  const double resid = __longlong_as_double((long long)fl[s].pll_resid_bits);
+  if (fl[s].pll_iters < 16) fl[s].pll_hist[fl[s].pll_iters] = resid;
+  fl[s].pll_iters++;
+  fl[s].pll_resid = resid;
+  for (int i = 0; i < 7; i++) { fl[s].pll_comp[i] = __longlong_as_double((long long)fl[s].pll_comp_bits[i]); fl[s].pll_comp_bits[i] = 0; }
+  fl[s].pll_resid_bits = 0;
+  if (resid <= tol) fl[s].pll_converged = 1;
 }
 
 // initial node guess: nominal ramp from the carried state
@@ -512,53 +582,81 @@ __global__ void k_pll_begin(double *__restrict__ nodes, ChunkTab ct, const Strea
   nd[3] = S.bq_i_x1; nd[4] = S.bq_i_x2; nd[5] = S.bq_q_x1; nd[6] = S.bq_q_x2;
 }
 
-// After convergence: per-block lock logic (PilotPhaseLock.cpp:154-167), PPS
-// events (:133-150) and the state commit.  One lane per stream.
-__global__ void k_pll_finish(const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt,
-                             ChunkTab ct, const float *__restrict__ atan_tab, PllConst pc, int pilot_shift,
-                             const double *__restrict__ nodes, const double *__restrict__ G,
-                             const int *__restrict__ ck_wraps, int *__restrict__ stereo_blk, StreamState *st,
-                             int n_streams, const IterFlags *__restrict__ fl) {
+// After convergence: per-block lock logic (PilotPhaseLock.cpp:154-167), PPS events
+// (:133-150) and the state commit.  k_pll_blocks reduces the chunk results to one
+// (wrap count, level) pair per block in parallel; k_pll_finish walks the blocks with one
+// wave per stream (64 blocks per load, values broadcast through SGPRs).
+__global__ void k_pll_blocks(BlockTab bt, ChunkTab ct, const double *__restrict__ G,
+                             const int *__restrict__ ck_wraps, int *__restrict__ blk_wraps,
+                             double *__restrict__ blk_level, const IterFlags *__restrict__ fl) {
+  const int s = blockIdx.y;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bt.nb || !fl[s].pll_converged || fl[s].pll_fallback) return;
+  int w = 0;
+  for (int c = ct.first[b]; c < ct.first[b + 1]; c++) w += ck_wraps[(long long)s * ct.nck + c];
+  blk_wraps[(long long)s * bt.nb + b] = w;
+  blk_level[(long long)s * bt.nb + b] =
+      (ct.first[b + 1] > ct.first[b]) ? G[((long long)s * ct.nck + (ct.first[b + 1] - 1)) * 9 + 7] : 0.0;
+}
+
+__global__ __launch_bounds__(64) void k_pll_finish(
+    const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt, ChunkTab ct,
+    const float *__restrict__ atan_tab, PllConst pc, int pilot_shift, const double *__restrict__ nodes,
+    const double *__restrict__ G, const int *__restrict__ ck_wraps, const int *__restrict__ blk_wraps,
+    const double *__restrict__ blk_level, int *__restrict__ stereo_blk, StreamState *st,
+    const IterFlags *__restrict__ fl) {
   __shared__ float tab[257];
   for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
   __syncthreads();
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_streams || !fl[s].pll_converged || fl[s].pll_fallback) return;
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (!fl[s].pll_converged || fl[s].pll_fallback) return;
   StreamState &S = st[s];
   int lock_cnt = S.lock_cnt, pilot_periods = S.pilot_periods;
   unsigned long long pps_cnt = S.pps_cnt, sample_cnt = S.sample_cnt;
   int n_pps = 0;
-  double level = S.pll_level;
-  for (int b = 0; b < bt.nb; b++) {
-    const int n = bt.if_len[b];
-    if (n == 0) { stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay); continue; }
-    const bool was_locked = (lock_cnt >= pc.lock_delay);
-    const int pps_blk_start = n_pps;
-    for (int c = ct.first[b]; c < ct.first[b + 1]; c++) {
-      const int w = ck_wraps[(long long)s * ct.nck + c];
+  long long wr = 0, ns = 0;
+  for (int b0 = 0; b0 < bt.nb; b0 += 64) {
+    const int bl = min(b0 + lane, bt.nb - 1);
+    const int my_n = bt.if_len[bl], my_w = blk_wraps[(long long)s * bt.nb + bl];
+    const double my_level = blk_level[(long long)s * bt.nb + bl];
+    int my_flag = 0;
+    const int cnt = min(64, bt.nb - b0);
+    for (int j = 0; j < cnt; j++) {
+      const int b = b0 + j;
+      const int n = __builtin_amdgcn_readlane(my_n, j);
+      const int w = __builtin_amdgcn_readlane(my_w, j);
+      const double level = readlane_d(my_level, j);
+      if (n == 0) { if (lane == j) my_flag = (lock_cnt >= pc.lock_delay); continue; }
+      const bool was_locked = (lock_cnt >= pc.lock_delay);
+      const int pps_blk_start = n_pps;
       if (pilot_periods + w >= pc.pilot_frequency) {
-        // the 19000th period ends inside this chunk: re-integrate it to find the sample
-        PllRegs R;
-        const double *nd = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
-        for (int k = 0; k < 7; k++) R.v[k] = nd[k];
-        const double *xin = base + (long long)s * base_stride + base_off + ct.off[c];
-        for (int i = 0; i < ct.len[c]; i++) {
-          double o;
-          if (pll_step<false>(R, xin[i], pc, tab, pilot_shift, o, nullptr)) {
-            pilot_periods++;
-            if (pilot_periods == pc.pilot_frequency) {
-              pilot_periods = 0;
-              if (was_locked) {
-                const int ib = ct.off[c] - bt.if_off[b] + i;   // index inside the block
-                if (n_pps < FMR_MAX_PPS) {
-                  PpsEventDev &ev = S.pps[n_pps];
-                  ev.pps_index = pps_cnt;
-                  ev.sample_index = sample_cnt + (unsigned long long)ib;
-                  ev.block_position = (double)ib / (double)n;
-                  ev.block = (unsigned)b;
+        // the 19000th period ends inside this block: walk its chunks, re-integrate the one that holds it
+        for (int c = ct.first[b]; c < ct.first[b + 1]; c++) {
+          const int cw = ck_wraps[(long long)s * ct.nck + c];
+          if (pilot_periods + cw < pc.pilot_frequency) { pilot_periods += cw; continue; }
+          PllRegs R;
+          const double *ndp = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
+          for (int k = 0; k < 7; k++) R.v[k] = ndp[k];
+          const double *xin = base + (long long)s * base_stride + base_off + ct.off[c];
+          for (int q = 0; q < ct.len[c]; q++) {
+            double o;
+            if (pll_step<false>(R, xin[q], pc, tab, pilot_shift, o, nullptr)) {
+              pilot_periods++;
+              if (pilot_periods == pc.pilot_frequency) {
+                pilot_periods = 0;
+                if (was_locked) {
+                  const int ib = ct.off[c] - bt.if_off[b] + q;   // index inside the block
+                  if (n_pps < FMR_MAX_PPS && lane == 0) {
+                    PpsEventDev &ev = S.pps[n_pps];
+                    ev.pps_index = pps_cnt;
+                    ev.sample_index = sample_cnt + (unsigned long long)ib;
+                    ev.block_position = (double)ib / (double)n;
+                    ev.block = (unsigned)b;
+                  }
+                  n_pps++;
+                  pps_cnt++;
                 }
-                n_pps++;
-                pps_cnt++;
               }
             }
           }
@@ -566,28 +664,28 @@ __global__ void k_pll_finish(const double *__restrict__ base, long long base_str
       } else {
         pilot_periods += w;
       }
+      wr += w; ns += n;
+      if (2 * level > pc.minsignal) {
+        if (lock_cnt < pc.lock_delay) lock_cnt += n;
+      } else {
+        lock_cnt = 0;
+      }
+      if (lock_cnt < pc.lock_delay) {
+        pilot_periods = 0;
+        pps_cnt = 0;
+        n_pps = pps_blk_start;
+      }
+      sample_cnt += (unsigned long long)n;
+      if (lane == j) my_flag = (lock_cnt >= pc.lock_delay);
     }
-    level = G[((long long)s * ct.nck + (ct.first[b + 1] - 1)) * 9 + 7];
-    if (2 * level > pc.minsignal) {
-      if (lock_cnt < pc.lock_delay) lock_cnt += n;
-    } else {
-      lock_cnt = 0;
-    }
-    if (lock_cnt < pc.lock_delay) {
-      pilot_periods = 0;
-      pps_cnt = 0;
-      n_pps = pps_blk_start;
-    }
-    sample_cnt += (unsigned long long)n;
-    stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay);
+    if (b0 + lane < bt.nb) stereo_blk[(long long)s * bt.nb + b0 + lane] = my_flag;
   }
+  if (lane != 0) return;
   if (ct.nck > 0) {
     const double *g = G + ((long long)s * ct.nck + (ct.nck - 1)) * 9;
-    long long wr = 0, ns = 0;
-    for (int c = 0; c < ct.nck; c++) { wr += ck_wraps[(long long)s * ct.nck + c]; ns += ct.len[c]; }
     if (ns >= 65536) {
       S.pll_favg = ((double)wr * 2.0 * 3.14159265358979323846 + (g[0] - S.pll_phase)) / (double)ns;
-      S.pll_favg_valid = (S.lock_cnt >= pc.lock_delay) ? 1 : 0;
+      S.pll_favg_valid = (lock_cnt >= pc.lock_delay) ? 1 : 0;
     }
     S.pll_phase = g[0]; S.pll_freq = g[1]; S.lf_x1 = g[2];
     S.bq_i_x1 = g[3]; S.bq_i_x2 = g[4]; S.bq_q_x1 = g[5]; S.bq_q_x2 = g[6];
@@ -613,7 +711,7 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
   PllRegs R;
   R.v[0] = S.pll_phase; R.v[1] = S.pll_freq; R.v[2] = S.lf_x1;
   R.v[3] = S.bq_i_x1; R.v[4] = S.bq_i_x2; R.v[5] = S.bq_q_x1; R.v[6] = S.bq_q_x2;
-  R.level = S.pll_level; R.freq_err = S.pll_freq_err;
+  R.li = S.pll_level; R.lq = 0.0; R.freq_err = S.pll_freq_err;
   int lock_cnt = S.lock_cnt, pilot_periods = S.pilot_periods;
   unsigned long long pps_cnt = S.pps_cnt, sample_cnt = S.sample_cnt;
   int n_pps = 0;
@@ -649,7 +747,7 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
       }
       out[off + i] = o;
     }
-    if (2 * R.level > pc.minsignal) {
+    if (2 * pll_level(R) > pc.minsignal) {
       if (lock_cnt < pc.lock_delay) lock_cnt += n;
     } else {
       lock_cnt = 0;
@@ -665,7 +763,7 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
   }
   S.pll_phase = R.v[0]; S.pll_freq = R.v[1]; S.lf_x1 = R.v[2];
   S.bq_i_x1 = R.v[3]; S.bq_i_x2 = R.v[4]; S.bq_q_x1 = R.v[5]; S.bq_q_x2 = R.v[6];
-  S.pll_level = R.level; S.pll_freq_err = R.freq_err;
+  S.pll_level = pll_level(R); S.pll_freq_err = R.freq_err;
   S.lock_cnt = lock_cnt; S.pilot_periods = pilot_periods; S.pps_cnt = pps_cnt; S.sample_cnt = sample_cnt;
   S.n_pps = n_pps < FMR_MAX_PPS ? n_pps : FMR_MAX_PPS;
   S.stereo_detected = (lock_cnt >= pc.lock_delay);
