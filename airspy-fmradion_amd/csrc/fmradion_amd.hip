@@ -54,7 +54,7 @@ constexpr double kIfAtten = 140.0;     // resampler spec, DESIGN.md
 constexpr double kAudioAtten = 180.0;
 constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
-constexpr int C_AGC = 256, C_DC = 1024, C_DE = 512;
+constexpr int C_AGC = 256, C_DC = 512, C_DE = 256;
 constexpr int C_PLL_MIN = 128;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
 constexpr int K_AGC_ITERS = 8, K_PLL_ITERS = 6;
 
@@ -108,6 +108,8 @@ struct fmr_chain {
       d_dc_G, d_dc_start;
   DevBuf<float> d_agc_nodes, d_agc_G;
   DevBuf<int> d_ck_wraps, d_blk_wraps;
+  DevBuf<unsigned long long> d_ck_mask;
+  int mask_words = 2;
   DevBuf<IterFlags> d_flags;
   std::vector<IterFlags> h_flags;
   // block tables: ring of pinned host slots + device slots so that queued
@@ -142,7 +144,7 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_ck_mask.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
@@ -321,6 +323,9 @@ int fmr_chain::init(const fmr_config *c) {
       if ((rc = d_pll_PQ.alloc((size_t)S * max_grp * 56))) return rc;
       if ((rc = d_pll_dstart.alloc((size_t)S * max_grp * 7))) return rc;
     }
+    c_pll = ((c_pll + 63) / 64) * 64;
+    mask_words = c_pll / 64;
+    if ((rc = d_ck_mask.alloc((size_t)S * max_ck * mask_words))) return rc;
     if ((rc = d_blk_wraps.alloc((size_t)S * max_blocks))) return rc;
     if ((rc = d_blk_level.alloc((size_t)S * max_blocks))) return rc;
     max_dc_nc = max_au / C_DC + 2;
@@ -533,7 +538,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);
     });
     timed("stats", [&] {
-      hipLaunchKernelGGL(k_stats, dim3((S + 63) / 64), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+      hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
                          d_bb_rms_blk.p, d_state.p, S, 1);
     });
     if (stereo) {
@@ -553,11 +558,11 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
             if (it < 2)
               hipLaunchKernelGGL(k_pll_shoot<true>, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p,
                                  base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
-                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_flags.p);
+                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p);
             else
               hipLaunchKernelGGL(k_pll_shoot<false>, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p,
                                  base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
-                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_flags.p);
+                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p);
             hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                                nck, d_pll_PQ.p, d_flags.p);
             hipLaunchKernelGGL(k_pll_nodes_b, dim3(S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_dstart.p,
@@ -572,8 +577,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
           hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, stream, bt, ct, d_pll_G.p,
                              d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
           hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt, ct, d_atan.p,
-                             pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_blk_wraps.p,
-                             d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
+                             pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
+                             d_blk_wraps.p, d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
         });
       }
     }
@@ -622,8 +627,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         timed("fm_out", [&] {
           hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
                              (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc);
-          hipLaunchKernelGGL(k_dc_nodes, dim3((S * nch + 63) / 64), dim3(64), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc,
-                             dk, d_state.p, S, nch);
+          hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
+                             d_state.p, S, nch);
           hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
                              (long long)max_au, bt, (int)N_au, dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,
                              d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
@@ -647,7 +652,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          (long long)max_if, d_bb_mean_blk.p, d_bb_rms_blk.p);
     });
     timed("stats", [&] {
-      hipLaunchKernelGGL(k_stats, dim3((S + 63) / 64), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+      hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
                          d_bb_rms_blk.p, d_state.p, S, 0);
     });
     timed("am_tail", [&] {

@@ -77,6 +77,35 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Serial per-lane loops over global memory: issue U independent loads first, then
+// run the U dependent steps, so one memory latency is paid per U samples instead of
+// per sample (the recurrences themselves cannot be reordered).
+template <int U, class T, class F>
+__device__ __forceinline__ void serial_prefetch(const T *__restrict__ p, int i0, int i1, F &&f) {
+  int i = i0;
+  for (; i + U <= i1; i += U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = p[i + u];
+#pragma unroll
+    for (int u = 0; u < U; u++) f(i + u, v[u]);
+  }
+  for (; i < i1; i++) f(i, p[i]);
+}
+template <int U, class T, class T2, class F>
+__device__ __forceinline__ void serial_prefetch2(const T *__restrict__ p, const T2 *__restrict__ q, int i0, int i1, F &&f) {
+  int i = i0;
+  for (; i + U <= i1; i += U) {
+    T v[U];
+    T2 w[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { v[u] = p[i + u]; w[u] = q[i + u]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) f(i + u, v[u], w[u]);
+  }
+  for (; i < i1; i++) f(i, p[i], q[i]);
+}
+
 template <int BLOCK>
 __device__ __forceinline__ float block_sum(float v, float *scratch /* BLOCK/64 */) {
   v = wave_sum(v);
@@ -578,19 +607,37 @@ __global__ __launch_bounds__(BLOCK) void k_am_demod(
 // last block, the 0.95/0.05 EMAs (FmDecode.cpp:149-150, AmDecode.cpp:208-209),
 // commit of the discriminator's carried phase.
 // ---------------------------------------------------------------------------
-__global__ void k_stats(BlockTab bt, const float *__restrict__ if_rms_blk, const float *__restrict__ bb_mean_blk,
-                        const float *__restrict__ bb_rms_blk, StreamState *st, int n_streams, int has_disc) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// one wave per stream: 64 block results per load, the EMA chain runs on SGPR broadcasts
+__global__ __launch_bounds__(64) void k_stats(BlockTab bt, const float *__restrict__ if_rms_blk,
+                                              const float *__restrict__ bb_mean_blk,
+                                              const float *__restrict__ bb_rms_blk, StreamState *st, int n_streams,
+                                              int has_disc) {
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
   if (s >= n_streams) return;
   float m = st[s].baseband_mean, l = st[s].baseband_level, r = st[s].if_rms;
-  for (int b = 0; b < bt.nb; b++) {
-    if (bt.if_len[b] == 0) continue;
-    r = if_rms_blk[(long long)s * bt.nb + b];
-    m = (float)(0.95 * (double)m + 0.05 * (double)bb_mean_blk[(long long)s * bt.nb + b]);
-    l = (float)(0.95 * (double)l + 0.05 * (double)bb_rms_blk[(long long)s * bt.nb + b]);
+  for (int b0 = 0; b0 < bt.nb; b0 += 64) {
+    const int b = min(b0 + lane, bt.nb - 1);
+    const int my_n = bt.if_len[b];
+    const float my_r = if_rms_blk[(long long)s * bt.nb + b];
+    const float my_m = bb_mean_blk[(long long)s * bt.nb + b];
+    const float my_l = bb_rms_blk[(long long)s * bt.nb + b];
+    const int cnt = min(64, bt.nb - b0);
+    for (int j = 0; j < cnt; j++) {
+      if (__builtin_amdgcn_readlane(my_n, j) == 0) continue;
+      r = readlane_f(my_r, j);
+      m = (float)(0.95 * (double)m + 0.05 * (double)readlane_f(my_m, j));
+      l = (float)(0.95 * (double)l + 0.05 * (double)readlane_f(my_l, j));
+    }
   }
-  st[s].baseband_mean = m; st[s].baseband_level = l; st[s].if_rms = r;
-  if (has_disc && st[s].disc_save_valid) { st[s].disc_save = st[s].disc_save_next; st[s].disc_save_valid = 0; }
+  if (lane == 0) {
+    st[s].baseband_mean = m; st[s].baseband_level = l; st[s].if_rms = r;
+    if (has_disc && st[s].disc_save_valid) { st[s].disc_save = st[s].disc_save_next; st[s].disc_save_valid = 0; }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -751,9 +798,18 @@ __global__ __launch_bounds__(BLOCK) void k_aud_decim(
   if (m >= count) return;
   const double *x = (ch ? x1 : x0) + (long long)s * x_stride + x_off;
   double *y = (ch ? y1 : y0) + (long long)s * y_stride + y_off;
-  const double *xp = x + top0 + (long long)m * D;
+  const double *xp = x + top0 + (long long)m * D - (NA - 1);   // oldest tap first in memory
   double acc = 0.0;
-  for (int k = 0; k < NA; k++) acc += hA[k] * xp[-k];
+  // acc += hA[k] * x[top - k], k ascending: walk memory backwards, 8 loads in flight
+  int k = 0;
+  for (; k + 8 <= NA; k += 8) {
+    double xv[8], hv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { xv[u] = xp[(NA - 1) - (k + u)]; hv[u] = hA[k + u]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += hv[u] * xv[u];
+  }
+  for (; k < NA; k++) acc += hA[k] * xp[(NA - 1) - k];
   y[m] = acc;
 }
 
@@ -773,7 +829,7 @@ __global__ __launch_bounds__(BLOCK) void k_aud_poly(
   const double *h = hB + (size_t)p * TB;
   const double *xp = mid + (nk - (TB >> 1) + 1 - mid_abs0);
   double acc = 0.0;
-  for (int j = 0; j < TB; j++) acc += h[j] * xp[j];
+  serial_prefetch2<8>(h, xp, 0, TB, [&](int, double hv, double xv) { acc += hv * xv; });
   y[k] = acc;
 }
 

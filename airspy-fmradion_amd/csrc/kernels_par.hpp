@@ -38,6 +38,13 @@ struct IterFlags {
   unsigned long long pll_resid_bits, pll_comp_bits[8];   // atomicMax accumulators of the running round
 };
 
+// broadcast a double from one lane to the whole wave through SGPRs (v_readlane)
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------
 // De-emphasis by warm-up (LowPassFilterRC::process_inplace, Filter.cpp:214-221)
 // ---------------------------------------------------------------------------
@@ -58,11 +65,11 @@ __global__ void k_deemph_par(const double *__restrict__ in0, const double *__res
     return;
   }
   double w = 0.0;
-  for (int i = start - FMR_DE_WARMUP; i < start; i++) w = x[i] - a1 * w;
-  for (int i = start; i < end; i++) {
-    w = x[i] - a1 * w;
+  serial_prefetch<8>(x, start - FMR_DE_WARMUP, start, [&](int, double v) { w = v - a1 * w; });
+  serial_prefetch<8>(x, start, end, [&](int i, double v) {
+    w = v - a1 * w;
     y[i] = b0 * w;      // b1 == 0
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -80,29 +87,39 @@ __global__ void k_dc_pass1(const double *__restrict__ p0, const double *__restri
   const double *p = (ch ? p1 : p0) + (long long)s * p_stride;
   const int start = c * C, end = min(start + C, n);
   double x1 = 0.0, x2 = 0.0;
-  for (int i = start; i < end; i++) {
-    const double x0 = p[i] - (k.a1 * x1 + k.a2 * x2);
+  serial_prefetch<8>(p, start, end, [&](int, double v) {
+    const double x0 = v - (k.a1 * x1 + k.a2 * x2);
     x2 = x1; x1 = x0;
-  }
+  });
   double *g = G + (((long long)s * 2 + ch) * nc + c) * 2;
   g[0] = x1; g[1] = x2;
 }
 
-// node pass: start[c+1] = G[c] + A^C start[c]; one lane per (stream, channel)
-__global__ void k_dc_nodes(const double *__restrict__ G, double *__restrict__ start, int nc, DcCoef k,
-                           StreamState *st, int n_streams, int nch) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// node pass: start[c+1] = G[c] + A^C start[c]; one wave per (stream, channel): the
+// lanes fetch 64 chunk results at once, the short recurrence runs on broadcast values.
+__global__ __launch_bounds__(64) void k_dc_nodes(const double *__restrict__ G, double *__restrict__ start, int nc,
+                                                  DcCoef k, StreamState *st, int n_streams, int nch) {
+  const int t = blockIdx.x;
   const int s = t / nch, ch = t % nch;
+  const int lane = threadIdx.x;
   if (s >= n_streams) return;
   const double *g = G + (((long long)s * 2 + ch) * nc) * 2;
   double *o = start + (((long long)s * 2 + ch) * nc) * 2;
   double x1 = ch ? st[s].dc_st_x1 : st[s].dc_mono_x1;
   double x2 = ch ? st[s].dc_st_x2 : st[s].dc_mono_x2;
-  for (int c = 0; c < nc; c++) {
-    o[2 * c] = x1; o[2 * c + 1] = x2;
-    const double n1 = g[2 * c] + (k.ac[0] * x1 + k.ac[1] * x2);
-    const double n2 = g[2 * c + 1] + (k.ac[2] * x1 + k.ac[3] * x2);
-    x1 = n1; x2 = n2;
+  for (int c0 = 0; c0 < nc; c0 += 64) {
+    const int c = min(c0 + lane, nc - 1);
+    const double g1 = g[2 * c], g2 = g[2 * c + 1];
+    double o1 = 0.0, o2 = 0.0;
+    const int cnt = min(64, nc - c0);
+    for (int j = 0; j < cnt; j++) {
+      if (lane == j) { o1 = x1; o2 = x2; }
+      const double gj1 = readlane_d(g1, j), gj2 = readlane_d(g2, j);
+      const double n1 = gj1 + (k.ac[0] * x1 + k.ac[1] * x2);
+      const double n2 = gj2 + (k.ac[2] * x1 + k.ac[3] * x2);
+      x1 = n1; x2 = n2;
+    }
+    if (c0 + lane < nc) { o[2 * (c0 + lane)] = o1; o[2 * (c0 + lane) + 1] = o2; }
   }
 }
 
@@ -135,12 +152,12 @@ __global__ void k_dc_pass2_mux(const double *__restrict__ p0, const double *__re
   }
   int bend = stereo ? bt.au_off[b] + bt.au_len[b] : n;
   int locked = stereo ? stereo_blk[(long long)s * bt.nb + b] : 0;
-  for (int i = i0; i < i1; i++) {
-    double x0 = m[i] - (k.a1 * m1 + k.a2 * m2);
+  serial_prefetch2<8>(m, stereo ? d : m, i0, i1, [&](int i, double mv, double dv) {
+    double x0 = mv - (k.a1 * m1 + k.a2 * m2);
     const double mm = k.b0 * x0 + k.b1 * m1 + k.b2 * m2;
     m2 = m1; m1 = x0;
-    if (!stereo) { out[i] = mm; continue; }
-    x0 = d[i] - (k.a1 * d1 + k.a2 * d2);
+    if (!stereo) { out[i] = mm; return; }
+    x0 = dv - (k.a1 * d1 + k.a2 * d2);
     const double dd = k.b0 * x0 + k.b1 * d1 + k.b2 * d2;
     d2 = d1; d1 = x0;
     while (i >= bend && b < bt.nb - 1) {
@@ -156,7 +173,7 @@ __global__ void k_dc_pass2_mux(const double *__restrict__ p0, const double *__re
       if (pilot_shift) { l = r = 0.0; } else { l = r = mm; }
     }
     out[2 * i] = l; out[2 * i + 1] = r;
-  }
+  });
   if (c == nc - 1) {
     st[s].dc_mono_x1 = m1; st[s].dc_mono_x2 = m2;
     if (stereo) { st[s].dc_st_x1 = d1; st[s].dc_st_x2 = d2; }
@@ -180,8 +197,7 @@ __global__ void k_agc_shoot(const float2 *__restrict__ x, long long x_stride, in
   float g = nodes[(long long)s * (nc + 1) + c];
   double dg = 1.0;
   const double r = (double)rate;
-  for (int i = i0; i < i1; i++) {
-    const float2 v = xs[i];
+  serial_prefetch<8>(xs, i0, i1, [&](int i, float2 v) {
     gs[i] = g;
     const float xr = v.x * g, xi = v.y * g;
     const float nrm = xr * xr + xi * xi;
@@ -192,12 +208,15 @@ __global__ void k_agc_shoot(const float2 *__restrict__ x, long long x_stride, in
     g = gn;
     if (!isfinite(g)) { g = initial_gain; dg = 0.0; }
     else if (g > max_gain) { g = max_gain; dg = 0.0; }
-  }
+  });
   G[(long long)s * nc + c] = g;
   M[(long long)s * nc + c] = dg;
 }
 
-// node pass: v[c+1] = G[c] + M[c] (v[c] - old[c]); wave-parallel affine scan.
+// node pass: v[c+1] = G[c] + M[c] (v[c] - old[c]); affine scan: every lane composes 8
+// consecutive chunk maps serially, one wave scan covers 512 chunks, then every lane
+// replays its 8 maps from its scanned start value.
+#define FMR_AGC_PER_LANE 8
 __global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, const float *__restrict__ G,
                                                   const double *__restrict__ M, int nc, StreamState *st,
                                                   IterFlags *fl) {
@@ -207,32 +226,49 @@ __global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, con
   float *nd = nodes + (long long)s * (nc + 1);
   const float *g = G + (long long)s * nc;
   const double *m = M + (long long)s * nc;
+  constexpr int K = FMR_AGC_PER_LANE;
   double carry = (double)nd[0];   // v[0] is the carried state, fixed
-  float old_first = nd[0];        // OLD value of nd[c0] (the previous step overwrote nd[c0])
   float maxrel = 0.f;
-  for (int c0 = 0; c0 < nc; c0 += 64) {
-    const int c = c0 + lane;
-    double a = 1.0, b = 0.0;
-    float old_next = 0.f;
-    if (c < nc) {
-      const float old_c = (lane == 0) ? old_first : nd[c];
-      old_next = nd[c + 1];
-      a = m[c];
-      b = (double)g[c] - a * (double)old_c;
+  for (int c0 = 0; c0 < nc; c0 += 64 * K) {
+    const int cb = c0 + lane * K;
+    double a[K], b[K];
+    float oldn[K];
+    // maps of this lane: v' = a v + b with b = G - a*old (old read before any write of this tile)
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const int c = cb + j;
+      if (c < nc) {
+        a[j] = m[c];
+        b[j] = (double)g[c] - a[j] * (double)nd[c];
+        oldn[j] = nd[c + 1];
+      } else { a[j] = 1.0; b[j] = 0.0; oldn[j] = 0.f; }
     }
-    // inclusive scan of affine maps: (a,b) o (pa,pb) = (a*pa, a*pb + b)
+    double ca = 1.0, cbv = 0.0;               // composition of the lane's K maps
+#pragma unroll
+    for (int j = 0; j < K; j++) { cbv = a[j] * cbv + b[j]; ca = a[j] * ca; }
+    // inclusive wave scan of the lane maps
+    double sa = ca, sb = cbv;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const double pa = __shfl_up(a, o, 64), pb = __shfl_up(b, o, 64);
-      if (lane >= o) { b = a * pb + b; a = a * pa; }
+      const double pa = __shfl_up(sa, o, 64), pb = __shfl_up(sb, o, 64);
+      if (lane >= o) { sb = sa * pb + sb; sa = sa * pa; }
     }
-    const float vf = (float)(a * carry + b);       // v[c+1]
-    if (c < nc) {
-      nd[c + 1] = vf;
-      maxrel = fmaxf(maxrel, fabsf(vf - old_next) / fmaxf(fabsf(vf), 1e-30f));
+    // exclusive value = start of this lane's first chunk
+    double ea = __shfl_up(sa, 1, 64), eb = __shfl_up(sb, 1, 64);
+    if (lane == 0) { ea = 1.0; eb = 0.0; }
+    double v = ea * carry + eb;
+    __syncthreads();                          // all old values of the tile are in registers
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const int c = cb + j;
+      v = a[j] * v + b[j];
+      const float vf = (float)v;
+      if (c < nc) {
+        nd[c + 1] = vf;
+        maxrel = fmaxf(maxrel, fabsf(vf - oldn[j]) / fmaxf(fabsf(vf), 1e-30f));
+      }
     }
-    carry = (double)__shfl(vf, 63, 64);            // lanes past nc hold identity maps
-    old_first = __shfl(old_next, 63, 64);
+    carry = (double)(float)(__shfl(sa, 63, 64) * carry + __shfl(sb, 63, 64));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) maxrel = fmaxf(maxrel, __shfl_xor(maxrel, o, 64));
@@ -240,16 +276,14 @@ __global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, con
     if (fl[s].agc_iters < 16) fl[s].agc_hist[fl[s].agc_iters] = maxrel;
     fl[s].agc_iters++;
     fl[s].agc_resid = maxrel;
-    // Float state: the Newton map is only defined up to a few ulp of rounding noise
-    // (each chunk re-rounds 256 times), so "converged" = node changes <= 8 ulp.
     // Two regimes.  Amplitude-modulated input (AM): z moves by many ulps per sample,
     // the map is smooth and Newton reaches <= 1e-6 in 2-4 rounds.  Constant-envelope
     // input (FM): |r (1 - |x g|^2)| < ulp(1)/2 most of the time, so z == 1.0f exactly
     // and the reference's gain only random-walks inside a dead zone ~3e-4 wide; there
     // the chunk map has no usable slope and the rounds stagnate at a few 1e-5.  That
     // is also the level at which the reference's own gain depends on FMA contraction
-    // (hazard H7), and atan2 is invariant to it: accept <= 5e-5 after 4 rounds.
-    if (maxrel <= 1.0e-6f || (fl[s].agc_iters >= 4 && maxrel <= 5.0e-5f)) {   // gains of the last shoot pass stand
+    // (hazard H7), and atan2 is invariant to it: accept <= 5e-5 from round 2 on.
+    if (maxrel <= 1.0e-6f || (fl[s].agc_iters >= 2 && maxrel <= 5.0e-5f)) {   // gains of the last shoot pass stand
       fl[s].agc_converged = 1;
       st[s].agc_gain = nd[nc];
     }
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
                             double *__restrict__ raw, long long raw_stride, int raw_off,
                             const float *__restrict__ atan_tab, PllConst pc, int pilot_shift,
                             const double *__restrict__ nodes, double *__restrict__ G, double *__restrict__ M,
-                            int *__restrict__ ck_wraps,
+                            int *__restrict__ ck_wraps, unsigned long long *__restrict__ ck_mask, int mask_words,
                             const IterFlags *__restrict__ fl) {
   __shared__ float tab[257];
   for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
@@ -396,11 +430,19 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
 #pragma unroll
     for (int k = 0; k < 7; k++) Mx[r][k] = (r == k) ? 1.0 : 0.0;
   int wraps = 0;
-  for (int i = 0; i < n; i++) {
+  // positions of the phase wraps inside the chunk (bit i = sample i wrapped): lets the
+  // finish pass place a PPS event without re-integrating the chunk
+  unsigned long long *mk = ck_mask + ((long long)s * ct.nck + c) * mask_words;
+  unsigned long long word = 0;
+  serial_prefetch<4>(xin, 0, n, [&](int i, double xv) {
     double o;
-    wraps += pll_step<JAC>(S, xin[i], pc, tab, pilot_shift, o, Mx);
+    const int wflag = pll_step<JAC>(S, xv, pc, tab, pilot_shift, o, Mx);
+    wraps += wflag;
+    word |= (unsigned long long)wflag << (i & 63);
+    if ((i & 63) == 63) { mk[i >> 6] = word; word = 0; }
     out[i] = o;
-  }
+  });
+  if (n & 63) mk[n >> 6] = word;
   double *g = G + ((long long)s * ct.nck + c) * 9;
 #pragma unroll
   for (int k = 0; k < 7; k++) g[k] = S.v[k];
@@ -428,13 +470,7 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
 // ~1e-9 in lock), i.e. ~7e-11 in freq per flip; scales sit above that floor:
 // phase 1e-7 rad, freq 1e-9, phase error 1e-5, biquad delays 1e-7 of the (I,Q) pair.
 // ---------------------------------------------------------------------------
-#define FMR_NODE_GRP 32
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
+#define FMR_NODE_GRP 64
 // mismatch r[c][i] = G[c][i] - old[c+1][i]
 __device__ __forceinline__ double pll_mismatch(const double *g, const double *nd, int c, int i) {
   double v = g[(long long)c * 9 + i] - nd[(long long)(c + 1) * 7 + i];
@@ -473,7 +509,9 @@ __global__ __launch_bounds__(64) void k_pll_nodes_a(const double *__restrict__ n
   if (act) PQ[(((long long)s * gridDim.x + grp) * 7 + i) * 8 + k] = val;
 }
 
-// Phase B: delta at the start of every group (one wave per stream, lane i = component i)
+// Phase B: delta at the start of every group (one wave per stream, lane i = component i);
+// the rows of the group maps are fetched two batches ahead of the dependent chain.
+struct PqRow { double v[8]; };
 __global__ __launch_bounds__(64) void k_pll_nodes_b(const double *__restrict__ PQ, int ngrp,
                                                     double *__restrict__ dstart, const IterFlags *__restrict__ fl) {
   const int s = blockIdx.x, i = threadIdx.x;
@@ -483,17 +521,36 @@ __global__ __launch_bounds__(64) void k_pll_nodes_b(const double *__restrict__ P
   const double *pq = PQ + (long long)s * ngrp * 56;
   double *ds = dstart + (long long)s * ngrp * 7;
   double d = 0.0;
-  for (int gq = 0; gq < ngrp; gq++) {
-    if (act) ds[(long long)gq * 7 + i] = d;
-    double row[8];
+  constexpr int NB = 4;
+  PqRow A[NB], B[NB];
+  auto load = [&](int g0, PqRow *L) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) row[k] = pq[((long long)gq * 7 + ii) * 8 + k];
-    const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2 = readlane_d(d, 2), d3 = readlane_d(d, 3),
-                 d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
-    const double p0 = fma(row[0], d0, fma(row[1], d1, row[7]));
-    const double p1 = fma(row[2], d2, row[3] * d3);
-    const double p2 = fma(row[4], d4, fma(row[5], d5, row[6] * d6));
-    d = p0 + (p1 + p2);
+    for (int j = 0; j < NB; j++) {
+      const int gq = min(g0 + j, ngrp - 1);
+#pragma unroll
+      for (int k = 0; k < 8; k++) L[j].v[k] = pq[((long long)gq * 7 + ii) * 8 + k];
+    }
+  };
+  auto run = [&](int g0, const PqRow *L) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      const int gq = g0 + j;
+      if (gq >= ngrp) break;
+      if (act) ds[(long long)gq * 7 + i] = d;
+      const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2 = readlane_d(d, 2), d3 = readlane_d(d, 3),
+                   d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
+      const double p0 = fma(L[j].v[0], d0, fma(L[j].v[1], d1, L[j].v[7]));
+      const double p1 = fma(L[j].v[2], d2, L[j].v[3] * d3);
+      const double p2 = fma(L[j].v[4], d4, fma(L[j].v[5], d5, L[j].v[6] * d6));
+      d = p0 + (p1 + p2);
+    }
+  };
+  load(0, A);
+  for (int g0 = 0; g0 < ngrp; g0 += 2 * NB) {
+    load(g0 + NB, B);
+    run(g0, A);
+    load(g0 + 2 * NB, A);
+    run(g0 + NB, B);
   }
 }
 
@@ -602,12 +659,9 @@ __global__ void k_pll_blocks(BlockTab bt, ChunkTab ct, const double *__restrict_
 __global__ __launch_bounds__(64) void k_pll_finish(
     const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt, ChunkTab ct,
     const float *__restrict__ atan_tab, PllConst pc, int pilot_shift, const double *__restrict__ nodes,
-    const double *__restrict__ G, const int *__restrict__ ck_wraps, const int *__restrict__ blk_wraps,
-    const double *__restrict__ blk_level, int *__restrict__ stereo_blk, StreamState *st,
-    const IterFlags *__restrict__ fl) {
-  __shared__ float tab[257];
-  for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
-  __syncthreads();
+    const double *__restrict__ G, const int *__restrict__ ck_wraps, const unsigned long long *__restrict__ ck_mask,
+    int mask_words, const int *__restrict__ blk_wraps, const double *__restrict__ blk_level,
+    int *__restrict__ stereo_blk, StreamState *st, const IterFlags *__restrict__ fl) {
   const int s = blockIdx.x;
   const int lane = threadIdx.x;
   if (!fl[s].pll_converged || fl[s].pll_fallback) return;
@@ -631,36 +685,36 @@ __global__ __launch_bounds__(64) void k_pll_finish(
       const bool was_locked = (lock_cnt >= pc.lock_delay);
       const int pps_blk_start = n_pps;
       if (pilot_periods + w >= pc.pilot_frequency) {
-        // the 19000th period ends inside this block: walk its chunks, re-integrate the one that holds it
+        // the 19000th period ends inside this block: find the chunk and the sample from the wrap masks
+        int kth = pc.pilot_frequency - pilot_periods;      // the kth wrap of this block (1-based)
+        int after = w - kth;                                // wraps of the block after the event
         for (int c = ct.first[b]; c < ct.first[b + 1]; c++) {
           const int cw = ck_wraps[(long long)s * ct.nck + c];
-          if (pilot_periods + cw < pc.pilot_frequency) { pilot_periods += cw; continue; }
-          PllRegs R;
-          const double *ndp = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
-          for (int k = 0; k < 7; k++) R.v[k] = ndp[k];
-          const double *xin = base + (long long)s * base_stride + base_off + ct.off[c];
-          for (int q = 0; q < ct.len[c]; q++) {
-            double o;
-            if (pll_step<false>(R, xin[q], pc, tab, pilot_shift, o, nullptr)) {
-              pilot_periods++;
-              if (pilot_periods == pc.pilot_frequency) {
-                pilot_periods = 0;
-                if (was_locked) {
-                  const int ib = ct.off[c] - bt.if_off[b] + q;   // index inside the block
-                  if (n_pps < FMR_MAX_PPS && lane == 0) {
-                    PpsEventDev &ev = S.pps[n_pps];
-                    ev.pps_index = pps_cnt;
-                    ev.sample_index = sample_cnt + (unsigned long long)ib;
-                    ev.block_position = (double)ib / (double)n;
-                    ev.block = (unsigned)b;
-                  }
-                  n_pps++;
-                  pps_cnt++;
-                }
-              }
-            }
+          if (kth > cw) { kth -= cw; continue; }
+          const unsigned long long *mk = ck_mask + ((long long)s * ct.nck + c) * mask_words;
+          int q = -1;
+          for (int wd = 0; wd < mask_words && q < 0; wd++) {
+            unsigned long long m = mk[wd];
+            const int pc_ = __popcll(m);
+            if (kth > pc_) { kth -= pc_; continue; }
+            for (int t = 1; t < kth; t++) m &= m - 1;       // drop the kth-1 lowest set bits
+            q = wd * 64 + (__ffsll((long long)m) - 1);
           }
+          if (was_locked) {
+            const int ib = ct.off[c] - bt.if_off[b] + q;   // index inside the block
+            if (n_pps < FMR_MAX_PPS && lane == 0) {
+              PpsEventDev &ev = S.pps[n_pps];
+              ev.pps_index = pps_cnt;
+              ev.sample_index = sample_cnt + (unsigned long long)ib;
+              ev.block_position = (double)ib / (double)n;
+              ev.block = (unsigned)b;
+            }
+            n_pps++;
+            pps_cnt++;
+          }
+          break;
         }
+        pilot_periods = after;
       } else {
         pilot_periods += w;
       }
