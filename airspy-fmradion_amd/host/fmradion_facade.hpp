@@ -1,0 +1,235 @@
+// fmradion_facade.hpp -- C++ facade above the C-ABI (include/fmradion_amd.h) with
+// the reference's class names, constructor arguments and member signatures, so
+// that the reference's stream loop (main.cpp:879-1002) compiles against it
+// unchanged:
+//
+//   FourthConverterIQ   include/FourthConverterIQ.h:30-82
+//   IfResampler         include/IfResampler.h:28-44
+//   FmDecoder           include/FmDecode.h:35-164
+//   AmDecoder           include/AmDecode.h:33-103
+//   FilterParameters    include/FilterParameters.h:29-53
+//
+// Header-only; link with libfmradion_amd.so.  Every process() call is one
+// fmr_process()/fmr_resample() on a one-stream chain (host buffers in, host
+// buffers out); the batched device-resident entry points of the C-ABI are what
+// bench.py and multi-stream users call directly.
+//
+// Differences a maintainer has to know (all stated in DESIGN.md):
+//  * FourthConverterIQ + IfResampler + decoder can be fused into ONE chain
+//    (FmDecoder::attach_front_end) so that the IF samples never leave HBM; used
+//    separately they behave like the reference classes (IF samples round-trip
+//    through host vectors, as in main.cpp).
+//  * IfResampler / AudioResampler arithmetic is this project's resampler
+//    specification, not r8brain's (absent from the reference tree).
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/fmradion_amd.h"
+
+using IQSample = std::complex<float>;
+using IQSampleVector = std::vector<IQSample>;
+using IQSampleDecodedVector = std::vector<float>;
+using Sample = double;
+using SampleVector = std::vector<Sample>;
+using IQSampleCoeff = std::vector<IQSample::value_type>;
+using SampleCoeff = std::vector<SampleVector::value_type>;
+enum class ModType { FM, NBFM, AM, DSB, USB, LSB, CW, WSPR };   // include/SoftFM.h:49
+
+namespace fmr_detail {
+inline void check(int rc, const char *what) {
+  if (rc != FMR_OK) throw std::runtime_error(std::string(what) + ": " + fmr_last_error());
+}
+inline fmr_chain *make(const fmr_config &cfg) {
+  fmr_chain *c = nullptr;
+  check(fmr_create(&cfg, &c), "fmr_create");
+  return c;
+}
+}  // namespace fmr_detail
+
+// FilterParameters (include/FilterParameters.h:31-49): tables served by the library.
+struct FilterParameters {
+  static IQSampleCoeff iq(const char *name) {
+    const void *p = nullptr;
+    int dbl = 0;
+    const int n = fmr_filter_table(name, &p, &dbl);
+    if (n < 0 || dbl) throw std::runtime_error("unknown IQ filter table");
+    const float *f = static_cast<const float *>(p);
+    return IQSampleCoeff(f, f + n);
+  }
+  static SampleCoeff audio(const char *name) {
+    const void *p = nullptr;
+    int dbl = 0;
+    const int n = fmr_filter_table(name, &p, &dbl);
+    if (n < 0 || !dbl) throw std::runtime_error("unknown audio filter table");
+    const double *f = static_cast<const double *>(p);
+    return SampleCoeff(f, f + n);
+  }
+  static inline const IQSampleCoeff delay_3taps_only_iq = {0.0f, 1.0f, 0.0f};
+  static inline const IQSampleCoeff jj1bdx_fm_384kHz_narrow = iq("jj1bdx_fm_384kHz_narrow");
+  static inline const IQSampleCoeff jj1bdx_fm_384kHz_medium = iq("jj1bdx_fm_384kHz_medium");
+  static inline const IQSampleCoeff jj1bdx_am_48khz_narrow = iq("jj1bdx_am_48khz_narrow");
+  static inline const IQSampleCoeff jj1bdx_am_48khz_medium = iq("jj1bdx_am_48khz_medium");
+  static inline const IQSampleCoeff jj1bdx_am_48khz_default = iq("jj1bdx_am_48khz_default");
+  static inline const IQSampleCoeff jj1bdx_am_48khz_wide = iq("jj1bdx_am_48khz_wide");
+  static inline const SampleCoeff jj1bdx_48khz_fmaudio = audio("jj1bdx_48khz_fmaudio");
+};
+
+// IfResampler::process(const IQSampleVector&, IQSampleVector&)  (IfResampler.h:35-38)
+class IfResampler {
+public:
+  static constexpr int max_input_length = 65536;   // IfResampler.h:31
+  IfResampler(const double input_rate, const double output_rate, int device = 0) {
+    if (output_rate != 384000.0) throw std::runtime_error("IfResampler facade: the FM IF rate is 384 kHz; AM chains fuse their front end (AmDecoder::attach_front_end)");
+    fmr_config cfg{};
+    cfg.device = device; cfg.n_streams = 1; cfg.mode = -1; cfg.input_rate = input_rate;
+    cfg.enable_resampler = 1; cfg.max_block_len = max_input_length; cfg.max_blocks = 1;
+    m_chain = fmr_detail::make(cfg);
+  }
+  ~IfResampler() { fmr_destroy(m_chain); }
+  IfResampler(const IfResampler &) = delete;
+  IfResampler &operator=(const IfResampler &) = delete;
+  void process(const IQSampleVector &samples_in, IQSampleVector &samples_out) {
+    samples_out.resize(samples_in.size() + 64);
+    size_t n = 0;
+    fmr_detail::check(fmr_resample(m_chain, reinterpret_cast<const float *>(samples_in.data()), samples_in.size(),
+                                   reinterpret_cast<float *>(samples_out.data()), samples_out.size(), &n),
+                      "fmr_resample");
+    samples_out.resize(n);
+  }
+
+private:
+  fmr_chain *m_chain = nullptr;
+};
+
+// PilotPhaseLock::PpsEvent (PilotPhaseLock.h:40-44)
+struct PilotPhaseLock {
+  struct PpsEvent {
+    std::uint64_t pps_index;
+    std::uint64_t sample_index;
+    double block_position;
+  };
+};
+
+// FmDecoder (FmDecode.h:63-105)
+class FmDecoder {
+public:
+  static constexpr double sample_rate_if = 384000;
+  static constexpr double sample_rate_pcm = 48000;
+  static constexpr double freq_dev = 75000;
+  static constexpr double deemphasis_time_eu = 50;
+  static constexpr double deemphasis_time_na = 75;
+
+  FmDecoder(bool fmfilter_enable, IQSampleCoeff &fmfilter_coeff, bool stereo, double deemphasis, bool pilot_shift,
+            unsigned int multipath_stages, int device = 0)
+      : m_stereo(stereo) {
+    m_cfg = fmr_config{};
+    m_cfg.device = device; m_cfg.n_streams = 1; m_cfg.mode = FMR_MODE_FM; m_cfg.input_rate = sample_rate_if;
+    m_cfg.fmfilter_enable = fmfilter_enable; m_cfg.filter_coeff = fmfilter_coeff.data();
+    m_cfg.n_filter_coeff = (int)fmfilter_coeff.size(); m_cfg.stereo = stereo; m_cfg.deemphasis_us = deemphasis;
+    m_cfg.pilot_shift = pilot_shift; m_cfg.multipath_stages = multipath_stages;
+    m_cfg.max_block_len = 65536; m_cfg.max_blocks = 1;
+    m_chain = fmr_detail::make(m_cfg);
+  }
+  ~FmDecoder() { fmr_destroy(m_chain); }
+  FmDecoder(const FmDecoder &) = delete;
+  FmDecoder &operator=(const FmDecoder &) = delete;
+
+  // Fuse FourthConverterIQ + IfResampler into this decoder's chain: process() then takes
+  // the source-rate IQ block (what main.cpp:889 pulls) and the IF never leaves the GPU.
+  void attach_front_end(double input_rate, bool fourth_down) {
+    fmr_destroy(m_chain);
+    m_cfg.input_rate = input_rate; m_cfg.enable_resampler = 1; m_cfg.enable_fourth_down = fourth_down;
+    m_chain = fmr_detail::make(m_cfg);
+  }
+
+  // samples_in by value, audio resized by the callee, empty = "nothing yet" (FmDecode.cpp:85-92)
+  void process(IQSampleVector samples_in, SampleVector &audio) {
+    audio.resize(2 * (samples_in.size() + 64));
+    size_t n = 0;
+    fmr_detail::check(fmr_process(m_chain, reinterpret_cast<const float *>(samples_in.data()), samples_in.size(),
+                                  audio.data(), audio.size(), &n),
+                      "fmr_process");
+    audio.resize(n);
+  }
+  bool stereo_detected() { return status().stereo_detected != 0; }
+  float get_tuning_offset() { return status().baseband_mean * freq_dev; }
+  float get_baseband_level() { return status().baseband_level; }
+  double get_pilot_level() { return status().pilot_level; }
+  float get_if_rms() { return status().if_rms; }
+  double get_multipath_error() { return status().multipath_error; }
+  std::vector<PilotPhaseLock::PpsEvent> get_pps_events() {
+    fmr_pps_event ev[64];
+    const int n = fmr_get_pps_events(m_chain, 0, ev, 64);
+    std::vector<PilotPhaseLock::PpsEvent> out;
+    for (int i = (int)m_pps_erased; i < n && i < 64; i++)
+      out.push_back({ev[i].pps_index, ev[i].sample_index, ev[i].block_position});
+    return out;
+  }
+  void erase_first_pps_event() { m_pps_erased++; }
+  const std::vector<std::complex<float>> &get_multipath_coefficients() {
+    m_coeff.resize(1300);
+    const int n = fmr_get_multipath_coefficients(m_chain, 0, reinterpret_cast<float *>(m_coeff.data()), 2600);
+    m_coeff.resize(n > 0 ? n : 0);
+    return m_coeff;
+  }
+
+private:
+  fmr_status status() {
+    fmr_status st{};
+    fmr_detail::check(fmr_get_status(m_chain, 0, &st), "fmr_get_status");
+    return st;
+  }
+  fmr_config m_cfg{};
+  fmr_chain *m_chain = nullptr;
+  bool m_stereo;
+  unsigned m_pps_erased = 0;
+  std::vector<std::complex<float>> m_coeff;
+};
+
+// AmDecoder (AmDecode.h:48-65), modes AM and DSB
+class AmDecoder {
+public:
+  static constexpr double sample_rate_pcm = 48000;
+  static constexpr double internal_rate_pcm = 48000;
+  AmDecoder(IQSampleCoeff &amfilter_coeff, const ModType mode, int device = 0) {
+    if (mode != ModType::AM && mode != ModType::DSB) throw std::runtime_error("AmDecoder facade: AM and DSB only");
+    m_cfg = fmr_config{};
+    m_cfg.device = device; m_cfg.n_streams = 1; m_cfg.mode = (mode == ModType::AM) ? FMR_MODE_AM : FMR_MODE_DSB;
+    m_cfg.input_rate = internal_rate_pcm; m_cfg.filter_coeff = amfilter_coeff.data();
+    m_cfg.n_filter_coeff = (int)amfilter_coeff.size(); m_cfg.max_block_len = 65536; m_cfg.max_blocks = 1;
+    m_chain = fmr_detail::make(m_cfg);
+  }
+  ~AmDecoder() { fmr_destroy(m_chain); }
+  AmDecoder(const AmDecoder &) = delete;
+  AmDecoder &operator=(const AmDecoder &) = delete;
+  void attach_front_end(double input_rate, bool fourth_down) {
+    fmr_destroy(m_chain);
+    m_cfg.input_rate = input_rate; m_cfg.enable_resampler = 1; m_cfg.enable_fourth_down = fourth_down;
+    m_chain = fmr_detail::make(m_cfg);
+  }
+  void process(IQSampleVector samples_in, SampleVector &audio) {
+    audio.resize(samples_in.size() + 64);
+    size_t n = 0;
+    fmr_detail::check(fmr_process(m_chain, reinterpret_cast<const float *>(samples_in.data()), samples_in.size(),
+                                  audio.data(), audio.size(), &n),
+                      "fmr_process");
+    audio.resize(n);
+  }
+  double get_baseband_level() { return status().baseband_level; }
+  float get_af_agc_current_gain() { return (float)status().af_agc_gain; }
+  float get_if_agc_current_gain() { return status().if_agc_gain; }
+  float get_if_rms() { return status().if_rms; }
+
+private:
+  fmr_status status() {
+    fmr_status st{};
+    fmr_detail::check(fmr_get_status(m_chain, 0, &st), "fmr_get_status");
+    return st;
+  }
+  fmr_config m_cfg{};
+  fmr_chain *m_chain = nullptr;
+};
