@@ -95,6 +95,8 @@ struct fmr_chain {
   int ntaps = 0, n_pilotcut = 0, mpf_N = 0, mpf_ref = 0;
   // device buffers
   DevBuf<float2> d_in, d_in_halo, d_mid, d_if, d_fir, d_mpf, d_mpf_coeff, d_mpf_state;
+  DevBuf<float> d_hpA;                 // stage-A taps in polyphase order [D][Q] (k_ifr_decim2)
+  int qa = 0;                          // taps per phase (even), 0 = v2 kernel not applicable
   DevBuf<float> d_gain, d_dec, d_hA, d_hB, d_coeff, d_atan, d_if_rms_blk, d_bb_mean_blk, d_bb_rms_blk;
   DevBuf<double> d_base, d_raw, d_am0, d_am1, d_a10, d_a11, d_pc0, d_pc1, d_audio, d_ahA, d_ahB, d_pilotcut;
   DevBuf<int> d_tab, d_mpf_ok, d_stereo_blk;
@@ -142,7 +144,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_hpA.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_ck_mask.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -216,6 +218,20 @@ int fmr_chain::init(const fmr_config *c) {
     int rc;
     if ((rc = upload(d_hA, fa.data(), fa.size()))) return rc;
     if ((rc = upload(d_hB, fb.data(), fb.size()))) return rc;
+    if (rs.D >= 2) {
+      int q = (rs.NA + rs.D - 1) / rs.D;
+      if (q & 1) q++;
+      if (q <= 16) {
+        qa = 16;
+        std::vector<float> hp((size_t)rs.D * qa, 0.f);
+        for (int k = 0; k < rs.NA; k++) hp[(size_t)(k % rs.D) * qa + k / rs.D] = fa[k];
+        if ((rc = upload(d_hpA, hp.data(), hp.size()))) return rc;
+      }
+    }
+    {
+      const char *e = getenv("FMR_DECIM_V1");
+      if (e && e[0] == '1') qa = 0;
+    }
     if ((rc = d_in_halo.alloc((size_t)S * H_in))) return rc;
     if ((rc = d_mid.alloc((size_t)S * (H_mid + max_mid)))) return rc;
   } else {
@@ -400,11 +416,30 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                            (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), cfg.enable_fourth_down);
       };
       const size_t per_out = sizeof(float2) * (size_t)rs.D, tail = sizeof(float2) * (size_t)(rs.NA - 1);
-      timed("ifr_decim", [&] {
-        if (256 * per_out + tail <= 60000) launch_decim(std::integral_constant<int, 256>{});
-        else if (128 * per_out + tail <= 60000) launch_decim(std::integral_constant<int, 128>{});
-        else launch_decim(std::integral_constant<int, 64>{});
-      });
+      constexpr int BL2 = 128, T2 = 2 * BL2;
+      int s_pad = T2 + 16;
+      while ((s_pad & 15) != 2) s_pad++;
+      const size_t lds2 = sizeof(float2) * ((size_t)rs.D * s_pad + 2);   // + the spare slot
+      if (qa == 16 && lds2 <= 64000 && (size_t)rs.D * (T2 + 16) <= (size_t)2 * 16 * BL2) {
+        const unsigned magic = (unsigned)((1u << 24) / (unsigned)rs.D + 1);
+        const dim3 grid2((count_mid + T2 - 1) / T2, S);
+        timed("ifr_decim", [&] {
+          if (cfg.enable_fourth_down)
+            hipLaunchKernelGGL((k_ifr_decim2<BL2, 16, 0, true>), grid2, dim3(BL2), lds2, stream, d_iq, (long long)stride,
+                               N_in, d_in_halo.p, H_in, d_hpA.p, rs.D, rs.ca(), top0 - rs.ca(), count_mid, d_mid.p,
+                               (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), 1, s_pad, magic);
+          else
+            hipLaunchKernelGGL((k_ifr_decim2<BL2, 16, 0, false>), grid2, dim3(BL2), lds2, stream, d_iq, (long long)stride,
+                               N_in, d_in_halo.p, H_in, d_hpA.p, rs.D, rs.ca(), top0 - rs.ca(), count_mid, d_mid.p,
+                               (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), 0, s_pad, magic);
+        });
+      } else {
+        timed("ifr_decim", [&] {
+          if (256 * per_out + tail <= 60000) launch_decim(std::integral_constant<int, 256>{});
+          else if (128 * per_out + tail <= 60000) launch_decim(std::integral_constant<int, 128>{});
+          else launch_decim(std::integral_constant<int, 64>{});
+        });
+      }
     }
     if (N_if > 0) {
       constexpr int BL = 256;

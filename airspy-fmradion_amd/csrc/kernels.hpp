@@ -180,6 +180,143 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_decim(
 }
 
 // ---------------------------------------------------------------------------
+// K_A v2  ifr_decim2 : the HBM-bound front-end kernel, LDS traffic cut 4x.
+//   y[m] = sum_p sum_q hp[p][q] * X_p[m - q],   X_p[i] = x[D i + ca - p]   (polyphase form)
+// * the input tile is staged with coalesced 16-byte loads (all issued before the first
+//   LDS write) and written to LDS DE-INTERLEAVED by phase (row p holds X_p), so that
+//   lanes that own adjacent outputs read adjacent LDS words: conflict-free ds_read_b128;
+// * every lane produces TWO adjacent outputs: one 16-byte LDS read (two samples)
+//   feeds four complex MACs;
+// * taps are wave-uniform: Q per phase through the scalar cache into SGPRs.
+// Q = taps per phase (even, zero padded), hp = [D][Q] on the host side.
+// ABL: ablation switch for tools/bench_decim.hip (0 = product, 1 = no compute, 2 = no loads).
+// ---------------------------------------------------------------------------
+template <int BLOCK, int Q, int ABL = 0, bool FOURTH = false, int CV = 1>
+__global__ __launch_bounds__(BLOCK) void k_ifr_decim2(
+    const float2 *__restrict__ iq, long long iq_stride, long long n_valid,
+    const float2 *__restrict__ halo, int H, const float *__restrict__ hp, int D, int ca,
+    long long n0 /* D*mA_prev - call_start: local input index of x[D*m] for output m = 0 */,
+    int count, float2 *__restrict__ mid, long long mid_stride, int mid_off, unsigned rot_base, int fourth,
+    int S_pad, unsigned div_magic) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds_a2[];
+  constexpr int T = 2 * BLOCK;            // outputs per workgroup
+  const int s = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * T;
+  // X_p[i], i = i0 .. i0 + T + Q - 1, i0 = m0 - Q;  input index n = n0 + D*i + ca - p
+  const long long n_base = n0 + (long long)D * (m0 - Q) + ca - (D - 1);   // smallest input index of the tile
+  const int span = D * (T + Q);
+  const float2 *xs = iq + (long long)s * iq_stride;
+  const float2 *hs = halo + (long long)s * H;
+  const int par = (int)(n_base & 1);                 // make the pair address 16-byte aligned
+  const long long n_al = n_base - par;
+  const int npairs = (span + par + 1) >> 1;
+  const unsigned dummy = (unsigned)(D * S_pad);      // one spare LDS slot swallows out-of-tile elements
+  // branch-free scatter of one staged sample: element index ee -> (phase row p, column u)
+  auto put = [&](int ee, float2 v, long long n) {
+    if (FOURTH) v = fourth_rot(v, (unsigned)((long long)rot_base + n));
+    const unsigned u = (unsigned)(((unsigned long long)(unsigned)ee * div_magic) >> 24);   // ee / D
+    const unsigned p = (unsigned)(D - 1) - ((unsigned)ee - u * (unsigned)D);
+    const unsigned addr = ((unsigned)ee < (unsigned)span) ? p * (unsigned)S_pad + u : dummy;
+    lds_a2[addr] = v;
+  };
+  // ---- stage.  Interior tiles issue ALL their 16-byte loads before the first LDS write
+  // (one HBM latency per tile); edge tiles (halo / end of the input) go element-wise.
+  if (n_al >= 0 && n_al + 2 * (long long)npairs <= n_valid) {
+    const float4 *src = reinterpret_cast<const float4 *>(xs + n_al);
+    const int full = npairs / BLOCK;                 // trips in which every lane has a pair
+    constexpr int MAXP = 16;
+    float4 w[MAXP];
+#pragma unroll
+    for (int t = 0; t < MAXP; t++) {
+      const int g = tid + t * BLOCK;
+      if (ABL == 2) w[t] = make_float4(1.f, 2.f, 3.f, 4.f);
+      else if (t < full || g < npairs) w[t] = src[g];
+    }
+#pragma unroll
+    for (int t = 0; t < MAXP; t++) {
+      const int g = tid + t * BLOCK;
+      if (t < full || g < npairs) {
+        const int e0 = 2 * g - par;
+        put(e0, make_float2(w[t].x, w[t].y), n_al + 2 * (long long)g);
+        put(e0 + 1, make_float2(w[t].z, w[t].w), n_al + 2 * (long long)g + 1);
+      }
+    }
+  } else {
+    for (int g = tid; g < npairs; g += BLOCK) {
+      const long long n = n_al + 2 * (long long)g;
+      float2 v0 = make_float2(0.f, 0.f), v1 = v0;
+      if (n < 0) { if (n >= -(long long)H) v0 = hs[H + n]; } else if (n < n_valid) v0 = xs[n];
+      const long long n1 = n + 1;
+      if (n1 < 0) { if (n1 >= -(long long)H) v1 = hs[H + n1]; } else if (n1 < n_valid) v1 = xs[n1];
+      put(2 * g - par, v0, n);
+      put(2 * g - par + 1, v1, n1);
+    }
+  }
+  __syncthreads();
+  // ---- compute: outputs m0 + 2*tid, m0 + 2*tid + 1
+  float y0r = 0.f, y0i = 0.f, y1r = 0.f, y1i = 0.f;
+  if (ABL == 1) {
+    const float2 t0 = lds_a2[Q + 2 * tid];
+    y0r = t0.x; y0i = t0.y;
+  } else {
+    if (CV == 0) {
+    for (int p = 0; p < D; p++) {
+      const float *h = hp + p * Q;
+      const float4 *row = reinterpret_cast<const float4 *>(lds_a2 + p * S_pad + Q + 2 * tid);
+#pragma unroll
+      for (int j = 0; j <= Q / 2; j++) {
+        const float4 ab = row[-j];
+        if (j < Q / 2) {
+          const float hb = h[2 * j], ha = h[2 * j + 1];
+          y1r = fmaf(hb, ab.z, y1r); y1i = fmaf(hb, ab.w, y1i);
+          y1r = fmaf(ha, ab.x, y1r); y1i = fmaf(ha, ab.y, y1i);
+          y0r = fmaf(hb, ab.x, y0r); y0i = fmaf(hb, ab.y, y0i);
+        }
+        if (j >= 1) {
+          const float h1 = h[2 * j - 1];
+          y0r = fmaf(h1, ab.z, y0r); y0i = fmaf(h1, ab.w, y0i);
+        }
+      }
+    }
+    } else {
+    // Explicit 2-wide vectors: (re,im) x broadcast tap -> v_pk_fma_f32; four independent
+    // accumulators per lane so that the packed FMAs do not queue behind each other.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v2f a0 = {0.f, 0.f}, b0 = a0, a1 = a0, b1 = a0;
+    for (int p = 0; p < D; p++) {
+      const float *h = hp + p * Q;                    // wave-uniform: scalar loads
+      const v4f *row = reinterpret_cast<const v4f *>(
+          __builtin_assume_aligned(lds_a2 + p * S_pad + Q + 2 * tid, 16));
+      v4f ab[Q / 2 + 1];
+#pragma unroll
+      for (int j = 0; j <= Q / 2; j++) ab[j] = row[-j];   // a = X_p[2l-2j] (xy), b = X_p[2l-2j+1] (zw)
+#pragma unroll
+      for (int j = 0; j < Q / 2; j++) {
+        const v2f hb = {h[2 * j], h[2 * j]}, ha = {h[2 * j + 1], h[2 * j + 1]};
+        const v2f aj = {ab[j].x, ab[j].y}, bj = {ab[j].z, ab[j].w}, bn = {ab[j + 1].z, ab[j + 1].w};
+        b1 = __builtin_elementwise_fma(hb, bj, b1);   // output 2l+1: q=2j   -> b_j
+        a1 = __builtin_elementwise_fma(ha, aj, a1);   //               q=2j+1 -> a_j
+        a0 = __builtin_elementwise_fma(hb, aj, a0);   // output 2l:   q=2j   -> a_j
+        b0 = __builtin_elementwise_fma(ha, bn, b0);   //               q=2j+1 -> b_{j+1}
+      }
+    }
+    y0r = a0.x + b0.x; y0i = a0.y + b0.y;
+    y1r = a1.x + b1.x; y1i = a1.y + b1.y;
+    }
+  }
+  const int m = m0 + 2 * tid;
+  float2 *o = mid + (long long)s * mid_stride + mid_off + m;
+  if (m + 1 < count) {
+    o[0] = make_float2(y0r, y0i);
+    o[1] = make_float2(y1r, y1i);
+  } else if (m < count) {
+    o[0] = make_float2(y0r, y0i);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K_B  ifr_poly : front-end stage B, rational LB/MB polyphase resampler.
 //   y[k] = sum_j hB[p_k][j] * mid[n_k - W + 1 + j],  t = k*MB, n_k = t / LB, p_k = t % LB
 // ---------------------------------------------------------------------------

@@ -84,7 +84,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--blocks", type=int, default=512, help="65536-sample blocks per step")
+    ap.add_argument("--blocks", type=int, default=2048,
+                    help="65536-sample blocks per step (2048 = 2^27 samples = 1 GiB of IQ, SURVEY.md 8d)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
