@@ -95,6 +95,8 @@ struct fmr_chain {
   int ntaps = 0, n_pilotcut = 0, mpf_N = 0, mpf_ref = 0;
   // device buffers
   DevBuf<float2> d_in, d_in_halo, d_mid, d_if, d_fir, d_mpf, d_mpf_coeff, d_mpf_state;
+  DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
+  int poly2_tile = 0;                  // staged mid samples per tile, 0 = v2 kernel not applicable
   DevBuf<float> d_hpA;                 // stage-A taps in polyphase order [D][Q] (k_ifr_decim2)
   int qa = 0;                          // taps per phase (even), 0 = v2 kernel not applicable
   DevBuf<float> d_gain, d_dec, d_hA, d_hB, d_coeff, d_atan, d_if_rms_blk, d_bb_mean_blk, d_bb_rms_blk;
@@ -144,7 +146,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_hpA.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_ck_mask.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -231,6 +233,20 @@ int fmr_chain::init(const fmr_config *c) {
     {
       const char *e = getenv("FMR_DECIM_V1");
       if (e && e[0] == '1') qa = 0;
+    }
+    {
+      // stage-B v2: 64 periods per tile must fit in LDS, odd MB keeps the lane stride conflict-free
+      std::vector<int> phi((size_t)rs.LB), off((size_t)rs.LB);
+      for (long long q = 0; q < rs.LB; q++) { phi[q] = (int)((q * rs.MB) % rs.LB); off[q] = (int)((q * rs.MB) / rs.LB); }
+      const long long tl = 64 * rs.MB + off[rs.LB - 1] + rs.TB;
+      const char *e = getenv("FMR_POLY_V1");
+      if (tl * 8 <= 98304 && rs.LB <= 4096 && !(e && e[0] == '1')) {
+        poly2_tile = (int)tl;
+        if ((rc = upload(d_bphi, phi.data(), phi.size()))) return rc;
+        if ((rc = upload(d_boff, off.data(), off.size()))) return rc;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly2<512>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+      }
     }
     if ((rc = d_in_halo.alloc((size_t)S * H_in))) return rc;
     if ((rc = d_mid.alloc((size_t)S * (H_mid + max_mid)))) return rc;
@@ -441,7 +457,16 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         });
       }
     }
-    if (N_if > 0) {
+    if (N_if > 0 && poly2_tile > 0) {
+      const long long P_first = kB_prev / rs.LB, P_last = (kB_prev + N_if - 1) / rs.LB;
+      const int tiles = (int)((P_last - P_first) / 64 + 1);
+      timed("ifr_poly", [&] {
+        hipLaunchKernelGGL(k_ifr_poly2<512>, dim3(tiles, S), dim3(512), sizeof(float2) * (size_t)poly2_tile, stream,
+                           d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_hB.p, rs.TB,
+                           (int)rs.LB, (int)rs.MB, d_bphi.p, d_boff.p, kB_prev, (int)N_if, d_if.p,
+                           (long long)(H_if + max_if), H_if, poly2_tile);
+      });
+    } else if (N_if > 0) {
       constexpr int BL = 256;
       const dim3 grid((unsigned)((N_if + BL - 1) / BL), S);
       const int span = (int)(((unsigned long long)(BL - 1) * rs.MB) / rs.LB) + rs.TB + 2;

@@ -361,6 +361,82 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_poly(
 }
 
 // ---------------------------------------------------------------------------
+// K_B v2  ifr_poly2 : rational polyphase stage with WAVE-UNIFORM taps.
+// Output k = P*LB + p (P = period, p = position in the period) uses tap phase
+// phi[p] = (p*MB) % LB at mid sample P*MB + off[p], off[p] = (p*MB) / LB.  Lanes own
+// 64 consecutive PERIODS and walk the positions p together, so every lane of a wave
+// needs the same tap row: taps come through the scalar cache (SGPR operands of packed
+// FMAs), and lane l reads LDS at l*MB + off[p] + j -- stride MB samples, conflict-free
+// for odd MB.  One workgroup = 64 periods x LB outputs; its 4 waves share the positions.
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ifr_poly2(
+    const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
+    const float *__restrict__ hB, int TB, int LB, int MB, const int *__restrict__ phi, const int *__restrict__ off,
+    long long k0 /* absolute index of the first output of this call */, int count,
+    float2 *__restrict__ out, long long out_stride, int out_off, int tile_len) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds_b2[];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const int s = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: tap rows go through SGPRs
+  constexpr int NW = BLOCK / 64;
+  const int W = TB >> 1;
+  const long long P0 = k0 / LB + (long long)blockIdx.x * 64;       // first period of this tile
+  const long long a0 = P0 * MB - W + 1;                            // absolute mid index of lds[0]
+  const float2 *ms = mid + (long long)s * mid_stride;
+  // ---- stage the mid-rate tile (coalesced, 8 loads in flight per lane)
+  for (int i0 = 0; i0 < tile_len; i0 += 8 * BLOCK) {
+    float2 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int i = i0 + t * BLOCK + tid;
+      const long long idx = a0 + i - mid_abs0;
+      v[t] = (i < tile_len && idx >= 0 && idx < mid_valid) ? ms[idx] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int i = i0 + t * BLOCK + tid;
+      if (i < tile_len) lds_b2[i] = v[t];
+    }
+  }
+  __syncthreads();
+  float2 *os = out + (long long)s * out_stride + out_off;
+  const long long kbase = (P0 + lane) * LB - k0;                   // local output index of position 0 of my period
+  const float2 *xl = lds_b2 + lane * MB;
+  // two positions per trip (independent accumulators) and 16 taps per inner step keep
+  // enough loads in flight to cover the LDS / scalar-cache latency
+  for (int p = wave; p < LB; p += 2 * NW) {
+    const int p2 = (p + NW < LB) ? p + NW : p;
+    const float *h0 = hB + (size_t)phi[p] * TB, *h1 = hB + (size_t)phi[p2] * TB;   // wave-uniform tap rows
+    const float2 *x0 = xl + off[p], *x1 = xl + off[p2];
+    v2f a0 = {0.f, 0.f}, a1 = a0, c0 = a0, c1 = a0;
+    int j = 0;
+    for (; j + 16 <= TB; j += 16) {
+      float2 xa[16], xb[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) { xa[u] = x0[j + u]; xb[u] = x1[j + u]; }
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        a0 = __builtin_elementwise_fma((v2f){h0[j + u], h0[j + u]}, (v2f){xa[u].x, xa[u].y}, a0);
+        a1 = __builtin_elementwise_fma((v2f){h0[j + u + 1], h0[j + u + 1]}, (v2f){xa[u + 1].x, xa[u + 1].y}, a1);
+        c0 = __builtin_elementwise_fma((v2f){h1[j + u], h1[j + u]}, (v2f){xb[u].x, xb[u].y}, c0);
+        c1 = __builtin_elementwise_fma((v2f){h1[j + u + 1], h1[j + u + 1]}, (v2f){xb[u + 1].x, xb[u + 1].y}, c1);
+      }
+    }
+    for (; j < TB; j++) {
+      const float2 xa = x0[j], xb = x1[j];
+      a0 = __builtin_elementwise_fma((v2f){h0[j], h0[j]}, (v2f){xa.x, xa.y}, a0);
+      c0 = __builtin_elementwise_fma((v2f){h1[j], h1[j]}, (v2f){xb.x, xb.y}, c0);
+    }
+    const long long k = kbase + p;
+    if (k >= 0 && k < count) os[k] = make_float2(a0.x + a1.x, a0.y + a1.y);
+    const long long k2 = kbase + p2;
+    if (p2 != p && k2 >= 0 && k2 < count) os[k2] = make_float2(c0.x + c1.x, c0.y + c1.y);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_shift_halo : re-seat prefix halos at the end of a call.  All elements are
 // 8 bytes (float2 or double).  newhalo[i] = concat(halo,data)[i + N].
 // ---------------------------------------------------------------------------
