@@ -153,6 +153,16 @@ def main():
     if rank == 0:
         kavg = {k: v[0] / v[1] for k, v in ktot.items()}
         dec_ms = kavg.get("ifr_decim", 0.0)
+        # HBM bytes of the dominant kernel from the rocprofv3 --pmc passes of the same command
+        # (profiles/r01_pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes); PMC counters
+        # cannot be read inside this process, so the figure is only attached for the profiled batch size.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pmc.get("blocks_per_step") == B and S == 1:
+                traffic = [v["hbm_bytes"] for k, v in pmc["kernels"].items() if "k_ifr_decim" in k][0]
+        except Exception:
+            traffic = None
         bytes_per_launch = 8.0 * S * n            # algorithmic: 8 B per input IQ sample
         achieved = bytes_per_launch / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         out = {
@@ -167,7 +177,7 @@ def main():
                        "resampler": ch.resampler_info()},
             "roofline": {"bound": "hbm", "kernel": "ifr_decim (front-end stage A, reads every IQ sample)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_ms": round(dec_ms, 5), "algorithmic_bytes_per_launch": bytes_per_launch},
             "kernel_ms_per_step": {k: round(v, 5) for k, v in kavg.items()},
             "audio_check": {"stereo_locked": int(st.stereo_detected), "pilot_level": round(st.pilot_level, 6)},

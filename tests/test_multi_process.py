@@ -1,0 +1,58 @@
+"""World-size-2 check of the multi-GPU launch contract on CPU (gloo): streams shard one per
+rank with no data-path collective; the only collectives are the start/stop barrier and the
+max-over-ranks time, exactly as bench.py does on N GPUs.  The per-rank work here is the CPU
+oracle (the HIP path needs a GPU); what is tested is the sharding/aggregation logic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_py as ora
+import siggen
+from conftest import load_filter
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blk, nblk = 65536, 4
+    x = siggen.fm_stereo_iq(nblk * blk, 10e6, stream_id=rank)      # stream s -> rank s, nothing exchanged
+    ifr = ora.IfResampler(10e6, 384e3)
+    fm = ora.FmDecoder(False, np.array([0, 1, 0], dtype=np.float32), True, 50.0, False, 0,
+                       load_filter("jj1bdx_48khz_fmaudio"))
+    dist.barrier()
+    n_audio = sum(len(fm.process(ifr.process(b))) for b in siggen.blocks(x, blk))
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)     # stand-in for the per-rank wall time
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    total = torch.tensor([float(nblk * blk)], dtype=torch.float64)
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    out[rank] = (n_audio, float(t.item()), float(total.item()), float(fm.get_if_rms()))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_streams_without_exchange():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    n0, t0, tot0, rms0 = out[0]
+    n1, t1, tot1, rms1 = out[1]
+    assert n0 == n1 > 0                       # identical block lengths -> identical counts on every rank
+    assert t0 == t1 == 2.0                    # max over ranks
+    assert tot0 == tot1 == 2 * 4 * 65536      # whole-job sample count = sum over ranks (weak scaling)
+    assert rms0 == pytest.approx(rms1, rel=1e-3)
