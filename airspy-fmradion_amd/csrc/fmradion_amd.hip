@@ -54,7 +54,7 @@ constexpr double kIfAtten = 140.0;     // resampler spec, DESIGN.md
 constexpr double kAudioAtten = 180.0;
 constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
-constexpr int C_AGC = 256, C_DC = 512, C_DE = 256;
+constexpr int C_AGC = 256, C_DC = 64, C_DE = 256;
 constexpr int C_PLL_MIN = 128;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
 constexpr int K_AGC_ITERS = 8, K_PLL_ITERS = 6;
 
@@ -83,6 +83,10 @@ struct fmr_chain {
   bool has_rs = false, has_dec = true, fir_enable = false, stereo = false, pilot_shift = false;
   bool enable_mpf = false;
   hipStream_t stream = nullptr;
+  // side stream: per-block bookkeeping (statistics EMAs, PLL lock logic / PPS) runs beside the
+  // audio chain instead of in front of it
+  hipStream_t side = nullptr;
+  hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr;
   // designs + counters
   ResamplerDesign rs, ars;
   ResamplerCounter rsc, arsc;
@@ -129,6 +133,7 @@ struct fmr_chain {
   Iir1Coef deemph{}, am_deemph{};
   BiquadCoef dcblock{}, am_dcblock{};
   double dc_ac[4] = {1, 0, 0, 1};       // A^C_DC of the DC-block biquad (state transition over one chunk)
+  double dc_agp[6][4] = {};             // (A^(C_DC*K))^(2^k): lane-group transitions of the node scan
   float agc_init = 1.f, agc_max = 1e5f, agc_rate = 1e-4f;
   float disc_nf = 1.f, disc_bound = 1.f;
   // last call
@@ -152,21 +157,25 @@ struct fmr_chain {
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_disc, ev_pll, ev_stats, ev_fin}) if (e) (void)hipEventDestroy(e);
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (stream) (void)hipStreamDestroy(stream);
   }
 
   // ---- kernel launch with optional HIP-event timing on the chain's stream ----
   template <class F>
-  void timed(const char *name, F &&launch) {
+  void timed_on(hipStream_t st, const char *name, F &&launch) {
     if (!timing) { launch(); return; }
     KernelTime kt{name, nullptr, nullptr};
     (void)hipEventCreate(&kt.a);
     (void)hipEventCreate(&kt.b);
-    (void)hipEventRecord(kt.a, stream);
+    (void)hipEventRecord(kt.a, st);
     launch();
-    (void)hipEventRecord(kt.b, stream);
+    (void)hipEventRecord(kt.b, st);
     ktimes.push_back(kt);
   }
+  template <class F>
+  void timed(const char *name, F &&launch) { timed_on(stream, name, launch); }
 
   int init(const fmr_config *c);
   int run(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
@@ -196,6 +205,8 @@ int fmr_chain::init(const fmr_config *c) {
   if (c->device < 0 || c->device >= ndev) { set_err("device %d out of range (%d devices)", c->device, ndev); return FMR_ERR_BAD_ARG; }
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  for (hipEvent_t *e : {&ev_disc, &ev_pll, &ev_stats, &ev_fin}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   const double dec_rate = (mode == FMR_MODE_FM || mode == FMR_MODE_NONE) ? kFmRate : kAmRate;
   has_rs = c->enable_resampler != 0;
   max_blocks = c->max_blocks;
@@ -326,6 +337,17 @@ int fmr_chain::init(const fmr_config *c) {
         for (int j = 0; j < 4; j++) r[j] = t[j];
       }
       for (int j = 0; j < 4; j++) dc_ac[j] = r[j];
+      auto mul = [](const double *x, const double *y, double *z) {
+        const double t[4] = {x[0] * y[0] + x[1] * y[2], x[0] * y[1] + x[1] * y[3], x[2] * y[0] + x[3] * y[2],
+                             x[2] * y[1] + x[3] * y[3]};
+        for (int j = 0; j < 4; j++) z[j] = t[j];
+      };
+      double gk[4] = {1, 0, 0, 1};
+      for (int i = 0; i < FMR_DC_K; i++) mul(dc_ac, gk, gk);          // A^(C*K)
+      for (int lv = 0; lv < 6; lv++) {
+        for (int j = 0; j < 4; j++) dc_agp[lv][j] = gk[j];
+        mul(gk, gk, gk);
+      }
     }
     if (!ars.design(kFmRate, kPcmRate, kAudioAtten)) { set_err("audio resampler design failed"); return FMR_ERR_UNSUPPORTED; }
     if (ars.D == 1) { ars.NA = 1; ars.hA.assign(1, 1.0); }
@@ -597,10 +619,14 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          disc_nf, disc_bound, d_dec.p, (long long)max_if, d_base.p, base_stride, H_b,
                          d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);
     });
-    timed("stats", [&] {
-      hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+    HIPCHK(hipEventRecord(ev_disc, stream));
+    HIPCHK(hipStreamWaitEvent(side, ev_disc, 0));
+    timed_on(side, "stats", [&] {
+      hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
                          d_bb_rms_blk.p, d_state.p, S, 1);
     });
+    HIPCHK(hipEventRecord(ev_stats, side));
+    bool fin_on_side = false;
     if (stereo) {
       if (serial_mode) {
         timed("pll", [&] {
@@ -634,12 +660,19 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
           hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
                              d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
                              S, d_flags.p);
-          hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, stream, bt, ct, d_pll_G.p,
+        });
+        // lock logic / PPS / state commit beside the audio chain (needed again only by fm_out)
+        HIPCHK(hipEventRecord(ev_pll, stream));
+        HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
+        timed_on(side, "pll_finish", [&] {
+          hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, side, bt, ct, d_pll_G.p,
                              d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
-          hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt, ct, d_atan.p,
+          hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, side, d_base.p, base_stride, H_b, bt, ct, d_atan.p,
                              pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
                              d_blk_wraps.p, d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
         });
+        HIPCHK(hipEventRecord(ev_fin, side));
+        fin_on_side = true;
       }
     }
     // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
@@ -674,6 +707,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch), dim3(128), 0, stream, d_a10.p, d_a11.p, a1_stride, H_pc,
                            bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
       });
+      if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
       if (serial_mode) {
         timed("fm_out", [&] {
           hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
@@ -683,7 +717,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       } else {
         // ---- DC block by linear multiple shooting + output mux
         const int dc_nc = (int)((N_au + C_DC - 1) / C_DC);
-        DcCoef dk{dcblock.b0, dcblock.b1, dcblock.b2, dcblock.a1, dcblock.a2, {dc_ac[0], dc_ac[1], dc_ac[2], dc_ac[3]}};
+        DcCoef dk{};
+        dk.b0 = dcblock.b0; dk.b1 = dcblock.b1; dk.b2 = dcblock.b2; dk.a1 = dcblock.a1; dk.a2 = dcblock.a2;
+        for (int j = 0; j < 4; j++) dk.ac[j] = dc_ac[j];
+        for (int lv = 0; lv < 6; lv++) for (int j = 0; j < 4; j++) dk.agp[lv][j] = dc_agp[lv][j];
         timed("fm_out", [&] {
           hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
                              (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc);
@@ -704,6 +741,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if (stereo) add_halo(d_am1.p, am_stride, H_am, count_am);
     add_halo(d_a10.p, a1_stride, H_pc, N_au);
     if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
+    HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
+    if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
   } else {
     timed("am_demod", [&] {

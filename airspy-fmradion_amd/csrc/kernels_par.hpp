@@ -76,7 +76,12 @@ __global__ void k_deemph_par(const double *__restrict__ in0, const double *__res
 // DC block (HighPassFilterIir) by linear multiple shooting + output mux
 // (FmDecode.cpp:194-220,242-283).
 // ---------------------------------------------------------------------------
-struct DcCoef { double b0, b1, b2, a1, a2; double ac[4]; /* A^C row-major */ };
+#define FMR_DC_K 32   // chunks per lane in the node pass
+struct DcCoef {
+  double b0, b1, b2, a1, a2;
+  double ac[4];        // A^C row-major: state transition over one chunk
+  double agp[6][4];    // (A^(C*K))^(2^k), k = 0..5: transitions over 1,2,4,..,32 lane groups
+};
 
 template <int C>
 __global__ void k_dc_pass1(const double *__restrict__ p0, const double *__restrict__ p1, long long p_stride, int n,
@@ -95,8 +100,15 @@ __global__ void k_dc_pass1(const double *__restrict__ p0, const double *__restri
   g[0] = x1; g[1] = x2;
 }
 
-// node pass: start[c+1] = G[c] + A^C start[c]; one wave per (stream, channel): the
-// lanes fetch 64 chunk results at once, the short recurrence runs on broadcast values.
+// node pass: start[c+1] = G[c] + A^C start[c].  One wave per (stream, channel); every lane
+// owns K consecutive chunks: it folds them into one vector q (K short steps), a log-step
+// wave scan with the precomputed powers of A^(C K) turns the q's into the lane start
+// states, and every lane replays its K chunks writing the chunk starts.  2048 chunks per
+// pass, the pass end state carries into the next pass.
+__device__ __forceinline__ void mv2(const double *m, double x1, double x2, double &y1, double &y2) {
+  y1 = m[0] * x1 + m[1] * x2;
+  y2 = m[2] * x1 + m[3] * x2;
+}
 __global__ __launch_bounds__(64) void k_dc_nodes(const double *__restrict__ G, double *__restrict__ start, int nc,
                                                   DcCoef k, StreamState *st, int n_streams, int nch) {
   const int t = blockIdx.x;
@@ -105,21 +117,53 @@ __global__ __launch_bounds__(64) void k_dc_nodes(const double *__restrict__ G, d
   if (s >= n_streams) return;
   const double *g = G + (((long long)s * 2 + ch) * nc) * 2;
   double *o = start + (((long long)s * 2 + ch) * nc) * 2;
-  double x1 = ch ? st[s].dc_st_x1 : st[s].dc_mono_x1;
-  double x2 = ch ? st[s].dc_st_x2 : st[s].dc_mono_x2;
-  for (int c0 = 0; c0 < nc; c0 += 64) {
-    const int c = min(c0 + lane, nc - 1);
-    const double g1 = g[2 * c], g2 = g[2 * c + 1];
-    double o1 = 0.0, o2 = 0.0;
-    const int cnt = min(64, nc - c0);
-    for (int j = 0; j < cnt; j++) {
-      if (lane == j) { o1 = x1; o2 = x2; }
-      const double gj1 = readlane_d(g1, j), gj2 = readlane_d(g2, j);
-      const double n1 = gj1 + (k.ac[0] * x1 + k.ac[1] * x2);
-      const double n2 = gj2 + (k.ac[2] * x1 + k.ac[3] * x2);
-      x1 = n1; x2 = n2;
+  double c1 = ch ? st[s].dc_st_x1 : st[s].dc_mono_x1;     // carry: state at the start of the pass
+  double c2 = ch ? st[s].dc_st_x2 : st[s].dc_mono_x2;
+  constexpr int K = FMR_DC_K;
+  for (int c0 = 0; c0 < nc; c0 += 64 * K) {
+    const int cb = c0 + lane * K;
+    // fold my K chunks from zero state
+    double q1 = 0.0, q2 = 0.0;
+    for (int j = 0; j < K; j++) {
+      const int c = cb + j;
+      if (c < nc) {
+        double n1, n2;
+        mv2(k.ac, q1, q2, n1, n2);
+        q1 = n1 + g[2 * c]; q2 = n2 + g[2 * c + 1];
+      }
+      // past the end: identity step would need A^-C; lanes past nc are never read back
     }
-    if (c0 + lane < nc) { o[2 * (c0 + lane)] = o1; o[2 * (c0 + lane) + 1] = o2; }
+    // inclusive scan: q_l <- sum_{i<=l} AG^(l-i) q_i
+#pragma unroll
+    for (int lv = 0; lv < 6; lv++) {
+      const int o_ = 1 << lv;
+      const double p1 = __shfl_up(q1, o_, 64), p2 = __shfl_up(q2, o_, 64);
+      if (lane >= o_) {
+        double m1, m2;
+        mv2(k.agp[lv], p1, p2, m1, m2);
+        q1 += m1; q2 += m2;
+      }
+    }
+    // my start = AG^lane * carry + (inclusive result of lane-1)
+    double e1 = __shfl_up(q1, 1, 64), e2 = __shfl_up(q2, 1, 64);
+    if (lane == 0) { e1 = 0.0; e2 = 0.0; }
+    double t1 = c1, t2 = c2;
+#pragma unroll
+    for (int lv = 0; lv < 6; lv++) {
+      if (lane & (1 << lv)) { double m1, m2; mv2(k.agp[lv], t1, t2, m1, m2); t1 = m1; t2 = m2; }
+    }
+    double x1 = t1 + e1, x2 = t2 + e2;
+    for (int j = 0; j < K; j++) {
+      const int c = cb + j;
+      if (c < nc) {
+        o[2 * c] = x1; o[2 * c + 1] = x2;
+        double n1, n2;
+        mv2(k.ac, x1, x2, n1, n2);
+        x1 = n1 + g[2 * c]; x2 = n2 + g[2 * c + 1];
+      }
+    }
+    // carry into the next pass = state after the last chunk of lane 63 (only used when the pass was full)
+    c1 = __shfl(x1, 63, 64); c2 = __shfl(x2, 63, 64);
   }
 }
 
