@@ -86,7 +86,7 @@ struct fmr_chain {
   // side stream: per-block bookkeeping (statistics EMAs, PLL lock logic / PPS) runs beside the
   // audio chain instead of in front of it
   hipStream_t side = nullptr;
-  hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr;
+  hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr;
   // designs + counters
   ResamplerDesign rs, ars;
   ResamplerCounter rsc, arsc;
@@ -157,7 +157,7 @@ struct fmr_chain {
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {ev_disc, ev_pll, ev_stats, ev_fin}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_disc, ev_pll, ev_stats, ev_fin, ev_if}) if (e) (void)hipEventDestroy(e);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -206,7 +206,7 @@ int fmr_chain::init(const fmr_config *c) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-  for (hipEvent_t *e : {&ev_disc, &ev_pll, &ev_stats, &ev_fin}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  for (hipEvent_t *e : {&ev_disc, &ev_pll, &ev_stats, &ev_fin, &ev_if}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   const double dec_rate = (mode == FMR_MODE_FM || mode == FMR_MODE_NONE) ? kFmRate : kAmRate;
   has_rs = c->enable_resampler != 0;
   max_blocks = c->max_blocks;
@@ -578,6 +578,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   const long long x_stride = fir_enable ? (long long)max_if : if_stride;
   const int x_off = fir_enable ? 0 : H_if;
   // ---- IF AGC: Newton multiple shooting over chunks of C_AGC samples (kernels_par.hpp)
+  const float *disc_gain = d_gain.p;      // gain sequence the discriminator multiplies in (nullptr = none)
   const int agc_nc = (int)((N_if + C_AGC - 1) / C_AGC);
   hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, stream, d_flags.p,
                      (serial_mode || enable_mpf) ? (float *)nullptr : d_agc_nodes.p,
@@ -590,17 +591,28 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate);
     });
   } else {
-    timed("if_agc", [&] {
+    // FM without the equaliser: the AGC output only feeds atan2, which is invariant to the
+    // (positive) gain, so the discriminator reads the un-gained samples and the gain recurrence
+    // -- still solved exactly as before, its state carries -- runs on the side stream, off the
+    // critical path (the two paths differ by 3.8e-8 RMS of float rounding).
+    const bool agc_aside = (mode == FMR_MODE_FM);
+    hipStream_t as = agc_aside ? side : stream;
+    if (agc_aside) {
+      HIPCHK(hipEventRecord(ev_if, stream));
+      HIPCHK(hipStreamWaitEvent(side, ev_if, 0));
+    }
+    timed_on(as, "if_agc", [&] {
       for (int it = 0; it < K_AGC_ITERS; it++) {
-        hipLaunchKernelGGL(k_agc_shoot<C_AGC>, dim3((agc_nc + 63) / 64, S), dim3(64), 0, stream, xin, x_stride, x_off,
+        hipLaunchKernelGGL(k_agc_shoot<C_AGC>, dim3((agc_nc + 63) / 64, S), dim3(64), 0, as, xin, x_stride, x_off,
                            (int)N_if, d_gain.p, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            agc_init, agc_max, agc_rate, d_flags.p);
-        hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64), 0, stream, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
+        hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64), 0, as, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            d_state.p, d_flags.p);
       }
-      hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, xin, x_stride, x_off, (int)N_if,
+      hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,
                          d_gain.p, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
     });
+    if (agc_aside) disc_gain = nullptr;
   }
   if (mode == FMR_MODE_FM) {
     if (any_mpf) {
@@ -614,7 +626,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
     const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
     timed("disc", [&] {
-      hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
+      hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
                          (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,
                          disc_nf, disc_bound, d_dec.p, (long long)max_if, d_base.p, base_stride, H_b,
                          d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);

@@ -721,6 +721,7 @@ __global__ __launch_bounds__(64) void k_mpf(
 __device__ __forceinline__ float2 disc_src(const float2 *xs, const float *gs, const float2 *ms, int use_mpf, int idx) {
   if (use_mpf) return ms[idx];
   const float2 v = xs[idx];
+  if (!gs) return v;               // gain applied elsewhere / not needed (atan2 is scale invariant)
   const float g = gs[idx];
   return make_float2(v.x * g, v.y * g);
 }
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(BLOCK) void k_disc(
   if (n == 0) return;
   const int off = bt.if_off[b];
   const float2 *xs = xin + (long long)s * x_stride + x_off;
-  const float *gs = gain + (long long)s * g_stride;
+  const float *gs = gain ? gain + (long long)s * g_stride : nullptr;
   const float2 *ms = mpfb ? mpfb + (long long)s * m_stride : nullptr;
   const int use_mpf = mpfb ? mpf_ok[(long long)s * bt.nb + b] : 0;
   float vsum = 0.f, vsq = 0.f;
