@@ -55,8 +55,8 @@ constexpr double kAudioAtten = 180.0;
 constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
 constexpr int C_AGC = 256, C_DC = 64, C_DE = 256;
-constexpr int C_PLL_MIN = 128;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
-constexpr int K_AGC_ITERS = 8, K_PLL_ITERS = 6;
+constexpr int C_PLL_MIN = 64;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
+constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 5;
 
 template <class T>
 struct DevBuf {
@@ -109,10 +109,11 @@ struct fmr_chain {
   DevBuf<StreamState> d_state;
   // time-parallel recurrences
   bool serial_mode = false;            // FMR_SERIAL=1: plain serial kernels (A/B, debugging)
-  int c_pll = 128;                     // PLL chunk length (env FMR_C_PLL, >= C_PLL_MIN)
+  int c_pll = 64;                      // PLL chunk length (env FMR_C_PLL, >= C_PLL_MIN)
   int H_b = 0;                         // halo of the pre-de-emphasis buffers (>= warm-up)
   size_t max_ck = 0, max_agc_nc = 0, max_dc_nc = 0;
-  DevBuf<double> d_base_de, d_raw_de, d_pll_nodes, d_pll_G, d_pll_M, d_pll_PQ, d_pll_dstart, d_blk_level, d_agc_M,
+  DevBuf<double> d_base_de, d_raw_de, d_pll_nodes, d_pll_G, d_pll_M, d_pll_PQ, d_pll_dstart, d_pll_PQ2, d_pll_dstart2,
+      d_blk_level, d_agc_M,
       d_dc_G, d_dc_start;
   DevBuf<float> d_agc_nodes, d_agc_G;
   DevBuf<int> d_ck_wraps, d_blk_wraps;
@@ -153,7 +154,7 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_ck_mask.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_ck_mask.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
@@ -376,6 +377,9 @@ int fmr_chain::init(const fmr_config *c) {
       const size_t max_grp = max_ck / FMR_NODE_GRP + 2;
       if ((rc = d_pll_PQ.alloc((size_t)S * max_grp * 56))) return rc;
       if ((rc = d_pll_dstart.alloc((size_t)S * max_grp * 7))) return rc;
+      const size_t max_grp2 = max_grp / FMR_NODE_GRP2 + 2;
+      if ((rc = d_pll_PQ2.alloc((size_t)S * max_grp2 * 56))) return rc;
+      if ((rc = d_pll_dstart2.alloc((size_t)S * max_grp2 * 7))) return rc;
     }
     c_pll = ((c_pll + 63) / 64) * 64;
     mask_words = c_pll / 64;
@@ -651,6 +655,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
           hipLaunchKernelGGL(k_pll_begin, dim3((nck + 1 + 63) / 64, S), dim3(64), 0, stream, d_pll_nodes.p, ct,
                              d_state.p, pllc);
           const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
+          const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
           for (int it = 0; it < K_PLL_ITERS; it++) {
             // rounds 0,1 integrate the sensitivities too; later rounds reuse them (chord Newton)
             if (it < 2)
@@ -663,8 +668,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                                  d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p);
             hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                                nck, d_pll_PQ.p, d_flags.p);
-            hipLaunchKernelGGL(k_pll_nodes_b, dim3(S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_dstart.p,
+            hipLaunchKernelGGL(k_pll_nodes_a2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_PQ2.p,
                                d_flags.p);
+            hipLaunchKernelGGL(k_pll_nodes_b, dim3(S), dim3(64), 0, stream, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p,
+                               d_flags.p);
+            hipLaunchKernelGGL(k_pll_nodes_c2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_dstart2.p,
+                               d_pll_dstart.p, d_flags.p);
             hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                                nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq);
             hipLaunchKernelGGL(k_pll_check, dim3((S + 63) / 64), dim3(64), 0, stream, d_flags.p, S, 1.0);
@@ -710,10 +719,23 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     }
     if (N_au > 0) {
       timed("aud_poly", [&] {
-        hipLaunchKernelGGL(k_aud_poly<128>, dim3((unsigned)((N_au + 127) / 128), S, nch), dim3(128), 0, stream,
-                           d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB, (unsigned)ars.LB,
-                           (unsigned)ars.MB, (unsigned long long)akB_prev * ars.MB, (int)N_au, d_a10.p, d_a11.p,
-                           a1_stride, H_pc);
+        if (ars.LB == 3 && ars.MB == 8) {
+          // period form: one lane per period (3 outputs), taps through the scalar cache
+          constexpr int BLP = 256;
+          const long long P_first = akB_prev / 3, P_last = (akB_prev + N_au - 1) / 3;
+          const int tiles = (int)((P_last - P_first) / BLP + 1);
+          const int lx = (BLP - 1) * (int)ars.MB + (int)((2 * ars.MB) / 3) + ars.TB;
+          int ni_pad = (lx + (int)ars.MB - 1) / (int)ars.MB + 1;
+          if ((ni_pad & 1) == 0) ni_pad++;
+          hipLaunchKernelGGL((k_aud_poly2<BLP, 3, 8>), dim3(tiles, S, nch), dim3(BLP), sizeof(double) * (size_t)ars.MB * ni_pad,
+                             stream, d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB,
+                             akB_prev, (int)N_au, d_a10.p, d_a11.p, a1_stride, H_pc, ni_pad, H_am + count_am);
+        } else {
+          hipLaunchKernelGGL(k_aud_poly<128>, dim3((unsigned)((N_au + 127) / 128), S, nch), dim3(128), 0, stream,
+                             d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB, (unsigned)ars.LB,
+                             (unsigned)ars.MB, (unsigned long long)akB_prev * ars.MB, (int)N_au, d_a10.p, d_a11.p,
+                             a1_stride, H_pc);
+        }
       });
       timed("pilotcut", [&] {
         hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch), dim3(128), 0, stream, d_a10.p, d_a11.p, a1_stride, H_pc,

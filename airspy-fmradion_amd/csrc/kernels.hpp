@@ -1047,6 +1047,79 @@ __global__ __launch_bounds__(BLOCK) void k_aud_poly(
   y[k] = acc;
 }
 
+// Audio stage B, period form (small LB): one lane per PERIOD computes its LB outputs as LB
+// interleaved accumulation chains (each still sequential in tap order -> bit-comparable with
+// the oracle), taps are wave-uniform (scalar loads), and the mid-rate tile is staged in LDS
+// de-interleaved by residue mod MB so that lanes read consecutive words (conflict-free).
+template <int BLOCK, int LBT, int MB>
+__global__ __launch_bounds__(BLOCK) void k_aud_poly2(
+    const double *__restrict__ m0, const double *__restrict__ m1, long long m_stride, long long mid_abs0,
+    const double *__restrict__ hB, int TB, long long k0, int count,
+    double *__restrict__ y0, double *__restrict__ y1, long long y_stride, int y_off, int ni_pad, int mid_valid) {
+  extern __shared__ __attribute__((aligned(16))) double lds_ap[];
+  const int s = blockIdx.y, ch = blockIdx.z;
+  const int tid = threadIdx.x;
+  const double *mid = (ch ? m1 : m0) + (long long)s * m_stride;
+  double *y = (ch ? y1 : y0) + (long long)s * y_stride + y_off;
+  const int W = TB >> 1;
+  const long long Pt = k0 / LBT + (long long)blockIdx.x * BLOCK;       // first period of the tile
+  const long long a0 = Pt * MB - W + 1;                                // absolute mid index of staged element 0
+  int off[LBT], phi[LBT];
+#pragma unroll
+  for (int p = 0; p < LBT; p++) { off[p] = (p * MB) / LBT; phi[p] = (p * MB) % LBT; }
+  const int lx = (BLOCK - 1) * MB + off[LBT - 1] + TB;                 // staged elements
+  // ---- stage (coalesced) with de-interleave: element e -> row e % MB, column e / MB
+  for (int e0 = 0; e0 < lx; e0 += 8 * BLOCK) {
+    double v[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int e = e0 + t * BLOCK + tid;
+      const long long idx = a0 + e - mid_abs0;      // tiles are period-aligned: they may stick out of the valid data
+      v[t] = (e < lx && idx >= 0 && idx < mid_valid) ? mid[idx] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int e = e0 + t * BLOCK + tid;
+      if (e < lx) lds_ap[(e % MB) * ni_pad + e / MB] = v[t];
+    }
+  }
+  __syncthreads();
+  double acc[LBT];
+#pragma unroll
+  for (int p = 0; p < LBT; p++) acc[p] = 0.0;
+  // batches of 8 taps: 8 scalar tap loads and 8 LDS reads per chain are in flight before the
+  // (ordered) multiply-adds consume them
+  int j = 0;
+  for (; j + 8 <= TB; j += 8) {
+    double hv[LBT][8], xv[LBT][8];
+#pragma unroll
+    for (int p = 0; p < LBT; p++)
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int jj = off[p] + j + u;                                  // wave-uniform
+        hv[p][u] = hB[(size_t)phi[p] * TB + j + u];
+        xv[p][u] = lds_ap[(jj % MB) * ni_pad + tid + jj / MB];
+      }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int p = 0; p < LBT; p++) acc[p] += hv[p][u] * xv[p][u];      // same order as the oracle
+  }
+  for (; j < TB; j++) {
+#pragma unroll
+    for (int p = 0; p < LBT; p++) {
+      const int jj = off[p] + j;
+      acc[p] += hB[(size_t)phi[p] * TB + j] * lds_ap[(jj % MB) * ni_pad + tid + jj / MB];
+    }
+  }
+  const long long kb = (Pt + tid) * LBT - k0;
+#pragma unroll
+  for (int p = 0; p < LBT; p++) {
+    const long long k = kb + p;
+    if (k >= 0 && k < count) y[k] = acc[p];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K_pcut : LowPassFilterFirAudio (Filter.cpp:107-163), the 19 kHz pilot-cut
 // FIR at 48 kHz, per audio block incl. the block-head path (hazard H1).

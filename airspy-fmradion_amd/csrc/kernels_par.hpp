@@ -514,7 +514,8 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
 // ~1e-9 in lock), i.e. ~7e-11 in freq per flip; scales sit above that floor:
 // phase 1e-7 rad, freq 1e-9, phase error 1e-5, biquad delays 1e-7 of the (I,Q) pair.
 // ---------------------------------------------------------------------------
-#define FMR_NODE_GRP 64
+#define FMR_NODE_GRP 32    // chunks per level-1 group
+#define FMR_NODE_GRP2 32   // level-1 groups per level-2 group
 // mismatch r[c][i] = G[c][i] - old[c+1][i]
 __device__ __forceinline__ double pll_mismatch(const double *g, const double *nd, int c, int i) {
   double v = g[(long long)c * 9 + i] - nd[(long long)(c + 1) * 7 + i];
@@ -522,7 +523,10 @@ __device__ __forceinline__ double pll_mismatch(const double *g, const double *nd
   return v;
 }
 
-// Phase A: lane (i*8 + k): k < 7 -> P[i][k], k == 7 -> q[i].  [P|q] <- [M P | M q + r]
+// Phase A: lane (i*8 + k): k < 7 -> P[i][k], k == 7 -> q[i].  [P|q] <- [M P | M q + r].
+// The rows of M and the mismatches are fetched a batch of chunks ahead of the dependent
+// LDS-transpose chain.
+struct ChunkRow { double m[7]; double r; };
 __global__ __launch_bounds__(64) void k_pll_nodes_a(const double *__restrict__ nodes, const double *__restrict__ G,
                                                     const double *__restrict__ M, int nck,
                                                     double *__restrict__ PQ, const IterFlags *__restrict__ fl) {
@@ -537,20 +541,93 @@ __global__ __launch_bounds__(64) void k_pll_nodes_a(const double *__restrict__ n
   const double *m = M + (long long)s * nck * 49;
   const int c0 = grp * FMR_NODE_GRP, c1 = min(c0 + FMR_NODE_GRP, nck);
   double val = (act && i == k) ? 1.0 : 0.0;   // P = I, q = 0
-  for (int c = c0; c < c1; c++) {
-    double mr[7];
+  constexpr int NB = 4;
+  ChunkRow A[NB], B[NB];
+  auto load = [&](int cb, ChunkRow *L) {
 #pragma unroll
-    for (int j = 0; j < 7; j++) mr[j] = m[(long long)c * 49 + ii * 7 + j];
-    const double rr = (k == 7) ? pll_mismatch(g, nd, c, ii) : 0.0;
+    for (int t = 0; t < NB; t++) {
+      const int c = min(cb + t, nck - 1);
+#pragma unroll
+      for (int j = 0; j < 7; j++) L[t].m[j] = m[(long long)c * 49 + ii * 7 + j];
+      L[t].r = (k == 7) ? pll_mismatch(g, nd, c, ii) : 0.0;
+    }
+  };
+  auto run = [&](int cb, const ChunkRow *L) {
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+      if (cb + t >= c1) break;
+      sh[lane] = val;
+      __syncthreads();                      // one wave per block: just orders the LDS write
+      double acc = L[t].r;
+#pragma unroll
+      for (int j = 0; j < 7; j++) acc = fma(L[t].m[j], sh[j * 8 + k], acc);
+      __syncthreads();
+      val = acc;
+    }
+  };
+  load(c0, A);
+  for (int cb = c0; cb < c1; cb += 2 * NB) {
+    load(cb + NB, B);
+    run(cb, A);
+    load(cb + 2 * NB, A);
+    run(cb + NB, B);
+  }
+  if (act) PQ[(((long long)s * gridDim.x + grp) * 7 + i) * 8 + k] = val;
+}
+
+// Phase A2: compose FMR_NODE_GRP2 consecutive level-1 group maps (already in [P|q] form)
+// into one level-2 map; same lane layout as phase A.
+__global__ __launch_bounds__(64) void k_pll_nodes_a2(const double *__restrict__ PQ1, int ngrp1,
+                                                     double *__restrict__ PQ2, const IterFlags *__restrict__ fl) {
+  __shared__ double sh[64];
+  const int s = blockIdx.y, grp = blockIdx.x;
+  if (fl[s].pll_converged) return;
+  const int lane = threadIdx.x, i = lane >> 3, k = lane & 7;
+  const bool act = i < 7;
+  const int ii = act ? i : 0;
+  const double *pq = PQ1 + (long long)s * ngrp1 * 56;
+  const int g0 = grp * FMR_NODE_GRP2, g1 = min(g0 + FMR_NODE_GRP2, ngrp1);
+  double val = (act && i == k) ? 1.0 : 0.0;
+  for (int gq = g0; gq < g1; gq++) {
+    double mr[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) mr[j] = pq[((long long)gq * 7 + ii) * 8 + j];
     sh[lane] = val;
-    __syncthreads();                      // one wave per block: just orders the LDS write
-    double acc = rr;
+    __syncthreads();
+    double acc = (k == 7) ? mr[7] : 0.0;
 #pragma unroll
     for (int j = 0; j < 7; j++) acc = fma(mr[j], sh[j * 8 + k], acc);
     __syncthreads();
     val = acc;
   }
-  if (act) PQ[(((long long)s * gridDim.x + grp) * 7 + i) * 8 + k] = val;
+  if (act) PQ2[(((long long)s * gridDim.x + grp) * 7 + i) * 8 + k] = val;
+}
+
+// Phase C2: from the start delta of a level-2 group, the start deltas of its level-1 groups
+__global__ __launch_bounds__(64) void k_pll_nodes_c2(const double *__restrict__ PQ1, int ngrp1,
+                                                     const double *__restrict__ dstart2, double *__restrict__ dstart1,
+                                                     const IterFlags *__restrict__ fl) {
+  const int s = blockIdx.y, grp = blockIdx.x;
+  if (fl[s].pll_converged) return;
+  const int i = threadIdx.x;
+  const bool act = i < 7;
+  const int ii = act ? i : 0;
+  const double *pq = PQ1 + (long long)s * ngrp1 * 56;
+  double *ds = dstart1 + (long long)s * ngrp1 * 7;
+  const int g0 = grp * FMR_NODE_GRP2, g1 = min(g0 + FMR_NODE_GRP2, ngrp1);
+  double d = dstart2[((long long)s * gridDim.x + grp) * 7 + ii];
+  for (int gq = g0; gq < g1; gq++) {
+    if (act) ds[(long long)gq * 7 + i] = d;
+    double row[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) row[k] = pq[((long long)gq * 7 + ii) * 8 + k];
+    const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2 = readlane_d(d, 2), d3 = readlane_d(d, 3),
+                 d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
+    const double p0 = fma(row[0], d0, fma(row[1], d1, row[7]));
+    const double p1 = fma(row[2], d2, row[3] * d3);
+    const double p2 = fma(row[4], d4, fma(row[5], d5, row[6] * d6));
+    d = p0 + (p1 + p2);
+  }
 }
 
 // Phase B: delta at the start of every group (one wave per stream, lane i = component i);
@@ -599,6 +676,7 @@ __global__ __launch_bounds__(64) void k_pll_nodes_b(const double *__restrict__ P
 }
 
 // Phase C: propagate inside every group, update the nodes, record the scaled residual
+struct ChunkRowC { double m[7]; double r, o; };
 __global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, const double *__restrict__ G,
                                                     const double *__restrict__ M, int nck,
                                                     const double *__restrict__ dstart, IterFlags *fl,
@@ -619,28 +697,49 @@ __global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, 
   double inv_scale = 1.0 / (1e-7 * (wm + 1.0));
   if (i == 0) inv_scale = 1e7; else if (i == 1) inv_scale = 1e9; else if (i == 2) inv_scale = 1e5;
   double resid = 0.0;
-  for (int c = c0; c < c1; c++) {
-    double mr[7];
+  constexpr int NB = 4;
+  ChunkRowC A[NB], B[NB];
+  // all old values of a batch are read before any node of that batch is rewritten:
+  // chunk c reads node c+1, chunk c writes node c+1 -> a batch only overlaps itself
+  auto load = [&](int cb, ChunkRowC *L) {
 #pragma unroll
-    for (int j = 0; j < 7; j++) mr[j] = m[(long long)c * 49 + ii * 7 + j];
-    const double old_next = nd[(long long)(c + 1) * 7 + ii];
-    const double rr = pll_mismatch(g, nd, c, ii);
-    const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2 = readlane_d(d, 2), d3 = readlane_d(d, 3),
-                 d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
-    const double p0 = fma(mr[0], d0, fma(mr[1], d1, rr));
-    const double p1 = fma(mr[2], d2, mr[3] * d3);
-    const double p2 = fma(mr[4], d4, fma(mr[5], d5, mr[6] * d6));
-    d = p0 + (p1 + p2);                       // delta of node c+1
-    double nv = old_next + d;
-    if (i == 0) {                             // keep the phase inside (0, 2 pi] like the reference
-      nv -= two_pi * floor(nv * inv_two_pi);
-      if (nv <= 0.0) nv += two_pi;
+    for (int t = 0; t < NB; t++) {
+      const int c = min(cb + t, nck - 1);
+#pragma unroll
+      for (int j = 0; j < 7; j++) L[t].m[j] = m[(long long)c * 49 + ii * 7 + j];
+      L[t].o = nd[(long long)(c + 1) * 7 + ii];
+      L[t].r = pll_mismatch(g, nd, c, ii);
     }
-    if (i == 1) nv = fmax(minfreq, fmin(maxfreq, nv));   // the true freq never leaves the clamp range
-    if (act) {
-      nd[(long long)(c + 1) * 7 + i] = nv;
-      resid = fmax(resid, fabs(d) * inv_scale);
+  };
+  auto run = [&](int cb, const ChunkRowC *L) {
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+      const int c = cb + t;
+      if (c >= c1) break;
+      const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2 = readlane_d(d, 2), d3 = readlane_d(d, 3),
+                   d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
+      const double p0 = fma(L[t].m[0], d0, fma(L[t].m[1], d1, L[t].r));
+      const double p1 = fma(L[t].m[2], d2, L[t].m[3] * d3);
+      const double p2 = fma(L[t].m[4], d4, fma(L[t].m[5], d5, L[t].m[6] * d6));
+      d = p0 + (p1 + p2);                       // delta of node c+1
+      double nv = L[t].o + d;
+      if (i == 0) {                             // keep the phase inside (0, 2 pi] like the reference
+        nv -= two_pi * floor(nv * inv_two_pi);
+        if (nv <= 0.0) nv += two_pi;
+      }
+      if (i == 1) nv = fmax(minfreq, fmin(maxfreq, nv));   // the true freq never leaves the clamp range
+      if (act) {
+        nd[(long long)(c + 1) * 7 + i] = nv;
+        resid = fmax(resid, fabs(d) * inv_scale);
+      }
     }
+  };
+  load(c0, A);
+  for (int cb = c0; cb < c1; cb += 2 * NB) {
+    load(cb + NB, B);
+    run(cb, A);
+    load(cb + 2 * NB, A);
+    run(cb + NB, B);
   }
   if (act) {
     // positive doubles order like their bit patterns: one atomicMax per lane
