@@ -244,11 +244,12 @@ class Chain:
         n = self._chk(lib().fmr_debug_read(self.h, stream, which, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
         return buf[:n].copy()
 
-    def enable_kernel_timing(self, on=True):
-        lib().fmr_enable_kernel_timing(self.h, int(on))
+    def enable_kernel_timing(self, mode=1):
+        """0 off, 1 every kernel of the last call, 2 the dominant kernel only (accumulated over calls)."""
+        lib().fmr_enable_kernel_timing(self.h, int(mode))
 
-    def kernel_times(self):
-        names = (C.c_char_p * 64)()
-        ms = (C.c_float * 64)()
-        n = self._chk(lib().fmr_get_kernel_times(self.h, names, ms, 64))
-        return [(names[i].decode(), ms[i]) for i in range(min(n, 64))]
+    def kernel_times(self, cap=4096):
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = self._chk(lib().fmr_get_kernel_times(self.h, names, ms, cap))
+        return [(names[i].decode(), ms[i]) for i in range(min(n, cap))]

@@ -85,8 +85,8 @@ struct fmr_chain {
   hipStream_t stream = nullptr;
   // side stream: per-block bookkeeping (statistics EMAs, PLL lock logic / PPS) runs beside the
   // audio chain instead of in front of it
-  hipStream_t side = nullptr;
-  hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr;
+  hipStream_t side = nullptr, side2 = nullptr;   // side2: the IF AGC when it is off the critical path
+  hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr;
   // designs + counters
   ResamplerDesign rs, ars;
   ResamplerCounter rsc, arsc;
@@ -112,7 +112,7 @@ struct fmr_chain {
   int c_pll = 64;                      // PLL chunk length (env FMR_C_PLL, >= C_PLL_MIN)
   int H_b = 0;                         // halo of the pre-de-emphasis buffers (>= warm-up)
   size_t max_ck = 0, max_agc_nc = 0, max_dc_nc = 0;
-  DevBuf<double> d_base_de, d_raw_de, d_pll_nodes, d_pll_G, d_pll_M, d_pll_PQ, d_pll_dstart, d_pll_PQ2, d_pll_dstart2,
+  DevBuf<double> d_base_de, d_raw_de, d_pll_nodes, d_pll_G, d_pll_M, d_pll_PQ, d_pll_dstart, d_pll_PQ2, d_pll_dstart2, d_pll_gres,
       d_blk_level, d_agc_M,
       d_dc_G, d_dc_start;
   DevBuf<float> d_agc_nodes, d_agc_G;
@@ -140,12 +140,14 @@ struct fmr_chain {
   // last call
   long long last_n_if = 0, last_n_au = 0;
   int last_nb = 0;
-  bool timing = false;
+  int timing = 0;                       // 0 off, 1 every kernel (diagnostics), 2 the dominant kernel only
+  std::vector<KernelTime> dom_times;    // mode 2: ifr_decim events accumulated over calls until queried
   std::vector<KernelTime> ktimes;
 
   ~fmr_chain() {
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
+    for (auto &k : dom_times) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     d_in.release(); d_in_halo.release(); d_mid.release(); d_if.release(); d_fir.release();
     d_mpf.release(); d_mpf_coeff.release(); d_mpf_state.release(); d_gain.release(); d_dec.release();
     d_hA.release(); d_hB.release(); d_coeff.release(); d_atan.release(); d_if_rms_blk.release();
@@ -154,19 +156,31 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_ck_mask.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {ev_disc, ev_pll, ev_stats, ev_fin, ev_if}) if (e) (void)hipEventDestroy(e);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (side2) { (void)hipStreamSynchronize(side2); (void)hipStreamDestroy(side2); }
+    if (ev_agc) (void)hipEventDestroy(ev_agc);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
   // ---- kernel launch with optional HIP-event timing on the chain's stream ----
   template <class F>
   void timed_on(hipStream_t st, const char *name, F &&launch) {
-    if (!timing) { launch(); return; }
+    if (timing == 2 && std::strcmp(name, "ifr_decim") == 0) {
+      KernelTime kt{name, nullptr, nullptr};
+      (void)hipEventCreate(&kt.a);
+      (void)hipEventCreate(&kt.b);
+      (void)hipEventRecord(kt.a, st);
+      launch();
+      (void)hipEventRecord(kt.b, st);
+      dom_times.push_back(kt);
+      return;
+    }
+    if (timing != 1) { launch(); return; }
     KernelTime kt{name, nullptr, nullptr};
     (void)hipEventCreate(&kt.a);
     (void)hipEventCreate(&kt.b);
@@ -207,6 +221,8 @@ int fmr_chain::init(const fmr_config *c) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&ev_agc, hipEventDisableTiming));
   for (hipEvent_t *e : {&ev_disc, &ev_pll, &ev_stats, &ev_fin, &ev_if}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   const double dec_rate = (mode == FMR_MODE_FM || mode == FMR_MODE_NONE) ? kFmRate : kAmRate;
   has_rs = c->enable_resampler != 0;
@@ -377,6 +393,7 @@ int fmr_chain::init(const fmr_config *c) {
       const size_t max_grp = max_ck / FMR_NODE_GRP + 2;
       if ((rc = d_pll_PQ.alloc((size_t)S * max_grp * 56))) return rc;
       if ((rc = d_pll_dstart.alloc((size_t)S * max_grp * 7))) return rc;
+      if ((rc = d_pll_gres.alloc((size_t)S * max_grp * 8))) return rc;
       const size_t max_grp2 = max_grp / FMR_NODE_GRP2 + 2;
       if ((rc = d_pll_PQ2.alloc((size_t)S * max_grp2 * 56))) return rc;
       if ((rc = d_pll_dstart2.alloc((size_t)S * max_grp2 * 7))) return rc;
@@ -583,6 +600,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   const int x_off = fir_enable ? 0 : H_if;
   // ---- IF AGC: Newton multiple shooting over chunks of C_AGC samples (kernels_par.hpp)
   const float *disc_gain = d_gain.p;      // gain sequence the discriminator multiplies in (nullptr = none)
+  bool agc_on_side = false;
   const int agc_nc = (int)((N_if + C_AGC - 1) / C_AGC);
   hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, stream, d_flags.p,
                      (serial_mode || enable_mpf) ? (float *)nullptr : d_agc_nodes.p,
@@ -600,10 +618,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     // -- still solved exactly as before, its state carries -- runs on the side stream, off the
     // critical path (the two paths differ by 3.8e-8 RMS of float rounding).
     const bool agc_aside = (mode == FMR_MODE_FM);
-    hipStream_t as = agc_aside ? side : stream;
+    hipStream_t as = agc_aside ? side2 : stream;
     if (agc_aside) {
       HIPCHK(hipEventRecord(ev_if, stream));
-      HIPCHK(hipStreamWaitEvent(side, ev_if, 0));
+      HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
     }
     timed_on(as, "if_agc", [&] {
       for (int it = 0; it < K_AGC_ITERS; it++) {
@@ -616,7 +634,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,
                          d_gain.p, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
     });
-    if (agc_aside) disc_gain = nullptr;
+    if (agc_aside) { disc_gain = nullptr; HIPCHK(hipEventRecord(ev_agc, side2)); agc_on_side = true; }
   }
   if (mode == FMR_MODE_FM) {
     if (any_mpf) {
@@ -675,8 +693,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
             hipLaunchKernelGGL(k_pll_nodes_c2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_dstart2.p,
                                d_pll_dstart.p, d_flags.p);
             hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
-                               nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq);
-            hipLaunchKernelGGL(k_pll_check, dim3((S + 63) / 64), dim3(64), 0, stream, d_flags.p, S, 1.0);
+                               nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
+            hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp);
           }
           hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
                              d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
@@ -776,6 +794,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     add_halo(d_a10.p, a1_stride, H_pc, N_au);
     if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
     HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
+    if (agc_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_agc, 0));
     if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
   } else {
@@ -987,12 +1006,23 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
   return n;
 }
 
-void fmr_enable_kernel_timing(fmr_chain *c, int enable) { if (c) c->timing = enable != 0; }
+void fmr_enable_kernel_timing(fmr_chain *c, int enable) { if (c) c->timing = enable; }
 
 int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap) {
   if (!c) return FMR_ERR_BAD_ARG;
   HIPCHK(hipStreamSynchronize(c->stream));
   int n = 0;
+  if (c->timing == 2) {   // dominant kernel only: one entry per call since the last query
+    for (auto &k : c->dom_times) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, k.a, k.b);
+      if (n < cap) { names[n] = k.name; ms[n] = t; }
+      n++;
+      (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b);
+    }
+    c->dom_times.clear();
+    return n;
+  }
   for (auto &k : c->ktimes) {
     float t = 0.f;
     (void)hipEventElapsedTime(&t, k.a, k.b);

@@ -680,7 +680,7 @@ struct ChunkRowC { double m[7]; double r, o; };
 __global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, const double *__restrict__ G,
                                                     const double *__restrict__ M, int nck,
                                                     const double *__restrict__ dstart, IterFlags *fl,
-                                                    double minfreq, double maxfreq) {
+                                                    double minfreq, double maxfreq, double *__restrict__ grp_resid) {
   const int s = blockIdx.y, grp = blockIdx.x;
   if (fl[s].pll_converged) return;
   const int i = threadIdx.x;
@@ -741,24 +741,43 @@ __global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, 
     load(cb + 2 * NB, A);
     run(cb + NB, B);
   }
-  if (act) {
-    // positive doubles order like their bit patterns: one atomicMax per lane
-    atomicMax((unsigned long long *)&fl[s].pll_resid_bits, (unsigned long long)__double_as_longlong(resid));
-    atomicMax((unsigned long long *)&fl[s].pll_comp_bits[i], (unsigned long long)__double_as_longlong(resid));
-  }
+  // one residual row per group (component 0..6, slot 7 = max); k_pll_check reduces them --
+  // same-address atomics from thousands of groups would serialise in L2
+  double rmax = act ? resid : 0.0;
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, 64));
+  double *gr = grp_resid + ((long long)s * gridDim.x + grp) * 8;
+  if (act) gr[i] = resid;
+  if (i == 7) gr[7] = rmax;
 }
 
-// round bookkeeping: one thread per stream
-__global__ void k_pll_check(IterFlags *fl, int n_streams, double tol) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+// round bookkeeping: one 1024-thread block per stream reduces the per-group residuals
+__global__ __launch_bounds__(1024) void k_pll_check(IterFlags *fl, int n_streams, double tol,
+                                                    const double *__restrict__ grp_resid, int ngrp) {
+  __shared__ double red[16][8];
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x;
   if (s >= n_streams || fl[s].pll_converged) return;
-  const double resid = __longlong_as_double((long long)fl[s].pll_resid_bits);
-  if (fl[s].pll_iters < 16) fl[s].pll_hist[fl[s].pll_iters] = resid;
-  fl[s].pll_iters++;
-  fl[s].pll_resid = resid;
-  for (int i = 0; i < 7; i++) { fl[s].pll_comp[i] = __longlong_as_double((long long)fl[s].pll_comp_bits[i]); fl[s].pll_comp_bits[i] = 0; }
-  fl[s].pll_resid_bits = 0;
-  if (resid <= tol) fl[s].pll_converged = 1;
+  const double *gr = grp_resid + (long long)s * ngrp * 8;
+  const int comp = tid & 7;
+  double r = 0.0;
+  for (int g = tid >> 3; g < ngrp; g += 128) r = fmax(r, gr[(long long)g * 8 + comp]);
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) r = fmax(r, __shfl_xor(r, o, 64));   // lanes with equal comp
+  if ((tid & 63) < 8) red[tid >> 6][comp] = r;
+  __syncthreads();
+  if (tid < 8) {
+    double m = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) m = fmax(m, red[w][tid]);
+    if (tid < 7) fl[s].pll_comp[tid] = m;
+    if (tid == 7) {
+      if (fl[s].pll_iters < 16) fl[s].pll_hist[fl[s].pll_iters] = m;
+      fl[s].pll_iters++;
+      fl[s].pll_resid = m;
+      if (m <= tol) fl[s].pll_converged = 1;
+    }
+  }
 }
 
 // initial node guess: nominal ramp from the carried state
@@ -814,23 +833,26 @@ __global__ __launch_bounds__(64) void k_pll_finish(
   int n_pps = 0;
   long long wr = 0, ns = 0;
   for (int b0 = 0; b0 < bt.nb; b0 += 64) {
-    const int bl = min(b0 + lane, bt.nb - 1);
-    const int my_n = bt.if_len[bl], my_w = blk_wraps[(long long)s * bt.nb + bl];
-    const double my_level = blk_level[(long long)s * bt.nb + bl];
-    int my_flag = 0;
     const int cnt = min(64, bt.nb - b0);
-    for (int j = 0; j < cnt; j++) {
+    const bool mine = lane < cnt;
+    const int bl = min(b0 + lane, bt.nb - 1);
+    const int my_n = mine ? bt.if_len[bl] : 0, my_w = mine ? blk_wraps[(long long)s * bt.nb + bl] : 0;
+    const double my_level = blk_level[(long long)s * bt.nb + bl];
+    const bool my_ok = (2 * my_level > pc.minsignal) || my_n == 0;    // block keeps the lock (or is empty)
+    int my_flag = 0;
+    // one block through the reference's per-block logic (PilotPhaseLock.cpp:133-167)
+    auto one_block = [&](int j) {
       const int b = b0 + j;
       const int n = __builtin_amdgcn_readlane(my_n, j);
       const int w = __builtin_amdgcn_readlane(my_w, j);
       const double level = readlane_d(my_level, j);
-      if (n == 0) { if (lane == j) my_flag = (lock_cnt >= pc.lock_delay); continue; }
+      if (n == 0) { if (lane == j) my_flag = (lock_cnt >= pc.lock_delay); return; }
       const bool was_locked = (lock_cnt >= pc.lock_delay);
       const int pps_blk_start = n_pps;
       if (pilot_periods + w >= pc.pilot_frequency) {
         // the 19000th period ends inside this block: find the chunk and the sample from the wrap masks
         int kth = pc.pilot_frequency - pilot_periods;      // the kth wrap of this block (1-based)
-        int after = w - kth;                                // wraps of the block after the event
+        const int after = w - kth;                          // wraps of the block after the event
         for (int c = ct.first[b]; c < ct.first[b + 1]; c++) {
           const int cw = ck_wraps[(long long)s * ct.nck + c];
           if (kth > cw) { kth -= cw; continue; }
@@ -874,6 +896,30 @@ __global__ __launch_bounds__(64) void k_pll_finish(
       }
       sample_cnt += (unsigned long long)n;
       if (lane == j) my_flag = (lock_cnt >= pc.lock_delay);
+    };
+    int pos = 0;
+    while (pos < cnt) {
+      if (lock_cnt < pc.lock_delay) { one_block(pos); pos++; continue; }   // acquiring: block by block
+      // locked: every following block that keeps the lock and does not complete the 19000th
+      // period only advances the counters -> take the whole run at once
+      const bool in_run = mine && lane >= pos;
+      int pw = in_run ? my_w : 0;                          // inclusive prefix sum of the wraps from pos
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pw, o, 64); if (lane >= o) pw += t; }
+      const bool stop = in_run && (!my_ok || pilot_periods + pw >= pc.pilot_frequency);
+      const unsigned long long sm = __ballot(stop);
+      const int run_end = sm ? (__ffsll((long long)sm) - 1) : cnt;   // first block that needs the full logic
+      if (run_end > pos) {
+        const bool take = in_run && lane < run_end;
+        int sw = take ? my_w : 0;
+        long long sn = take ? my_n : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sw += __shfl_xor(sw, o, 64); sn += __shfl_xor(sn, o, 64); }
+        pilot_periods += sw; wr += sw; ns += sn; sample_cnt += (unsigned long long)sn;
+        if (take) my_flag = 1;
+      }
+      pos = run_end;
+      if (pos < cnt) { one_block(pos); pos++; }
     }
     if (b0 + lane < bt.nb) stereo_blk[(long long)s * bt.nb + b0 + lane] = my_flag;
   }

@@ -151,8 +151,11 @@ int fmr_get_multipath_coefficients(fmr_chain *c, int stream, float *coeff, int c
  * de-emphasis (double), 4 = AGC gain sequence (float).  Returns element count. */
 long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t cap_bytes);
 
-/* Kernel timing of the most recent call, measured with HIP events on the
- * chain's stream: fills names/ms for up to cap kernels, returns the count. */
+/* Kernel timing with HIP events on the chain's own streams.  enable = 1: every kernel of
+ * the most recent call (diagnostics; the extra events cost host time).  enable = 2: only the
+ * dominant front-end kernel ("ifr_decim"), one entry per call accumulated until queried
+ * (what bench.py uses inside its timed region).  Fills names/ms for up to cap entries,
+ * returns the count. */
 int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap);
 void fmr_enable_kernel_timing(fmr_chain *c, int enable);
 
