@@ -9,6 +9,7 @@
 // the whole call at once, the block structure travels as small offset tables
 // the host derives from the resampler's integer output-count law.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cstdarg>
 #include <cstdio>
@@ -85,6 +86,13 @@ struct fmr_chain {
   hipStream_t stream = nullptr;
   // side stream: per-block bookkeeping (statistics EMAs, PLL lock logic / PPS) runs beside the
   // audio chain instead of in front of it
+  double hp_fe = 0, hp_tab = 0, hp_dec = 0; long long hp_calls = 0; bool host_prof = false;   // FMR_HOST_PROF=1
+  hipStream_t fe = nullptr;              // front-end stream (cross-call pipelining)
+  bool pipelined = false;
+  int if_parity = 0;
+  DevBuf<float2> d_if_pp[2];
+  float2 *last_if = nullptr;
+  hipEvent_t ev_fe[2] = {}, ev_dec[2] = {};
   hipStream_t side = nullptr, side2 = nullptr;   // side2: the IF AGC when it is off the critical path
   hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr;
   // designs + counters
@@ -162,7 +170,14 @@ struct fmr_chain {
     for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {ev_disc, ev_pll, ev_stats, ev_fin, ev_if}) if (e) (void)hipEventDestroy(e);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (host_prof && hp_calls)
+      fprintf(stderr, "[fmr host prof] calls %lld  front-end %.1f us  tables %.1f us  decoder %.1f us per call\n", hp_calls,
+              hp_fe / hp_calls, hp_tab / hp_calls, hp_dec / hp_calls);
     if (side2) { (void)hipStreamSynchronize(side2); (void)hipStreamDestroy(side2); }
+    if (fe) { (void)hipStreamSynchronize(fe); (void)hipStreamDestroy(fe); }
+    for (auto &e : ev_fe) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ev_dec) if (e) (void)hipEventDestroy(e);
+    d_if_pp[0].release(); d_if_pp[1].release();
     if (ev_agc) (void)hipEventDestroy(ev_agc);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -288,6 +303,22 @@ int fmr_chain::init(const fmr_config *c) {
   if (has_dec && (ntaps < 1 || !c->filter_coeff)) { set_err("filter_coeff missing"); return FMR_ERR_BAD_ARG; }
   H_if = has_dec ? (ntaps > 1 ? ntaps - 1 : 1) : 1;
   if ((rc = d_if.alloc((size_t)S * (H_if + max_if)))) return rc;
+  last_if = d_if.p;
+  { const char *e = getenv("FMR_HOST_PROF"); host_prof = e && e[0] == '1'; }
+  {
+    // Opt-in (FMR_PIPELINE=1): +5 % whole-job rate on config 2, but the front-end kernel then shares HBM
+    // with the decoder's tail and its own launch takes 0.28 ms instead of 0.20 ms.
+    const char *e = getenv("FMR_PIPELINE");
+    pipelined = has_rs && has_dec && !fir_enable && e && e[0] == '1';
+    if (pipelined) {
+      HIPCHK(hipStreamCreateWithFlags(&fe, hipStreamNonBlocking));
+      for (int q = 0; q < 2; q++) {
+        if ((rc = d_if_pp[q].alloc((size_t)S * (H_if + max_if)))) return rc;
+        HIPCHK(hipEventCreateWithFlags(&ev_fe[q], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_dec[q], hipEventDisableTiming));
+      }
+    }
+  }
   h_state.assign(S, StreamState{});
   for (auto &st : h_state) {
     st.agc_gain = 1.0f;
@@ -442,6 +473,19 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     N_in += block_len[b];
   }
   HIPCHK(hipSetDevice(cfg.device));
+  const auto hp0 = std::chrono::steady_clock::now();
+  auto hp1 = hp0, hp2 = hp0;
+  struct HostProf {
+    fmr_chain *c; const std::chrono::steady_clock::time_point &t0, &t1, &t2;
+    ~HostProf() {
+      if (!c->host_prof) return;
+      const auto t3 = std::chrono::steady_clock::now();
+      c->hp_fe += std::chrono::duration<double, std::micro>(t1 - t0).count();
+      c->hp_tab += std::chrono::duration<double, std::micro>(t2 - t1).count();
+      c->hp_dec += std::chrono::duration<double, std::micro>(t3 - t2).count();
+      c->hp_calls++;
+    }
+  } host_prof_guard{this, hp0, hp1, hp2};
   for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
   ktimes.clear();
   const int slot = tab_slot;
@@ -453,6 +497,13 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       *t_au_len = h_tab + 3 * max_blocks, *t_mpf = h_tab + 4 * max_blocks;
   // ------------------------------------------------------------------ front end
   long long N_if = 0, count_mid_call = 0;
+  // Cross-call pipelining: the front end of call N+1 (its own stream, its own IF buffer) runs
+  // beside the decoder of call N, whose recurrence kernels leave most of the chip idle.
+  const int par = pipelined ? (if_parity ^= 1) : 0;
+  hipStream_t fes = pipelined ? fe : stream;
+  float2 *ifbuf = pipelined ? d_if_pp[par].p : d_if.p;
+  last_if = ifbuf;
+  if (pipelined) HIPCHK(hipStreamWaitEvent(fe, ev_dec[par], 0));   // decoder of call N-2 is done with this buffer
   if (has_rs) {
     const long long mA_prev = rsc.mA, kB_prev = rsc.kB, n_prev = rsc.n_in;
     for (int b = 0; b < nb; b++) {
@@ -470,7 +521,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         constexpr int BL = decltype(bl_tag)::value;
         const dim3 grid((count_mid + BL - 1) / BL, S);
         const size_t lds = sizeof(float2) * ((size_t)BL * rs.D + rs.NA - 1);
-        hipLaunchKernelGGL(k_ifr_decim<BL>, grid, dim3(BL), lds, stream, d_iq, (long long)stride, N_in,
+        hipLaunchKernelGGL(k_ifr_decim<BL>, grid, dim3(BL), lds, fes, d_iq, (long long)stride, N_in,
                            d_in_halo.p, H_in, d_hA.p, rs.NA, rs.D, top0, count_mid, d_mid.p,
                            (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), cfg.enable_fourth_down);
       };
@@ -482,18 +533,18 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       if (qa == 16 && lds2 <= 64000 && (size_t)rs.D * (T2 + 16) <= (size_t)2 * 16 * BL2) {
         const unsigned magic = (unsigned)((1u << 24) / (unsigned)rs.D + 1);
         const dim3 grid2((count_mid + T2 - 1) / T2, S);
-        timed("ifr_decim", [&] {
+        timed_on(fes, "ifr_decim", [&] {
           if (cfg.enable_fourth_down)
-            hipLaunchKernelGGL((k_ifr_decim2<BL2, 16, 0, true>), grid2, dim3(BL2), lds2, stream, d_iq, (long long)stride,
+            hipLaunchKernelGGL((k_ifr_decim2<BL2, 16, 0, true>), grid2, dim3(BL2), lds2, fes, d_iq, (long long)stride,
                                N_in, d_in_halo.p, H_in, d_hpA.p, rs.D, rs.ca(), top0 - rs.ca(), count_mid, d_mid.p,
                                (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), 1, s_pad, magic);
           else
-            hipLaunchKernelGGL((k_ifr_decim2<BL2, 16, 0, false>), grid2, dim3(BL2), lds2, stream, d_iq, (long long)stride,
+            hipLaunchKernelGGL((k_ifr_decim2<BL2, 16, 0, false>), grid2, dim3(BL2), lds2, fes, d_iq, (long long)stride,
                                N_in, d_in_halo.p, H_in, d_hpA.p, rs.D, rs.ca(), top0 - rs.ca(), count_mid, d_mid.p,
                                (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), 0, s_pad, magic);
         });
       } else {
-        timed("ifr_decim", [&] {
+        timed_on(fes, "ifr_decim", [&] {
           if (256 * per_out + tail <= 60000) launch_decim(std::integral_constant<int, 256>{});
           else if (128 * per_out + tail <= 60000) launch_decim(std::integral_constant<int, 128>{});
           else launch_decim(std::integral_constant<int, 64>{});
@@ -503,33 +554,33 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if (N_if > 0 && poly2_tile > 0) {
       const long long P_first = kB_prev / rs.LB, P_last = (kB_prev + N_if - 1) / rs.LB;
       const int tiles = (int)((P_last - P_first) / 64 + 1);
-      timed("ifr_poly", [&] {
-        hipLaunchKernelGGL(k_ifr_poly2<512>, dim3(tiles, S), dim3(512), sizeof(float2) * (size_t)poly2_tile, stream,
+      timed_on(fes, "ifr_poly", [&] {
+        hipLaunchKernelGGL(k_ifr_poly2<512>, dim3(tiles, S), dim3(512), sizeof(float2) * (size_t)poly2_tile, fes,
                            d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_hB.p, rs.TB,
-                           (int)rs.LB, (int)rs.MB, d_bphi.p, d_boff.p, kB_prev, (int)N_if, d_if.p,
+                           (int)rs.LB, (int)rs.MB, d_bphi.p, d_boff.p, kB_prev, (int)N_if, ifbuf,
                            (long long)(H_if + max_if), H_if, poly2_tile);
       });
     } else if (N_if > 0) {
       constexpr int BL = 256;
       const dim3 grid((unsigned)((N_if + BL - 1) / BL), S);
       const int span = (int)(((unsigned long long)(BL - 1) * rs.MB) / rs.LB) + rs.TB + 2;
-      timed("ifr_poly", [&] {
-        hipLaunchKernelGGL(k_ifr_poly<BL>, grid, dim3(BL), sizeof(float2) * span, stream, d_mid.p,
+      timed_on(fes, "ifr_poly", [&] {
+        hipLaunchKernelGGL(k_ifr_poly<BL>, grid, dim3(BL), sizeof(float2) * span, fes, d_mid.p,
                            (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_hB.p, rs.TB,
                            (unsigned)rs.LB, (unsigned)rs.MB, (unsigned long long)kB_prev * rs.MB, (int)N_if,
-                           d_if.p, (long long)(H_if + max_if), H_if);
+                           ifbuf, (long long)(H_if + max_if), H_if);
       });
     }
     if (N_in > 0) {
-      timed("in_halo", [&] {
-        hipLaunchKernelGGL(k_update_in_halo<256>, dim3(1, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq,
+      timed_on(fes, "in_halo", [&] {
+        hipLaunchKernelGGL(k_update_in_halo<256>, dim3(1, S), dim3(256), 0, fes, d_in_halo.p, H_in, d_iq,
                            (long long)stride, N_in);
       });
     }
   } else {
     for (int b = 0; b < nb; b++) { t_if_off[b] = (int)N_if; t_if_len[b] = (int)block_len[b]; N_if += block_len[b]; }
     if (N_if > 0)
-      HIPCHK(hipMemcpy2DAsync(d_if.p + H_if, sizeof(float2) * (H_if + max_if), d_iq, sizeof(float2) * stride,
+      HIPCHK(hipMemcpy2DAsync(ifbuf + H_if, sizeof(float2) * (H_if + max_if), d_iq, sizeof(float2) * stride,
                               sizeof(float2) * N_if, S, hipMemcpyDeviceToDevice, stream));
   }
   abs_in += (unsigned long long)N_in;
@@ -539,15 +590,28 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   auto add_halo = [&](void *buf, long long stride_e, int H, long long N) {
     if (H > 0 && N > 0) ht.d[ht.n++] = HaloDesc{(unsigned long long *)buf, stride_e, H, (int)N};
   };
-  if (has_rs) add_halo(d_mid.p, H_mid + (long long)max_mid, H_mid, count_mid_call);
+  if (has_rs && pipelined) {
+    if (count_mid_call > 0) {
+      HaloTable hm{};
+      hm.d[0] = HaloDesc{(unsigned long long *)d_mid.p, H_mid + (long long)max_mid, H_mid, (int)count_mid_call};
+      hm.n = 1;
+      hipLaunchKernelGGL(k_shift_halo<256>, dim3(1, S), dim3(256), 0, fe, hm);
+    }
+    HIPCHK(hipEventRecord(ev_fe[par], fe));
+    HIPCHK(hipStreamWaitEvent(stream, ev_fe[par], 0));
+  } else if (has_rs) {
+    add_halo(d_mid.p, H_mid + (long long)max_mid, H_mid, count_mid_call);
+  }
   if (!has_dec || N_if == 0) {
+    if (pipelined) HIPCHK(hipEventRecord(ev_dec[par], stream));
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = 0;
-    if (has_dec && fir_enable) add_halo(d_if.p, H_if + (long long)max_if, H_if, N_if);
+    if (has_dec && fir_enable) add_halo(ifbuf, H_if + (long long)max_if, H_if, N_if);
     if (ht.n) hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht);
     HIPCHK(hipGetLastError());
     return FMR_OK;
   }
   // --------------------------------------------------------------- block tables
+  hp1 = std::chrono::steady_clock::now();
   long long N_au = 0;
   bool any_mpf = false;
   const long long amA_prev = arsc.mA, akB_prev = arsc.kB, an_prev = arsc.n_in;
@@ -569,33 +633,38 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   }
   last_n_au = N_au;
   // PLL chunk table: every decoder block is cut into chunks of <= C_PLL samples
-  int *t_ck_off = h_tab + 5 * (size_t)max_blocks, *t_ck_len = t_ck_off + max_ck, *t_ck_blk = t_ck_len + max_ck,
-      *t_first = t_ck_blk + max_ck;
+  // The per-chunk arrays (off, len, blk) are filled on the device from the block table; the
+  // host only sends 6*max_blocks+1 ints per call.
+  int *t_first = h_tab + 5 * (size_t)max_blocks;
   int nck = 0;
   for (int b = 0; b < nb; b++) {
     t_first[b] = nck;
-    for (int o = 0; o < t_if_len[b]; o += c_pll) {
-      t_ck_off[nck] = t_if_off[b] + o;
-      t_ck_len[nck] = std::min(c_pll, t_if_len[b] - o);
-      t_ck_blk[nck] = b;
-      nck++;
-    }
+    nck += (t_if_len[b] + c_pll - 1) / c_pll;
   }
   t_first[nb] = nck;
-  HIPCHK(hipMemcpyAsync(d_tab_slot, h_tab, sizeof(int) * tab_ints, hipMemcpyHostToDevice, stream));
-  int *d_ck = d_tab_slot + 5 * (size_t)max_blocks;
-  ChunkTab ct{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_ck + 3 * max_ck, nck};
+  const size_t head_ints = 6 * (size_t)max_blocks + 1;
+  // a kernel pulls the table out of the pinned host slot: hipMemcpyAsync H2D made the caller wait for the
+  // stream to drain up to the copy (0.5-1 ms of host time per call), a launch does not
+  hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((head_ints + 255) / 256)), dim3(256), 0, stream,
+                     (const int *)h_tab, d_tab_slot, (int)head_ints);
+  int *d_first = d_tab_slot + 5 * (size_t)max_blocks;
+  int *d_ck = d_tab_slot + head_ints;
+  ChunkTab ct{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_first, nck};
   HIPCHK(hipEventRecord(tab_ev[slot], stream));
+  if (mode == FMR_MODE_FM && nck > 0)
+    hipLaunchKernelGGL(k_chunk_tab, dim3(nb), dim3(64), 0, stream, d_tab_slot, d_tab_slot + max_blocks, d_first, c_pll,
+                       d_ck, d_ck + max_ck, d_ck + 2 * max_ck);
   BlockTab bt{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
               d_tab_slot + 4 * max_blocks, nb};
   const long long if_stride = H_if + (long long)max_if;
+  hp2 = std::chrono::steady_clock::now();
   // ------------------------------------------------------- decoder, IF-rate part
   timed("fm_block", [&] {
-    hipLaunchKernelGGL(k_fm_block<256>, dim3(nb, S), dim3(256), 0, stream, d_if.p, if_stride, H_if, bt, d_coeff.p,
+    hipLaunchKernelGGL(k_fm_block<256>, dim3(nb, S), dim3(256), 0, stream, ifbuf, if_stride, H_if, bt, d_coeff.p,
                        ntaps, (int)fir_enable, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if,
                        d_if_rms_blk.p);
   });
-  const float2 *xin = fir_enable ? d_fir.p : d_if.p;
+  const float2 *xin = fir_enable ? d_fir.p : ifbuf;
   const long long x_stride = fir_enable ? (long long)max_if : if_stride;
   const int x_off = fir_enable ? 0 : H_if;
   // ---- IF AGC: Newton multiple shooting over chunks of C_AGC samples (kernels_par.hpp)
@@ -784,7 +853,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         });
       }
     }
-    if (fir_enable) add_halo(d_if.p, if_stride, H_if, N_if);
+    if (fir_enable) add_halo(ifbuf, if_stride, H_if, N_if);
     add_halo(d_base.p, base_stride, H_b, N_if);
     if (stereo) add_halo(d_raw.p, base_stride, H_b, N_if);
     add_halo(d_base_de.p, de_stride, H_a, N_if);
@@ -813,12 +882,13 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          0.001, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
                          d_state.p, S);   // AfSimpleAgc(1.0, 1.5, 0.6, 0.001): AmDecode.cpp:54-66
     });
-    add_halo(d_if.p, if_stride, H_if, N_if);
+    add_halo(ifbuf, if_stride, H_if, N_if);
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)t_au_len[b];
   }
   if (ht.n) {
     timed("shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht); });
   }
+  if (pipelined) HIPCHK(hipEventRecord(ev_dec[par], stream));
   HIPCHK(hipGetLastError());
   return FMR_OK;
 }
@@ -880,7 +950,7 @@ int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, cons
   HIPCHK(hipSetDevice(c->cfg.device));
   if (N_in)
     HIPCHK(hipMemcpy2DAsync(c->d_in.p, sizeof(float2) * c->max_in, iq, sizeof(float2) * stream_stride,
-                            sizeof(float2) * N_in, c->S, hipMemcpyHostToDevice, c->stream));
+                            sizeof(float2) * N_in, c->S, hipMemcpyHostToDevice, c->pipelined ? c->fe : c->stream));
   const size_t dstride = c->stereo ? 2 * c->max_au : c->max_au;
   std::vector<uint32_t> alen(n_blocks, 0);
   const int rc = c->run(c->d_in.p, c->max_in, block_len, n_blocks, c->d_audio.p, dstride, alen.data());
@@ -993,7 +1063,7 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
   const void *src = nullptr;
   size_t esz = 0;
   switch (which) {
-  case 0: src = c->d_if.p + (size_t)stream * (c->H_if + c->max_if) + c->H_if; esz = sizeof(float2); break;
+  case 0: src = c->last_if + (size_t)stream * (c->H_if + c->max_if) + c->H_if; esz = sizeof(float2); break;
   case 1: src = c->d_dec.p ? c->d_dec.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
   case 2: src = c->d_raw_de.p ? c->d_raw_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 3: src = c->d_base_de.p ? c->d_base_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;

@@ -389,6 +389,26 @@ struct ChunkTab {
   int nck;
 };
 
+// Per-call block table: pinned host slot -> device slot (the host pointer is device-visible).
+__global__ void k_copy_ints(const int *__restrict__ src, int *__restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+// Chunk table from the block table: block b owns chunks first[b] .. first[b+1]-1, each c_pll
+// IF samples (the last one shorter).  One wave per block.
+__global__ __launch_bounds__(64) void k_chunk_tab(const int *__restrict__ if_off, const int *__restrict__ if_len,
+                                                  const int *__restrict__ first, int c_pll, int *__restrict__ ck_off,
+                                                  int *__restrict__ ck_len, int *__restrict__ ck_blk) {
+  const int b = blockIdx.x;
+  const int f = first[b], n = first[b + 1] - f, off = if_off[b], len = if_len[b];
+  for (int j = threadIdx.x; j < n; j += 64) {
+    ck_off[f + j] = off + j * c_pll;
+    ck_len[f + j] = min(c_pll, len - j * c_pll);
+    ck_blk[f + j] = b;
+  }
+}
+
 __device__ __forceinline__ double wrap_pm_pi(double d) {
   const double two_pi = 2.0 * 3.14159265358979323846;
   if (d > 3.14159265358979323846) d -= two_pi;

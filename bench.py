@@ -131,6 +131,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         alen = step()
+    t_enq = time.perf_counter() - t0          # host time to enqueue all K steps (launch-bound check)
     ch.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -187,6 +188,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_ms": round(dec_ms, 5), "algorithmic_bytes_per_launch": bytes_per_launch},
             "kernel_ms_per_step": {k: round(v, 5) for k, v in kavg.items()},
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "audio_check": {"stereo_locked": int(st.stereo_detected), "pilot_level": round(st.pilot_level, 6)},
             "recurrences": {"agc_newton_rounds": st.agc_iterations, "pll_newton_rounds": st.pll_iterations,
                             "agc_serial_fallback": st.agc_fallback, "pll_serial_fallback": st.pll_fallback},

@@ -354,6 +354,26 @@ def test_multi_stream_batch(pilotcut):
     ch.close()
 
 
+def test_pipelined_front_end_equals_plain(pilotcut, monkeypatch):
+    """FMR_PIPELINE=1 (front end of call N+1 on its own stream and IF buffer, beside the decoder of call N)
+    changes scheduling only: audio is bit-identical to the plain chain over many calls."""
+    nblk, blk, batch = 24, 65536, 2
+    x = siggen.fm_stereo_iq(nblk * blk, 10e6)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FMR_PIPELINE", flag)
+        ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, max_block_len=blk,
+                       max_blocks=batch)
+        got = []
+        for i in range(0, nblk, batch):
+            a, alen = ch.process_blocks(x[None, i * blk:(i + batch) * blk], [blk] * batch)
+            got.append(a[0].copy())
+        outs.append(np.concatenate(got))
+        ch.close()
+    assert len(outs[0]) == len(outs[1]) and len(outs[0]) > 0
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_library_is_the_hip_path():
     """The product never routes through the oracle: its shared object holds gfx950 code objects."""
     data = open(fmr.LIB_PATH, "rb").read()

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun) from the repo root: collects everything profiles/ is built from.
+#   tools/collect_profiles.sh <tag>        e.g. r01
+# Outputs under gpurun_out/<tag>_*; tools/finish_profiles.sh copies the summaries into profiles/.
+set -u
+tag=${1:-r01}
+root=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+cd "$root"
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
+python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o ${tag} -- python bench.py --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_write.log 2>&1
+tail -3 gpurun_out/${tag}_pytest_gpu.log
+cat gpurun_out/${tag}_smoke.log | tail -2
+cut -c1-400 gpurun_out/${tag}_bench.json
+find gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write -name '*.csv' | head -20
