@@ -86,6 +86,7 @@ struct fmr_chain {
   hipStream_t stream = nullptr;
   // side stream: per-block bookkeeping (statistics EMAs, PLL lock logic / PPS) runs beside the
   // audio chain instead of in front of it
+  int pll_jac_rounds = 1;                // rounds that re-integrate the sensitivities (env FMR_PLL_JAC)
   double hp_fe = 0, hp_tab = 0, hp_dec = 0; long long hp_calls = 0; bool host_prof = false;   // FMR_HOST_PROF=1
   hipStream_t fe = nullptr;              // front-end stream (cross-call pipelining)
   bool pipelined = false;
@@ -94,7 +95,8 @@ struct fmr_chain {
   float2 *last_if = nullptr;
   hipEvent_t ev_fe[2] = {}, ev_dec[2] = {};
   hipStream_t side = nullptr, side2 = nullptr;   // side2: the IF AGC when it is off the critical path
-  hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr;
+  hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr,
+             ev_tab = nullptr;
   // designs + counters
   ResamplerDesign rs, ars;
   ResamplerCounter rsc, arsc;
@@ -179,6 +181,7 @@ struct fmr_chain {
     for (auto &e : ev_dec) if (e) (void)hipEventDestroy(e);
     d_if_pp[0].release(); d_if_pp[1].release();
     if (ev_agc) (void)hipEventDestroy(ev_agc);
+    if (ev_tab) (void)hipEventDestroy(ev_tab);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -238,6 +241,7 @@ int fmr_chain::init(const fmr_config *c) {
   HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&ev_agc, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ev_tab, hipEventDisableTiming));
   for (hipEvent_t *e : {&ev_disc, &ev_pll, &ev_stats, &ev_fin, &ev_if}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   const double dec_rate = (mode == FMR_MODE_FM || mode == FMR_MODE_NONE) ? kFmRate : kAmRate;
   has_rs = c->enable_resampler != 0;
@@ -305,6 +309,7 @@ int fmr_chain::init(const fmr_config *c) {
   if ((rc = d_if.alloc((size_t)S * (H_if + max_if)))) return rc;
   last_if = d_if.p;
   { const char *e = getenv("FMR_HOST_PROF"); host_prof = e && e[0] == '1'; }
+  { const char *e = getenv("FMR_PLL_JAC"); if (e && e[0] >= '1' && e[0] <= '9') pll_jac_rounds = e[0] - '0'; }
   {
     // Opt-in (FMR_PIPELINE=1): +5 % whole-job rate on config 2, but the front-end kernel then shares HBM
     // with the decoder's tail and its own launch takes 0.28 ms instead of 0.20 ms.
@@ -645,15 +650,24 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   const size_t head_ints = 6 * (size_t)max_blocks + 1;
   // a kernel pulls the table out of the pinned host slot: hipMemcpyAsync H2D made the caller wait for the
   // stream to drain up to the copy (0.5-1 ms of host time per call), a launch does not
-  hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((head_ints + 255) / 256)), dim3(256), 0, stream,
+  // Table kernels and the PLL's initial node guess run on the side stream, beside the front end.
+  hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((head_ints + 255) / 256)), dim3(256), 0, side,
                      (const int *)h_tab, d_tab_slot, (int)head_ints);
   int *d_first = d_tab_slot + 5 * (size_t)max_blocks;
   int *d_ck = d_tab_slot + head_ints;
   ChunkTab ct{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_first, nck};
-  HIPCHK(hipEventRecord(tab_ev[slot], stream));
-  if (mode == FMR_MODE_FM && nck > 0)
-    hipLaunchKernelGGL(k_chunk_tab, dim3(nb), dim3(64), 0, stream, d_tab_slot, d_tab_slot + max_blocks, d_first, c_pll,
+  HIPCHK(hipEventRecord(tab_ev[slot], side));
+  if (mode == FMR_MODE_FM && nck > 0) {
+    hipLaunchKernelGGL(k_chunk_tab, dim3(nb), dim3(64), 0, side, d_tab_slot, d_tab_slot + max_blocks, d_first, c_pll,
                        d_ck, d_ck + max_ck, d_ck + 2 * max_ck);
+    if (stereo && !serial_mode)
+      timed_on(side, "pll_begin", [&] {
+        hipLaunchKernelGGL(k_pll_begin, dim3((nck + 1 + 63) / 64, S), dim3(64), 0, side, d_pll_nodes.p, ct, d_state.p,
+                           pllc);
+      });
+  }
+  HIPCHK(hipEventRecord(ev_tab, side));
+  HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
   BlockTab bt{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
               d_tab_slot + 4 * max_blocks, nb};
   const long long if_stride = H_if + (long long)max_if;
@@ -739,13 +753,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       } else {
         // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
         timed("pll", [&] {
-          hipLaunchKernelGGL(k_pll_begin, dim3((nck + 1 + 63) / 64, S), dim3(64), 0, stream, d_pll_nodes.p, ct,
-                             d_state.p, pllc);
           const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
           const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
           for (int it = 0; it < K_PLL_ITERS; it++) {
-            // rounds 0,1 integrate the sensitivities too; later rounds reuse them (chord Newton)
-            if (it < 2)
+            // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
+            // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
+            if (it < pll_jac_rounds)
               hipLaunchKernelGGL(k_pll_shoot<true>, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p,
                                  base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
                                  d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p);
@@ -825,8 +838,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         }
       });
       timed("pilotcut", [&] {
-        hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch), dim3(128), 0, stream, d_a10.p, d_a11.p, a1_stride, H_pc,
-                           bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
+        if (n_pilotcut <= FMR_PCUT_MAXTAPS)
+          hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, nch), dim3(320), 0, stream, d_a10.p, d_a11.p,
+                             a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
+        else
+          hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch), dim3(128), 0, stream, d_a10.p, d_a11.p, a1_stride, H_pc,
+                             bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
       });
       if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
       if (serial_mode) {

@@ -1148,6 +1148,45 @@ __global__ __launch_bounds__(BLOCK) void k_pilotcut(
   }
 }
 
+// LDS-staged form of k_pilotcut: the block's samples (plus the `order` samples before it) and the taps
+// sit in LDS, adjacent lanes own adjacent outputs (conflict-free ds_read_b64).  Same summation order.
+#define FMR_PCUT_MAXTAPS 128
+template <int BLOCK, int TILE>
+__global__ __launch_bounds__(BLOCK) void k_pilotcut2(
+    const double *__restrict__ a0, const double *__restrict__ a1, long long a_stride, int a_halo,
+    BlockTab bt, const double *__restrict__ coeff, int ntaps,
+    double *__restrict__ p0, double *__restrict__ p1, long long p_stride) {
+  __shared__ double cs[FMR_PCUT_MAXTAPS];
+  __shared__ double xs[TILE + FMR_PCUT_MAXTAPS];
+  const int b = blockIdx.x, s = blockIdx.y, ch = blockIdx.z;
+  const int n = bt.au_len[b];
+  if (n == 0) return;
+  const double *x = (ch ? a1 : a0) + (long long)s * a_stride + a_halo + bt.au_off[b];
+  double *y = (ch ? p1 : p0) + (long long)s * p_stride + bt.au_off[b];
+  const int order = ntaps - 1, half_order = (order - 1) / 2;
+  for (int j = threadIdx.x; j < ntaps; j += BLOCK) cs[j] = coeff[j];
+  for (int t0 = 0; t0 < n; t0 += TILE) {
+    const int tn = min(TILE, n - t0);
+    __syncthreads();
+    for (int m = threadIdx.x; m < tn + order; m += BLOCK) xs[m] = x[t0 + m - order];
+    __syncthreads();
+    for (int r = threadIdx.x; r < tn; r += BLOCK) {
+      const int i = t0 + r;
+      const double *xc = xs + r + order;      // xc[-j] = x[i - j]
+      double acc = 0.0;
+      if (i < order) {
+        for (int j = i + 1; j <= order; j++) acc += xc[-j] * cs[j];
+        for (int j = 1; j <= i; j++) acc += xc[-j] * cs[j];
+      } else {
+#pragma unroll 8
+        for (int k = 0; k <= half_order; k++) acc += (xc[-k] + xc[-(order - k)]) * cs[k];
+        if ((order % 2) == 0) acc += xc[-(order / 2)] * cs[order / 2];
+      }
+      y[i] = acc;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K_out : DC block (HighPassFilterIir, Filter.cpp:243-250,301-311) on mono and
 // L-R -- two serial lanes per stream -- then the output mux of
