@@ -86,6 +86,9 @@ struct fmr_chain {
   hipStream_t stream = nullptr;
   // side stream: per-block bookkeeping (statistics EMAs, PLL lock logic / PPS) runs beside the
   // audio chain instead of in front of it
+  bool debug_taps = false;               // FMR_DEBUG_TAPS=1: keep the de-emphasised 384 kHz signal readable (fmr_debug_read 2,3)
+  DeScan de_scan{};
+  DevBuf<double> d_de_pow;
   int pll_jac_rounds = 1;                // rounds that re-integrate the sensitivities (env FMR_PLL_JAC)
   double hp_fe = 0, hp_tab = 0, hp_dec = 0; long long hp_calls = 0; bool host_prof = false;   // FMR_HOST_PROF=1
   hipStream_t fe = nullptr;              // front-end stream (cross-call pipelining)
@@ -111,6 +114,8 @@ struct fmr_chain {
   DevBuf<float2> d_in, d_in_halo, d_mid, d_if, d_fir, d_mpf, d_mpf_coeff, d_mpf_state;
   DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
   int poly2_tile = 0;                  // staged mid samples per tile, 0 = v2 kernel not applicable
+  bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
+  DevBuf<float> d_hBp;                 // zero-padded tap rows for v3
   DevBuf<float> d_hpA;                 // stage-A taps in polyphase order [D][Q] (k_ifr_decim2)
   int qa = 0;                          // taps per phase (even), 0 = v2 kernel not applicable
   DevBuf<float> d_gain, d_dec, d_hA, d_hB, d_coeff, d_atan, d_if_rms_blk, d_bb_mean_blk, d_bb_rms_blk;
@@ -164,7 +169,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -293,6 +298,23 @@ int fmr_chain::init(const fmr_config *c) {
         if ((rc = upload(d_boff, off.data(), off.size()))) return rc;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly2<512>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        // v3: Q = 4 consecutive positions per wave; their window shift must fit the zero padding
+        constexpr int Q3 = 4;
+        int dmax = 0;
+        for (long long g = 0; g * Q3 < rs.LB; g++)
+          dmax = std::max(dmax, off[std::min<long long>(g * Q3 + Q3 - 1, rs.LB - 1)] - off[g * Q3]);
+        const char *e3 = getenv("FMR_POLY_V2");
+        if (dmax <= FMR_POLY_PADZ - 8 && (tl + 64) * 8 <= 98304 && !(e3 && e3[0] == '1')) {
+          const int TBP = rs.TB + 2 * FMR_POLY_PADZ;
+          std::vector<float> hp((size_t)rs.LB * TBP, 0.f);
+          for (long long r = 0; r < rs.LB; r++)
+            for (int j = 0; j < rs.TB; j++) hp[(size_t)r * TBP + FMR_POLY_PADZ + j] = fb[(size_t)r * rs.TB + j];
+          if ((rc = upload(d_hBp, hp.data(), hp.size()))) return rc;
+          poly2_tile = (int)tl + 64;       // slack: the last 8-sample step may run past the union window
+          poly3 = true;
+          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly3<384, Q3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        }
       }
     }
     if ((rc = d_in_halo.alloc((size_t)S * H_in))) return rc;
@@ -309,6 +331,7 @@ int fmr_chain::init(const fmr_config *c) {
   if ((rc = d_if.alloc((size_t)S * (H_if + max_if)))) return rc;
   last_if = d_if.p;
   { const char *e = getenv("FMR_HOST_PROF"); host_prof = e && e[0] == '1'; }
+  { const char *e = getenv("FMR_DEBUG_TAPS"); debug_taps = e && e[0] == '1'; }
   { const char *e = getenv("FMR_PLL_JAC"); if (e && e[0] >= '1' && e[0] <= '9') pll_jac_rounds = e[0] - '0'; }
   {
     // Opt-in (FMR_PIPELINE=1): +5 % whole-job rate on config 2, but the front-end kernel then shares HBM
@@ -382,6 +405,17 @@ int fmr_chain::init(const fmr_config *c) {
     deemph = lowpass_rc((de == 0) ? 1.0 : (de * kFmRate * 1.0e-6));      // FmDecode.cpp:67-70
     dcblock = highpass_iir(0.0001);                                       // FmDecode.cpp:62
     {
+      double a16 = 1.0;
+      for (int i = 0; i < FMR_DE_LPL; i++) a16 *= -deemph.a1;             // A^LPL, A = -a1 = exp(-1/tau)
+      std::vector<double> apow(65);
+      apow[0] = 1.0;
+      for (int k = 1; k <= 64; k++) apow[k] = apow[k - 1] * a16;
+      double pwr = a16;
+      for (int j = 0; j < 7; j++) { de_scan.pw[j] = pwr; pwr *= pwr; }
+      if ((rc = upload(d_de_pow, apow.data(), apow.size()))) return rc;
+      de_scan.apow = d_de_pow.p;
+    }
+    {
       // A = [[-a1, -a2], [1, 0]] acts on (w[n-1], w[n-2]); A^C by repeated multiplication
       double a[4] = {-dcblock.a1, -dcblock.a2, 1.0, 0.0}, r[4] = {1, 0, 0, 1};
       for (int i = 0; i < C_DC; i++) {
@@ -416,7 +450,7 @@ int fmr_chain::init(const fmr_config *c) {
     float tab[257];
     make_fast_atan_table(tab);
     if ((rc = upload(d_atan, tab, (size_t)257))) return rc;
-    H_b = std::max(H_a, FMR_DE_WARMUP);
+    H_b = FMR_DE_WARMUP + H_a;           // warm-up of the fused de-emphasis reaches below the oldest stage-A tap
     if ((rc = d_base.alloc((size_t)S * (H_b + max_if)))) return rc;
     if ((rc = d_raw.alloc((size_t)S * (H_b + max_if)))) return rc;
     if ((rc = d_base_de.alloc((size_t)S * (H_a + max_if)))) return rc;
@@ -560,6 +594,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       const long long P_first = kB_prev / rs.LB, P_last = (kB_prev + N_if - 1) / rs.LB;
       const int tiles = (int)((P_last - P_first) / 64 + 1);
       timed_on(fes, "ifr_poly", [&] {
+        if (poly3)
+          hipLaunchKernelGGL((k_ifr_poly3<384, 4>), dim3(tiles, S), dim3(384), sizeof(float2) * (size_t)poly2_tile, fes,
+                             d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_hBp.p, rs.TB,
+                             (int)rs.LB, (int)rs.MB, d_bphi.p, d_boff.p, kB_prev, (int)N_if, ifbuf,
+                             (long long)(H_if + max_if), H_if, poly2_tile);
+        else
         hipLaunchKernelGGL(k_ifr_poly2<512>, dim3(tiles, S), dim3(512), sizeof(float2) * (size_t)poly2_tile, fes,
                            d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_hB.p, rs.TB,
                            (int)rs.LB, (int)rs.MB, d_bphi.p, d_boff.p, kB_prev, (int)N_if, ifbuf,
@@ -796,26 +836,48 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         fin_on_side = true;
       }
     }
-    // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
     const int nch = stereo ? 2 : 1;
-    timed("deemph", [&] {
-      const int nt = (int)((N_if + C_DE - 1) / C_DE);
-      hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch), dim3(64), 0, stream, d_base.p, d_raw.p,
-                         base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
-                         (int)(stereo && !pilot_shift));
-    });
     // ---------------------------------------------------- audio resampler + tail
     const int count_am = (int)(arsc.mA - amA_prev);
     const long long am_stride = H_am + (long long)max_amid;
     const long long a1_stride = H_pc + (long long)max_au;
     if ((size_t)count_am > max_amid || (size_t)N_au > max_au) { set_err("internal audio capacity exceeded"); return FMR_ERR_CAPACITY; }
-    if (count_am > 0) {
-      const long long top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
-      timed("aud_decim", [&] {
-        hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch), dim3(128), 0, stream, d_base_de.p,
-                           d_raw_de.p, de_stride, H_a, d_ahA.p, ars.NA, ars.D, top0, count_am, d_am0.p, d_am1.p,
-                           am_stride, H_am);
+    const long long a_top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
+    // fused de-emphasis + stage A: the tile (warm-up + (TOUT-1) D + NA samples) must fit BLOCK * LPL LDS slots
+    constexpr int DE_BLOCK = 256, DE_SLOTS = DE_BLOCK * FMR_DE_LPL;
+    const int de_tout = ((DE_SLOTS - FMR_DE_WARMUP - ars.NA - ars.D) / ars.D) & ~3;
+    const bool de_fused = !serial_mode && de_tout >= 64;
+    if (de_fused) {
+      if (count_am > 0) {
+        timed("deemph_decim", [&] {
+          const int tiles = (count_am + de_tout - 1) / de_tout;
+          const size_t lds = sizeof(double) * (size_t)(DE_SLOTS + DE_SLOTS / 16 + 1);
+          auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(tiles, S, nch), dim3(DE_BLOCK), lds, stream, d_base.p, d_raw.p, base_stride, H_b,
+                               (int)N_if, deemph.b0, deemph.a1, de_scan, 1, (int)(stereo && !pilot_shift), d_ahA.p,
+                               ars.NA, ars.D, a_top0, count_am, de_tout, d_am0.p, d_am1.p, am_stride, H_am,
+                               debug_taps ? d_base_de.p : (double *)nullptr,
+                               debug_taps ? d_raw_de.p : (double *)nullptr, de_stride, H_a);
+          };
+          if (ars.NA == 59 && ars.D == 3) go(k_deemph_decim<DE_BLOCK, 59, 3>);     // 384 kHz -> 48 kHz
+          else go(k_deemph_decim<DE_BLOCK, 0, 0>);
+        });
+      }
+    } else {
+      // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
+      timed("deemph", [&] {
+        const int nt = (int)((N_if + C_DE - 1) / C_DE);
+        hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch), dim3(64), 0, stream, d_base.p, d_raw.p,
+                           base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
+                           (int)(stereo && !pilot_shift));
       });
+      if (count_am > 0) {
+        timed("aud_decim", [&] {
+          hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch), dim3(128), 0, stream, d_base_de.p,
+                             d_raw_de.p, de_stride, H_a, d_ahA.p, ars.NA, ars.D, a_top0, count_am, d_am0.p, d_am1.p,
+                             am_stride, H_am);
+        });
+      }
     }
     if (N_au > 0) {
       timed("aud_poly", [&] {

@@ -437,6 +437,90 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_poly2(
 }
 
 // ---------------------------------------------------------------------------
+// K_B v3  ifr_poly3 : as v2 (lanes own periods, wave-uniform taps), but a wave takes Q CONSECUTIVE
+// positions p0..p0+Q-1 at once and walks the union of their windows (TB + off[p0+Q-1] - off[p0]
+// samples) a single time: every mid sample read from LDS feeds Q packed FMAs, one per position,
+// with tap hq[i] = h[phi[p0+q]][i - (off[p0+q] - off[p0])] taken from a ZERO-PADDED tap row (PADZ
+// zeros either side) -- so the shift costs a pointer offset, not a branch.  v2 issues one
+// ds_read_b64 per packed FMA and is LDS-bandwidth bound at a quarter of the FMA rate; v3 reads Q
+// times less.  Per-position accumulation is sequential in tap order.
+// ---------------------------------------------------------------------------
+#define FMR_POLY_PADZ 32
+template <int BLOCK, int Q>
+__global__ __launch_bounds__(BLOCK) void k_ifr_poly3(
+    const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
+    const float *__restrict__ hBp, int TB, int LB, int MB, const int *__restrict__ phi, const int *__restrict__ off,
+    long long k0, int count, float2 *__restrict__ out, long long out_stride, int out_off, int tile_len) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds_b3[];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const int s = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NW = BLOCK / 64;
+  const int W = TB >> 1;
+  const int TBP = TB + 2 * FMR_POLY_PADZ;
+  const long long P0 = k0 / LB + (long long)blockIdx.x * 64;
+  const long long a0 = P0 * MB - W + 1;
+  const float2 *ms = mid + (long long)s * mid_stride;
+  for (int i0 = 0; i0 < tile_len; i0 += 8 * BLOCK) {
+    float2 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int i = i0 + t * BLOCK + tid;
+      const long long idx = a0 + i - mid_abs0;
+      v[t] = (i < tile_len && idx >= 0 && idx < mid_valid) ? ms[idx] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int i = i0 + t * BLOCK + tid;
+      if (i < tile_len) lds_b3[i] = v[t];
+    }
+  }
+  __syncthreads();
+  float2 *os = out + (long long)s * out_stride + out_off;
+  const long long kbase = (P0 + lane) * LB - k0;
+  const float2 *xl = lds_b3 + lane * MB;
+  const int ngroups = (LB + Q - 1) / Q;
+  for (int g = wave; g < ngroups; g += NW) {
+    const int p0 = g * Q;
+    const int o0 = __builtin_amdgcn_readfirstlane(off[p0]);
+    const float *hq[Q];
+    int dmax = 0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const int pq = min(p0 + q, LB - 1);
+      const int dq = __builtin_amdgcn_readfirstlane(off[pq]) - o0;
+      const int ph = __builtin_amdgcn_readfirstlane(phi[pq]);
+      hq[q] = hBp + (size_t)ph * TBP + FMR_POLY_PADZ - dq;
+      dmax = dq;
+    }
+    const int span = TB + dmax;
+    const float2 *x0 = xl + o0;
+    v2f acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) acc[q] = (v2f){0.f, 0.f};
+    for (int i = 0; i < span; i += 8) {
+      float2 xa[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) xa[u] = x0[i + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+          const float h = hq[q][i + u];
+          acc[q] = __builtin_elementwise_fma((v2f){h, h}, (v2f){xa[u].x, xa[u].y}, acc[q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const long long k = kbase + p0 + q;
+      if (p0 + q < LB && k >= 0 && k < count) os[k] = make_float2(acc[q].x, acc[q].y);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_shift_halo : re-seat prefix halos at the end of a call.  All elements are
 // 8 bytes (float2 or double).  newhalo[i] = concat(halo,data)[i + N].
 // ---------------------------------------------------------------------------

@@ -73,6 +73,116 @@ __global__ void k_deemph_par(const double *__restrict__ in0, const double *__res
 }
 
 // ---------------------------------------------------------------------------
+// De-emphasis fused with audio stage A (integer decimation): one workgroup stages the tile's
+// discriminator-rate samples (768 warm-up + (TOUT-1)*D + NA) in LDS, de-emphasises them in place
+// and runs the stage-A FIR out of LDS -- the de-emphasised 384 kHz signal never goes to HBM.
+// In-tile recurrence w[n] = x[n] - a1 w[n-1] (Filter.cpp:214-221, b1 == 0): every lane owns
+// FMR_DE_LPL consecutive samples; (1) zero-state end value per lane, (2) workgroup scan of the
+// affine maps (A^LPL, e) -> true start state per lane, (3) the lane replays its samples with the
+// reference's arithmetic.  Only the start state goes through the re-associated scan (a few ulp,
+// decaying like A^n); the far end of the warm-up starts from 0 (A^768 = 4e-18).
+// FIR: acc += hA[k] * x[top-k], k ascending (same order as k_aud_decim / the oracle).
+// ---------------------------------------------------------------------------
+#define FMR_DE_LPL 16
+struct DeScan {
+  double pw[7];          // (A^LPL)^(2^j), j = 0..6
+  const double *apow;    // (A^LPL)^k, k = 0..64
+};
+__device__ __forceinline__ int de_idx(int j) { return j + (j >> 4); }   // one pad word per lane run: 2-way at worst
+
+// NA_T/D_T > 0: compile-time stage-A shape; every lane then owns 4 consecutive outputs and walks their
+// 4 accumulation chains over one shared run of NA + 3 D samples (17 LDS reads per output instead of NA).
+template <int BLOCK, int NA_T, int D_T>
+__global__ __launch_bounds__(BLOCK) void k_deemph_decim(
+    const double *__restrict__ in0, const double *__restrict__ in1, long long in_stride, int in_off, int n_if,
+    double b0, double a1, DeScan sc, int filt0, int filt1,
+    const double *__restrict__ hA, int NA, int D, long long top0, int count, int tout,
+    double *__restrict__ y0, double *__restrict__ y1, long long y_stride, int y_off,
+    double *__restrict__ dbg0, double *__restrict__ dbg1, long long dbg_stride, int dbg_off) {
+  extern __shared__ double de_xs[];
+  __shared__ double wave_tot[BLOCK / 64];
+  const int s = blockIdx.y, ch = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m0 = blockIdx.x * tout;
+  const int cnt = min(tout, count - m0);
+  if (cnt <= 0) return;
+  const double *x = (ch ? in1 : in0) + (long long)s * in_stride + in_off;
+  double *dbg = ch ? dbg1 : dbg0;
+  const long long lo = top0 + (long long)m0 * D - (NA - 1);
+  long long hi = top0 + (long long)(m0 + cnt - 1) * D;
+  if (dbg && blockIdx.x == gridDim.x - 1) hi = n_if - 1;    // debug tap: cover the call to its last sample
+  const long long r0 = lo - FMR_DE_WARMUP;
+  const int n_t = (int)(hi - r0 + 1);                       // <= BLOCK * FMR_DE_LPL (host-checked)
+  for (int j = tid; j < BLOCK * FMR_DE_LPL; j += BLOCK) de_xs[de_idx(j)] = (j < n_t) ? x[r0 + j] : 0.0;
+  __syncthreads();
+  if (ch ? filt1 : filt0) {
+    double *mine = de_xs + tid * (FMR_DE_LPL + 1);
+    double v[FMR_DE_LPL];
+#pragma unroll
+    for (int i = 0; i < FMR_DE_LPL; i++) v[i] = mine[i];
+    double e = 0.0;
+#pragma unroll
+    for (int i = 0; i < FMR_DE_LPL; i++) e = v[i] - a1 * e;
+    // inclusive scan of S_l = A16 S_{l-1} + e_l inside the wave
+    double S = e;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const double t = __shfl_up(S, 1 << j, 64);
+      if (lane >= (1 << j)) S = fma(sc.pw[j], t, S);
+    }
+    if (lane == 63) wave_tot[wv] = S;
+    __syncthreads();
+    double O = 0.0;                                          // state entering this wave
+    for (int u = 0; u < wv; u++) O = fma(sc.pw[6], O, wave_tot[u]);
+    double st = __shfl_up(S, 1, 64);
+    if (lane == 0) st = 0.0;
+    st = fma(sc.apow[lane], O, st);                          // true state before this lane's first sample
+    double w = st;
+#pragma unroll
+    for (int i = 0; i < FMR_DE_LPL; i++) {
+      w = v[i] - a1 * w;
+      mine[i] = b0 * w;
+    }
+  }
+  __syncthreads();
+  if (dbg) {
+    double *dp = dbg + (long long)s * dbg_stride + dbg_off;
+    for (int j = FMR_DE_WARMUP + tid; j < n_t; j += BLOCK) {
+      const long long pos = r0 + j;
+      if (pos >= 0 && pos < n_if) dp[pos] = de_xs[de_idx(j)];
+    }
+  }
+  double *y = (ch ? y1 : y0) + (long long)s * y_stride + y_off;
+  if constexpr (NA_T > 0) {
+    constexpr int R = 4, SPAN = NA_T + (R - 1) * D_T;
+    for (int q = tid; q * R < cnt; q += BLOCK) {
+      const int r0 = q * R;
+      const int jtop = FMR_DE_WARMUP + (NA_T - 1) + (r0 + R - 1) * D_T;     // newest sample of the run
+      double acc[R] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < SPAN; u++) {
+        const double xv = de_xs[de_idx(jtop - u)];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+          const int k = u - (R - 1 - i) * D_T;       // tap of output r0+i that meets this sample
+          if (k >= 0 && k < NA_T) acc[i] += hA[k] * xv;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < R; i++)
+        if (r0 + i < cnt) y[m0 + r0 + i] = acc[i];
+    }
+  } else {
+    for (int r = tid; r < cnt; r += BLOCK) {
+      const int jt = FMR_DE_WARMUP + (NA - 1) + r * D;
+      double acc = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < NA; k++) acc += hA[k] * de_xs[de_idx(jt - k)];
+      y[m0 + r] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // DC block (HighPassFilterIir) by linear multiple shooting + output mux
 // (FmDecode.cpp:194-220,242-283).
 // ---------------------------------------------------------------------------

@@ -83,9 +83,13 @@ def test_fourth_converter_front_end():
 def _fm_case(name, x, blk, batch, *, fir=None, stereo=True, deemph=50.0, pilot_shift=False, stages=0,
              tol=1e-6, pilotcut=None):
     coeff = fmr.DELAY_3TAPS if fir is None else fir
-    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=384e3, enable_resampler=False, fmfilter_enable=fir is not None,
-                   filter_coeff=coeff, stereo=stereo, deemphasis_us=deemph, pilot_shift=pilot_shift,
-                   multipath_stages=stages, max_block_len=blk, max_blocks=batch)
+    os.environ["FMR_DEBUG_TAPS"] = "1"      # keep the de-emphasised 384 kHz signal readable (debug_read 2, 3)
+    try:
+        ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=384e3, enable_resampler=False, fmfilter_enable=fir is not None,
+                       filter_coeff=coeff, stereo=stereo, deemphasis_us=deemph, pilot_shift=pilot_shift,
+                       multipath_stages=stages, max_block_len=blk, max_blocks=batch)
+    finally:
+        del os.environ["FMR_DEBUG_TAPS"]
     fm = ora.FmDecoder(fir is not None, coeff, stereo, deemph, pilot_shift, stages, pilotcut)
     nblk = len(x) // blk
     got, ref = [], []
