@@ -89,6 +89,8 @@ struct fmr_chain {
   bool debug_taps = false;               // FMR_DEBUG_TAPS=1: keep the de-emphasised 384 kHz signal readable (fmr_debug_read 2,3)
   DeScan de_scan{};
   DevBuf<double> d_de_pow;
+  double pll_rtol = 0.01;                // mismatch-based acceptance threshold (env FMR_PLL_RTOL, 0 = off)
+  DevBuf<double> d_pll_wgr;
   int pll_jac_rounds = 1;                // rounds that re-integrate the sensitivities (env FMR_PLL_JAC)
   double hp_fe = 0, hp_tab = 0, hp_dec = 0; long long hp_calls = 0; bool host_prof = false;   // FMR_HOST_PROF=1
   hipStream_t fe = nullptr;              // front-end stream (cross-call pipelining)
@@ -171,7 +173,7 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_pll_wgr.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
@@ -332,6 +334,7 @@ int fmr_chain::init(const fmr_config *c) {
   last_if = d_if.p;
   { const char *e = getenv("FMR_HOST_PROF"); host_prof = e && e[0] == '1'; }
   { const char *e = getenv("FMR_DEBUG_TAPS"); debug_taps = e && e[0] == '1'; }
+  { const char *e = getenv("FMR_PLL_RTOL"); if (e && e[0]) pll_rtol = atof(e); }
   { const char *e = getenv("FMR_PLL_JAC"); if (e && e[0] >= '1' && e[0] <= '9') pll_jac_rounds = e[0] - '0'; }
   {
     // Opt-in (FMR_PIPELINE=1): +5 % whole-job rate on config 2, but the front-end kernel then shares HBM
@@ -464,6 +467,7 @@ int fmr_chain::init(const fmr_config *c) {
       if ((rc = d_pll_PQ.alloc((size_t)S * max_grp * 56))) return rc;
       if ((rc = d_pll_dstart.alloc((size_t)S * max_grp * 7))) return rc;
       if ((rc = d_pll_gres.alloc((size_t)S * max_grp * 8))) return rc;
+      if ((rc = d_pll_wgr.alloc((size_t)S * (max_ck / 64 + 2)))) return rc;
       const size_t max_grp2 = max_grp / FMR_NODE_GRP2 + 2;
       if ((rc = d_pll_PQ2.alloc((size_t)S * max_grp2 * 56))) return rc;
       if ((rc = d_pll_dstart2.alloc((size_t)S * max_grp2 * 7))) return rc;
@@ -801,11 +805,16 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
             if (it < pll_jac_rounds)
               hipLaunchKernelGGL(k_pll_shoot<true>, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p,
                                  base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
-                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p);
+                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p,
+                                 d_pll_wgr.p);
             else
               hipLaunchKernelGGL(k_pll_shoot<false>, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p,
                                  base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
-                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p);
+                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p,
+                                 d_pll_wgr.p);
+            hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
+                               (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
+            if (it == K_PLL_ITERS - 1) break;      // nothing integrates the nodes a last update would give
             hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                                nck, d_pll_PQ.p, d_flags.p);
             hipLaunchKernelGGL(k_pll_nodes_a2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_PQ2.p,
@@ -816,7 +825,6 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                                d_pll_dstart.p, d_flags.p);
             hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                                nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
-            hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp);
           }
           hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
                              d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
@@ -1107,6 +1115,8 @@ int fmr_get_status(fmr_chain *c, int stream, fmr_status *st) {
   st->pll_residual = f.pll_resid;
   for (int i = 0; i < 16; i++) { st->agc_residual_history[i] = f.agc_hist[i]; st->pll_residual_history[i] = f.pll_hist[i]; }
   for (int i = 0; i < 8; i++) st->pll_residual_components[i] = f.pll_comp[i];
+  for (int i = 0; i < 16; i++) st->pll_mismatch_history[i] = f.pll_rhist[i];
+  st->pll_mismatch_accepted = f.pll_r_accepted;
   return FMR_OK;
 }
 

@@ -35,6 +35,8 @@ struct IterFlags {
   float agc_hist[16];     // residual after each Newton round (diagnostics)
   double pll_hist[16];
   double pll_comp[8];     // last round: residual per state component
+  double pll_rhist[16];   // scaled boundary mismatch seen by each round's integration pass
+  int pll_ticket, pll_r_accepted;
   unsigned long long pll_resid_bits, pll_comp_bits[8];   // atomicMax accumulators of the running round
 };
 
@@ -583,52 +585,71 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
                             const float *__restrict__ atan_tab, PllConst pc, int pilot_shift,
                             const double *__restrict__ nodes, double *__restrict__ G, double *__restrict__ M,
                             int *__restrict__ ck_wraps, unsigned long long *__restrict__ ck_mask, int mask_words,
-                            const IterFlags *__restrict__ fl) {
+                            const IterFlags *__restrict__ fl, double *__restrict__ wg_r) {
   __shared__ float tab[257];
   for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
   __syncthreads();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
-  if (c >= ct.nck || fl[s].pll_converged) return;
-  const double *xin = base + (long long)s * base_stride + base_off + ct.off[c];
-  double *out = raw + (long long)s * raw_stride + raw_off + ct.off[c];
-  const int n = ct.len[c];
-  PllRegs S;
-  const double *nd = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
+  if (fl[s].pll_converged) return;          // uniform: every workgroup of the stream leaves
+  const bool valid = c < ct.nck;
+  double rmax = 0.0;
+  if (valid) {
+    const double *xin = base + (long long)s * base_stride + base_off + ct.off[c];
+    double *out = raw + (long long)s * raw_stride + raw_off + ct.off[c];
+    const int n = ct.len[c];
+    PllRegs S;
+    const double *nd = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
 #pragma unroll
-  for (int k = 0; k < 7; k++) S.v[k] = nd[k];
-  S.li = 0.0; S.lq = 0.0; S.freq_err = 0.0;
-  double Mx[7][7];
-#pragma unroll
-  for (int r = 0; r < 7; r++)
-#pragma unroll
-    for (int k = 0; k < 7; k++) Mx[r][k] = (r == k) ? 1.0 : 0.0;
-  int wraps = 0;
-  // positions of the phase wraps inside the chunk (bit i = sample i wrapped): lets the
-  // finish pass place a PPS event without re-integrating the chunk
-  unsigned long long *mk = ck_mask + ((long long)s * ct.nck + c) * mask_words;
-  unsigned long long word = 0;
-  serial_prefetch<4>(xin, 0, n, [&](int i, double xv) {
-    double o;
-    const int wflag = pll_step<JAC>(S, xv, pc, tab, pilot_shift, o, Mx);
-    wraps += wflag;
-    word |= (unsigned long long)wflag << (i & 63);
-    if ((i & 63) == 63) { mk[i >> 6] = word; word = 0; }
-    out[i] = o;
-  });
-  if (n & 63) mk[n >> 6] = word;
-  double *g = G + ((long long)s * ct.nck + c) * 9;
-#pragma unroll
-  for (int k = 0; k < 7; k++) g[k] = S.v[k];
-  g[7] = pll_level(S); g[8] = S.freq_err;
-  if (JAC) {   // JAC == false: frozen-Jacobian round, the stored M of the last JAC round stands
-    double *m = M + ((long long)s * ct.nck + c) * 49;
+    for (int k = 0; k < 7; k++) S.v[k] = nd[k];
+    S.li = 0.0; S.lq = 0.0; S.freq_err = 0.0;
+    double Mx[7][7];
 #pragma unroll
     for (int r = 0; r < 7; r++)
 #pragma unroll
-      for (int k = 0; k < 7; k++) m[r * 7 + k] = Mx[r][k];
+      for (int k = 0; k < 7; k++) Mx[r][k] = (r == k) ? 1.0 : 0.0;
+    int wraps = 0;
+    // positions of the phase wraps inside the chunk (bit i = sample i wrapped): lets the
+    // finish pass place a PPS event without re-integrating the chunk
+    unsigned long long *mk = ck_mask + ((long long)s * ct.nck + c) * mask_words;
+    unsigned long long word = 0;
+    serial_prefetch<4>(xin, 0, n, [&](int i, double xv) {
+      double o;
+      const int wflag = pll_step<JAC>(S, xv, pc, tab, pilot_shift, o, Mx);
+      wraps += wflag;
+      word |= (unsigned long long)wflag << (i & 63);
+      if ((i & 63) == 63) { mk[i >> 6] = word; word = 0; }
+      out[i] = o;
+    });
+    if (n & 63) mk[n >> 6] = word;
+    double *g = G + ((long long)s * ct.nck + c) * 9;
+#pragma unroll
+    for (int k = 0; k < 7; k++) g[k] = S.v[k];
+    g[7] = pll_level(S); g[8] = S.freq_err;
+    if (JAC) {   // JAC == false: frozen-Jacobian round, the stored M of the last JAC round stands
+      double *m = M + ((long long)s * ct.nck + c) * 49;
+#pragma unroll
+      for (int r = 0; r < 7; r++)
+#pragma unroll
+        for (int k = 0; k < 7; k++) m[r * 7 + k] = Mx[r][k];
+    }
+    ck_wraps[(long long)s * ct.nck + c] = wraps;
+    // scaled mismatch against the start node of the next chunk (same scales as the node pass);
+    // the call's end node has no consumer
+    if (c + 1 < ct.nck) {
+      const double wsc = 1.0 / (1e-7 * (fabs(S.v[3]) + fabs(S.v[5]) + 1.0));
+      rmax = fabs(wrap_pm_pi(S.v[0] - nd[7])) * 1e7;
+      rmax = fmax(rmax, fabs(S.v[1] - nd[8]) * 1e9);
+      rmax = fmax(rmax, fabs(S.v[2] - nd[9]) * 1e5);
+#pragma unroll
+      for (int k = 3; k < 7; k++) rmax = fmax(rmax, fabs(S.v[k] - nd[7 + k]) * wsc);
+    }
   }
-  ck_wraps[(long long)s * ct.nck + c] = wraps;
+  // per-workgroup maximum; k_pll_check (next launch) reduces them and may accept the round on the
+  // mismatch alone, which skips this round's node pass
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, 64));
+  if (threadIdx.x == 0) wg_r[(long long)s * gridDim.x + blockIdx.x] = rmax;
 }
 
 // ---------------------------------------------------------------------------
@@ -881,31 +902,51 @@ __global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, 
   if (i == 7) gr[7] = rmax;
 }
 
-// round bookkeeping: one 1024-thread block per stream reduces the per-group residuals
+// Round bookkeeping, launched right after every integration pass: one 1024-thread block per stream
+// reduces (a) the per-workgroup boundary mismatches r of that pass and (b) the per-group Newton
+// steps d of the PREVIOUS round's node pass.  The trajectory just written is accepted if it closes
+// to rtol by itself, or if the node update that produced its start nodes was already below tol
+// (the nodes are then better than tol by the contraction factor).  Accepting here makes all node
+// kernels of this round no-ops.
 __global__ __launch_bounds__(1024) void k_pll_check(IterFlags *fl, int n_streams, double tol,
-                                                    const double *__restrict__ grp_resid, int ngrp) {
+                                                    const double *__restrict__ grp_resid, int ngrp, int have_d,
+                                                    const double *__restrict__ wg_r, int nwg, double rtol) {
   __shared__ double red[16][8];
+  __shared__ double redr[16];
   const int s = blockIdx.x;
   const int tid = threadIdx.x;
   if (s >= n_streams || fl[s].pll_converged) return;
   const double *gr = grp_resid + (long long)s * ngrp * 8;
   const int comp = tid & 7;
   double r = 0.0;
-  for (int g = tid >> 3; g < ngrp; g += 128) r = fmax(r, gr[(long long)g * 8 + comp]);
+  if (have_d)
+    for (int g = tid >> 3; g < ngrp; g += 128) r = fmax(r, gr[(long long)g * 8 + comp]);
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1) r = fmax(r, __shfl_xor(r, o, 64));   // lanes with equal comp
   if ((tid & 63) < 8) red[tid >> 6][comp] = r;
+  double rr = 0.0;
+  for (int w = tid; w < nwg; w += 1024) rr = fmax(rr, wg_r[(long long)s * nwg + w]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rr = fmax(rr, __shfl_xor(rr, o, 64));
+  if ((tid & 63) == 0) redr[tid >> 6] = rr;
   __syncthreads();
   if (tid < 8) {
     double m = 0.0;
 #pragma unroll
     for (int w = 0; w < 16; w++) m = fmax(m, red[w][tid]);
-    if (tid < 7) fl[s].pll_comp[tid] = m;
+    if (tid < 7 && have_d) fl[s].pll_comp[tid] = m;
     if (tid == 7) {
-      if (fl[s].pll_iters < 16) fl[s].pll_hist[fl[s].pll_iters] = m;
-      fl[s].pll_iters++;
-      fl[s].pll_resid = m;
-      if (m <= tol) fl[s].pll_converged = 1;
+      double mr = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; w++) mr = fmax(mr, redr[w]);
+      IterFlags &F = fl[s];
+      const int it = F.pll_iters;                    // integration passes done before this one
+      if (it < 16) F.pll_rhist[it] = mr;
+      if (have_d && it >= 1 && it <= 16) F.pll_hist[it - 1] = m;
+      F.pll_iters = it + 1;
+      if (mr <= rtol) { F.pll_converged = 1; F.pll_r_accepted = 1; F.pll_resid = mr; }
+      else if (have_d && m <= tol) { F.pll_converged = 1; F.pll_resid = m; }
+      else F.pll_resid = have_d ? m : mr;
     }
   }
 }

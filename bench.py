@@ -191,6 +191,8 @@ def main():
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "audio_check": {"stereo_locked": int(st.stereo_detected), "pilot_level": round(st.pilot_level, 6)},
             "recurrences": {"agc_newton_rounds": st.agc_iterations, "pll_newton_rounds": st.pll_iterations,
+                            "pll_residuals": [float("%.3g" % v) for v in st.pll_residual_history[:st.pll_iterations]],
+                            "pll_mismatches": [float("%.3g" % v) for v in st.pll_mismatch_history[:st.pll_iterations]],
                             "agc_serial_fallback": st.agc_fallback, "pll_serial_fallback": st.pll_fallback},
         }
         if world == 1 and not args.no_cpu_baseline:

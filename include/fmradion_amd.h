@@ -96,6 +96,9 @@ typedef struct {
   float agc_residual_history[16];   /* residual after each Newton round */
   double pll_residual_history[16];
   double pll_residual_components[8];
+  double pll_mismatch_history[16];  /* scaled chunk-boundary mismatch seen by each round's integration pass */
+  int pll_mismatch_accepted;        /* 1: the last round was accepted on the mismatch alone (node pass skipped) */
+  int reserved0;
 } fmr_status;
 
 typedef struct fmr_chain fmr_chain;

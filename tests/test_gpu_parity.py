@@ -327,7 +327,9 @@ def test_fm_stereo_config2(pilotcut):
             agc_iters=st.agc_iterations, pll_iters=st.pll_iterations, agc_fallback=st.agc_fallback,
             pll_fallback=st.pll_fallback, pll_resid=st.pll_residual,
             agc_hist=[float(v) for v in st.agc_residual_history[:st.agc_iterations]],
-            pll_hist=[float(v) for v in st.pll_residual_history[:st.pll_iterations]])
+            pll_hist=[float(v) for v in st.pll_residual_history[:st.pll_iterations]],
+            pll_rhist=[float(v) for v in st.pll_mismatch_history[:st.pll_iterations]],
+            pll_r_accepted=st.pll_mismatch_accepted)
     assert st.agc_fallback == 0 and st.pll_fallback == 0
     assert fm.stereo_detected() and st.stereo_detected == 1
     assert err < 1e-5
