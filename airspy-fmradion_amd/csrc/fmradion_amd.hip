@@ -10,6 +10,7 @@
 // the host derives from the resampler's integer output-count law.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <thread>
 
 #include <cstdarg>
 #include <cstdio>
@@ -96,9 +97,11 @@ struct fmr_chain {
   hipStream_t fe = nullptr;              // front-end stream (cross-call pipelining)
   bool pipelined = false;
   int if_parity = 0;
-  DevBuf<float2> d_if_pp[2];
+  static constexpr int kPipe = 3;       // IF buffers in flight when pipelined
+  unsigned long long pipe_seq = 0;       // pipelined calls issued
+  DevBuf<float2> d_if_pp[kPipe];
   float2 *last_if = nullptr;
-  hipEvent_t ev_fe[2] = {}, ev_dec[2] = {};
+  hipEvent_t ev_fe[kPipe] = {};
   hipStream_t side = nullptr, side2 = nullptr;   // side2: the IF AGC when it is off the critical path
   hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr,
              ev_tab = nullptr;
@@ -143,8 +146,8 @@ struct fmr_chain {
   static constexpr int kTabSlots = 8;
   int *h_tab_all = nullptr;  // pinned, kTabSlots * tab_ints
   size_t tab_ints = 0;       // 5*max_blocks block table + 3*max_ck chunk table + (max_blocks+1) first-chunk table
-  hipEvent_t tab_ev[kTabSlots] = {};
-  int tab_slot = 0;
+  unsigned long long call_seq = 0;      // calls issued
+  unsigned long long *h_marks = nullptr; // pinned: [0] calls whose table copy has run, [1] pipelined calls whose decoder has finished
   std::vector<StreamState> h_state;
   // constants
   PllConst pllc{};
@@ -176,17 +179,16 @@ struct fmr_chain {
     d_pll_wgr.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
-    for (auto &e : tab_ev) if (e) (void)hipEventDestroy(e);
+    if (h_marks) (void)hipHostFree(h_marks);
     for (hipEvent_t e : {ev_disc, ev_pll, ev_stats, ev_fin, ev_if}) if (e) (void)hipEventDestroy(e);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (host_prof && hp_calls)
       fprintf(stderr, "[fmr host prof] calls %lld  front-end %.1f us  tables %.1f us  decoder %.1f us per call\n", hp_calls,
               hp_fe / hp_calls, hp_tab / hp_calls, hp_dec / hp_calls);
-    if (side2) { (void)hipStreamSynchronize(side2); (void)hipStreamDestroy(side2); }
+    if (side2 && side2 != side) { (void)hipStreamSynchronize(side2); (void)hipStreamDestroy(side2); }
     if (fe) { (void)hipStreamSynchronize(fe); (void)hipStreamDestroy(fe); }
     for (auto &e : ev_fe) if (e) (void)hipEventDestroy(e);
-    for (auto &e : ev_dec) if (e) (void)hipEventDestroy(e);
-    d_if_pp[0].release(); d_if_pp[1].release();
+    for (auto &b : d_if_pp) b.release();
     if (ev_agc) (void)hipEventDestroy(ev_agc);
     if (ev_tab) (void)hipEventDestroy(ev_tab);
     if (stream) (void)hipStreamDestroy(stream);
@@ -217,6 +219,16 @@ struct fmr_chain {
   template <class F>
   void timed(const char *name, F &&launch) { timed_on(stream, name, launch); }
 
+  // poll a counter in pinned host memory that a one-thread kernel advances (k_signal_host)
+  int wait_mark(unsigned long long *mark, unsigned long long need) {
+    if (need == 0) return FMR_OK;
+    const auto t_lim = std::chrono::steady_clock::now() + std::chrono::seconds(60);
+    while (__atomic_load_n(mark, __ATOMIC_ACQUIRE) < need) {
+      std::this_thread::yield();
+      if (std::chrono::steady_clock::now() > t_lim) { set_err("the GPU did not reach mark %llu within 60 s", need); return FMR_ERR_HIP; }
+    }
+    return FMR_OK;
+  }
   int init(const fmr_config *c);
   int run(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
           size_t astride, uint32_t *audio_len);
@@ -342,11 +354,14 @@ int fmr_chain::init(const fmr_config *c) {
     const char *e = getenv("FMR_PIPELINE");
     pipelined = has_rs && has_dec && !fir_enable && e && e[0] == '1';
     if (pipelined) {
+      // HIP multiplexes streams onto 4 hardware queues: a fifth stream would share one with the AGC stream and the
+      // front end would queue behind 0.45 ms of AGC kernels.  The AGC moves onto `side` (after the statistics).
+      (void)hipStreamDestroy(side2);
+      side2 = side;
       HIPCHK(hipStreamCreateWithFlags(&fe, hipStreamNonBlocking));
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < kPipe; q++) {
         if ((rc = d_if_pp[q].alloc((size_t)S * (H_if + max_if)))) return rc;
         HIPCHK(hipEventCreateWithFlags(&ev_fe[q], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_dec[q], hipEventDisableTiming));
       }
     }
   }
@@ -360,7 +375,8 @@ int fmr_chain::init(const fmr_config *c) {
   max_ck = max_if / C_PLL_MIN + (size_t)max_blocks + 2;
   tab_ints = 5 * (size_t)max_blocks + 3 * max_ck + (size_t)max_blocks + 1;
   HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * tab_ints));
-  for (auto &e : tab_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(hipHostMalloc((void **)&h_marks, 2 * sizeof(unsigned long long)));
+  h_marks[0] = h_marks[1] = 0;
   if ((rc = d_tab.alloc((size_t)kTabSlots * tab_ints))) return rc;
   h_flags.assign(S, IterFlags{});
   if ((rc = d_flags.alloc((size_t)S))) return rc;
@@ -531,9 +547,13 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   } host_prof_guard{this, hp0, hp1, hp2};
   for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
   ktimes.clear();
-  const int slot = tab_slot;
-  tab_slot = (tab_slot + 1) % kTabSlots;
-  HIPCHK(hipEventSynchronize(tab_ev[slot]));   // slot free again (no-op if never recorded)
+  // Table slot ring: the slot is free once the copy kernel of the call that used it kTabSlots calls ago has run.
+  // That kernel's successor writes a counter into pinned host memory which is polled here -- hipEventSynchronize
+  // would block until the newest signal of the side stream at call time (most of the PREVIOUS call) and stop the
+  // host from enqueueing ahead (measured).
+  call_seq++;
+  const int slot = (int)(call_seq % kTabSlots);
+  if (int rcw = wait_mark(&h_marks[0], call_seq > (unsigned long long)kTabSlots ? call_seq - kTabSlots : 0)) return rcw;
   int *h_tab = h_tab_all + (size_t)slot * tab_ints;
   int *d_tab_slot = d_tab.p + (size_t)slot * tab_ints;
   int *t_if_off = h_tab, *t_if_len = h_tab + max_blocks, *t_au_off = h_tab + 2 * max_blocks,
@@ -542,11 +562,18 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   long long N_if = 0, count_mid_call = 0;
   // Cross-call pipelining: the front end of call N+1 (its own stream, its own IF buffer) runs
   // beside the decoder of call N, whose recurrence kernels leave most of the chip idle.
-  const int par = pipelined ? (if_parity ^= 1) : 0;
+  const int par = pipelined ? (if_parity = (if_parity + 1) % kPipe) : 0;
   hipStream_t fes = pipelined ? fe : stream;
   float2 *ifbuf = pipelined ? d_if_pp[par].p : d_if.p;
   last_if = ifbuf;
-  if (pipelined) HIPCHK(hipStreamWaitEvent(fe, ev_dec[par], 0));   // decoder of call N-2 is done with this buffer
+  // The decoder that last read this IF buffer (kPipe calls ago) must be done before the front end refills it.
+  // The host polls a counter that a one-thread kernel at the end of every decoder writes into pinned host memory:
+  // HIP event waits (stream-side or host-side) resolve against the newest signal of the other stream at call
+  // time -- most of the PREVIOUS call -- and serialise the two stages again (measured).
+  if (pipelined) {
+    pipe_seq++;
+    if (int rcw = wait_mark(&h_marks[1], pipe_seq > (unsigned long long)kPipe ? pipe_seq - kPipe : 0)) return rcw;
+  }
   if (has_rs) {
     const long long mA_prev = rsc.mA, kB_prev = rsc.kB, n_prev = rsc.n_in;
     for (int b = 0; b < nb; b++) {
@@ -652,7 +679,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     add_halo(d_mid.p, H_mid + (long long)max_mid, H_mid, count_mid_call);
   }
   if (!has_dec || N_if == 0) {
-    if (pipelined) HIPCHK(hipEventRecord(ev_dec[par], stream));
+    hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, side, &h_marks[0], call_seq);   // no table this call
+    if (pipelined) hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, stream, &h_marks[1], pipe_seq);
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = 0;
     if (has_dec && fir_enable) add_halo(ifbuf, H_if + (long long)max_if, H_if, N_if);
     if (ht.n) hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht);
@@ -700,7 +728,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   int *d_first = d_tab_slot + 5 * (size_t)max_blocks;
   int *d_ck = d_tab_slot + head_ints;
   ChunkTab ct{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_first, nck};
-  HIPCHK(hipEventRecord(tab_ev[slot], side));
+  hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, side, &h_marks[0], call_seq);
   if (mode == FMR_MODE_FM && nck > 0) {
     hipLaunchKernelGGL(k_chunk_tab, dim3(nb), dim3(64), 0, side, d_tab_slot, d_tab_slot + max_blocks, d_first, c_pll,
                        d_ck, d_ck + max_ck, d_ck + 2 * max_ck);
@@ -975,7 +1003,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   if (ht.n) {
     timed("shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht); });
   }
-  if (pipelined) HIPCHK(hipEventRecord(ev_dec[par], stream));
+  if (pipelined) hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, stream, &h_marks[1], pipe_seq);
   HIPCHK(hipGetLastError());
   return FMR_OK;
 }

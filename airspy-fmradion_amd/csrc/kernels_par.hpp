@@ -501,6 +501,11 @@ struct ChunkTab {
   int nck;
 };
 
+// End-of-decoder mark for the pipelined chain: a counter in pinned host memory the caller polls.
+__global__ void k_signal_host(unsigned long long *flag, unsigned long long value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Per-call block table: pinned host slot -> device slot (the host pointer is device-visible).
 __global__ void k_copy_ints(const int *__restrict__ src, int *__restrict__ dst, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
