@@ -120,6 +120,8 @@ struct fmr_chain {
   DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
   int poly2_tile = 0;                  // staged mid samples per tile, 0 = v2 kernel not applicable
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
+  bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
+  DevBuf<float> d_afrag;               // v4: constant A fragments
   DevBuf<float> d_hBp;                 // zero-padded tap rows for v3
   DevBuf<float> d_hpA;                 // stage-A taps in polyphase order [D][Q] (k_ifr_decim2)
   int qa = 0;                          // taps per phase (even), 0 = v2 kernel not applicable
@@ -174,7 +176,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_afrag.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -327,6 +329,21 @@ int fmr_chain::init(const fmr_config *c) {
           poly2_tile = (int)tl + 64;       // slack: the last 8-sample step may run past the union window
           poly3 = true;
           HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly3<384, Q3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        }
+        const char *e4 = getenv("FMR_POLY_V3");
+        if (poly3 && rs.LB == 48 && rs.MB == 125 && rs.TB == 210 && !(e4 && e4[0] == '1')) {
+          using SH = Poly4Shape<48, 125, 210>;
+          std::vector<float> af((size_t)SH::MT * SH::NK * 64, 0.f);
+          for (int mt = 0; mt < SH::MT; mt++)
+            for (int i = 0; i < SH::nks(mt); i++)
+              for (int l = 0; l < 64; l++) {
+                const int pp = 16 * mt + (l & 15), m = 4 * (SH::ks_lo(mt) + i) + (l >> 4), j = m - off[pp];
+                if (j >= 0 && j < rs.TB) af[((size_t)mt * SH::NK + i) * 64 + l] = fb[(size_t)phi[pp] * rs.TB + j];
+              }
+          if ((rc = upload(d_afrag, af.data(), af.size()))) return rc;
+          poly4 = true;
+          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 125, 210>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
         }
       }
@@ -625,7 +642,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       const long long P_first = kB_prev / rs.LB, P_last = (kB_prev + N_if - 1) / rs.LB;
       const int tiles = (int)((P_last - P_first) / 64 + 1);
       timed_on(fes, "ifr_poly", [&] {
-        if (poly3)
+        if (poly4)
+          hipLaunchKernelGGL((k_ifr_poly4<48, 125, 210>), dim3(std::min(tiles, 512), S), dim3(256),
+                             sizeof(float2) * (size_t)(poly2_tile + 4 * 8 * 48), fes, d_mid.p,
+                             (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag.p, kB_prev,
+                             (int)N_if, ifbuf, (long long)(H_if + max_if), H_if, poly2_tile, tiles);
+        else if (poly3)
           hipLaunchKernelGGL((k_ifr_poly3<384, 4>), dim3(tiles, S), dim3(384), sizeof(float2) * (size_t)poly2_tile, fes,
                              d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_hBp.p, rs.TB,
                              (int)rs.LB, (int)rs.MB, d_bphi.p, d_boff.p, kB_prev, (int)N_if, ifbuf,

@@ -521,6 +521,108 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_poly3(
 }
 
 // ---------------------------------------------------------------------------
+// K_B v4  ifr_poly4 : the rational polyphase stage as an f32 MFMA product, for the LB/MB = 48/125,
+// TB = 210 shape (every source rate whose stage A lands on 1 MHz: 10, 6, 3 MS/s ...).
+// For one period P the LB outputs are  Y[p] = sum_m A[p][m] X[m],  X[m] = mid[P*MB - W + 1 + m],
+// A[p][m] = h[phi[p]][m - off[p]] (0 outside the TB taps): a constant (48 x 332) banded matrix.
+// v_mfma_f32_16x16x4_f32 tiles: rows = 16 positions (3 row tiles), columns = 8 periods x (re, im),
+// k = 4 consecutive m.  The A fragments of all 3 x 63 live (non-zero) k-steps stay in registers for
+// the life of the (persistent) workgroup, so the taps are never re-read; every B fragment (one
+// ds_read_b32 per lane) feeds up to three MFMAs.  v2/v3 stream the taps through the scalar cache
+// (52 KB table, 16 KB cache) and stall on its misses at ~25 % VALU utilisation.
+// An MFMA is bit-for-bit a k-ordered fmaf chain, i.e. the same sequential tap-order accumulation
+// as v2/v3 (plus exact zero terms).
+// ---------------------------------------------------------------------------
+template <int LB, int MB, int TB>
+struct Poly4Shape {
+  static constexpr int off(int p) { return (p * MB) / LB; }
+  static constexpr int ks_lo(int mt) { return off(16 * mt) / 4; }
+  static constexpr int ks_hi(int mt) { return (off(16 * mt + 15) + TB + 3) / 4 - 1; }
+  static constexpr int MT = LB / 16;
+  static constexpr int nks(int mt) { return ks_hi(mt) - ks_lo(mt) + 1; }
+  static constexpr int NK = nks(0) > nks(MT - 1) ? (nks(0) > nks(1) ? nks(0) : nks(1)) : (nks(MT - 1) > nks(1) ? nks(MT - 1) : nks(1));
+  static constexpr int KS_ALL = ks_hi(MT - 1) + 1;          // k-steps of the union window
+  static constexpr int XLEN = 4 * KS_ALL;                   // mid samples one period touches
+};
+
+template <int LB, int MB, int TB>
+__global__ __launch_bounds__(256, 2) void k_ifr_poly4(
+    const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
+    const float *__restrict__ afrag, long long k0, int count, float2 *__restrict__ out, long long out_stride,
+    int out_off, int tile_len, int n_tiles) {
+  using SH = Poly4Shape<LB, MB, TB>;
+  static_assert(LB == 48, "three 16-row tiles");
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float2 lds_b4[];
+  float2 *stage = lds_b4 + tile_len;                         // 4 waves x (8 periods x LB) float2
+  const int s = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  constexpr int W = TB >> 1;
+  // ---- the constant A fragments: a[mt][i] = A[16 mt + n][4 (ks_lo(mt) + i) + kq]
+  float a[SH::MT][SH::NK];
+#pragma unroll
+  for (int mt = 0; mt < SH::MT; mt++)
+#pragma unroll
+    for (int i = 0; i < SH::NK; i++) a[mt][i] = afrag[(mt * SH::NK + i) * 64 + lane];
+  const float2 *ms = mid + (long long)s * mid_stride;
+  float2 *os = out + (long long)s * out_stride + out_off;
+  float2 *mystage = stage + wave * (8 * LB);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long P0 = k0 / LB + (long long)tile * 64;
+    const long long a0 = P0 * MB - W + 1;
+    __syncthreads();                                          // previous tile fully consumed
+    for (int i0 = 0; i0 < tile_len; i0 += 8 * 256) {
+      float2 v[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const int i = i0 + t * 256 + tid;
+        const long long idx = a0 + i - mid_abs0;
+        v[t] = (i < tile_len && idx >= 0 && idx < mid_valid) ? ms[idx] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const int i = i0 + t * 256 + tid;
+        if (i < tile_len) lds_b4[i] = v[t];
+      }
+    }
+    __syncthreads();
+    const float *xf = reinterpret_cast<const float *>(lds_b4);
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const int q0 = (wave + 4 * h) * 8;                      // first period of this column tile
+      const float *xb = xf + 2 * ((q0 + (n >> 1)) * MB + kq) + (n & 1);
+      v4f acc[SH::MT];
+#pragma unroll
+      for (int mt = 0; mt < SH::MT; mt++) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < SH::KS_ALL; ks++) {
+        const float b = xb[8 * ks];
+#pragma unroll
+        for (int mt = 0; mt < SH::MT; mt++)
+          if (ks >= SH::ks_lo(mt) && ks <= SH::ks_hi(mt))
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][ks - SH::ks_lo(mt)], b, acc[mt], 0, 0, 0);
+      }
+      // D[row = 4 kq + v][col = n] -> position p = 16 mt + 4 kq + v of period q0 + n/2, component n & 1
+      float *sf = reinterpret_cast<float *>(mystage);
+#pragma unroll
+      for (int mt = 0; mt < SH::MT; mt++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * LB + 16 * mt + 4 * kq + v) + (n & 1)] = acc[mt][v];
+      __syncthreads();
+      const long long kb = (P0 + q0) * LB - k0;               // local output index of the staged run
+#pragma unroll
+      for (int t = 0; t < (8 * LB) / 64; t++) {
+        const int idx = t * 64 + lane;
+        const long long k = kb + idx;
+        if (k >= 0 && k < count) os[k] = mystage[idx];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_shift_halo : re-seat prefix halos at the end of a call.  All elements are
 // 8 bytes (float2 or double).  newhalo[i] = concat(halo,data)[i + N].
 // ---------------------------------------------------------------------------
