@@ -982,7 +982,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         timed("fm_out", [&] {
           hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
                              (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc);
-          hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
+          const int dc_nw = std::max(1, std::min(16, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
+          hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
                              d_state.p, S, nch);
           hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
                              (long long)max_au, bt, (int)N_au, dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,

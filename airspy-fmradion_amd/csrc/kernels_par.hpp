@@ -221,19 +221,30 @@ __device__ __forceinline__ void mv2(const double *m, double x1, double x2, doubl
   y1 = m[0] * x1 + m[1] * x2;
   y2 = m[2] * x1 + m[3] * x2;
 }
-__global__ __launch_bounds__(64) void k_dc_nodes(const double *__restrict__ G, double *__restrict__ start, int nc,
-                                                  DcCoef k, StreamState *st, int n_streams, int nch) {
+__global__ __launch_bounds__(1024) void k_dc_nodes(const double *__restrict__ G, double *__restrict__ start, int nc,
+                                                    DcCoef k, StreamState *st, int n_streams, int nch) {
+  // blockDim.x = 64 * NW: the NW waves take consecutive 64*K-chunk segments of a pass, scan them with a zero
+  // carry in parallel, chain the NW segment totals (A^(C K 64) per segment) and replay with the true carries.
+  __shared__ double tot[16][2];
+  __shared__ double endst[2];
   const int t = blockIdx.x;
   const int s = t / nch, ch = t % nch;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
   if (s >= n_streams) return;
   const double *g = G + (((long long)s * 2 + ch) * nc) * 2;
   double *o = start + (((long long)s * 2 + ch) * nc) * 2;
   double c1 = ch ? st[s].dc_st_x1 : st[s].dc_mono_x1;     // carry: state at the start of the pass
   double c2 = ch ? st[s].dc_st_x2 : st[s].dc_mono_x2;
   constexpr int K = FMR_DC_K;
-  for (int c0 = 0; c0 < nc; c0 += 64 * K) {
-    const int cb = c0 + lane * K;
+  // AG^64 = (AG^32)^2: transition over one wave segment
+  double ag64[4];
+  {
+    const double *x = k.agp[5];
+    ag64[0] = x[0] * x[0] + x[1] * x[2]; ag64[1] = x[0] * x[1] + x[1] * x[3];
+    ag64[2] = x[2] * x[0] + x[3] * x[2]; ag64[3] = x[2] * x[1] + x[3] * x[3];
+  }
+  for (int c0 = 0; c0 < nc; c0 += 64 * K * NW) {
+    const int cb = c0 + (wv * 64 + lane) * K;
     // fold my K chunks from zero state
     double q1 = 0.0, q2 = 0.0;
     for (int j = 0; j < K; j++) {
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(64) void k_dc_nodes(const double *__restrict__ G, d
       }
       // past the end: identity step would need A^-C; lanes past nc are never read back
     }
-    // inclusive scan: q_l <- sum_{i<=l} AG^(l-i) q_i
+    // inclusive scan inside the wave: q_l <- sum_{i<=l} AG^(l-i) q_i
 #pragma unroll
     for (int lv = 0; lv < 6; lv++) {
       const int o_ = 1 << lv;
@@ -256,10 +267,19 @@ __global__ __launch_bounds__(64) void k_dc_nodes(const double *__restrict__ G, d
         q1 += m1; q2 += m2;
       }
     }
+    if (lane == 63) { tot[wv][0] = q1; tot[wv][1] = q2; }
+    __syncthreads();
+    // carry entering my wave's segment (segments before a partial one are always full)
+    double w1 = c1, w2 = c2;
+    for (int u = 0; u < wv; u++) {
+      double m1, m2;
+      mv2(ag64, w1, w2, m1, m2);
+      w1 = m1 + tot[u][0]; w2 = m2 + tot[u][1];
+    }
     // my start = AG^lane * carry + (inclusive result of lane-1)
     double e1 = __shfl_up(q1, 1, 64), e2 = __shfl_up(q2, 1, 64);
     if (lane == 0) { e1 = 0.0; e2 = 0.0; }
-    double t1 = c1, t2 = c2;
+    double t1 = w1, t2 = w2;
 #pragma unroll
     for (int lv = 0; lv < 6; lv++) {
       if (lane & (1 << lv)) { double m1, m2; mv2(k.agp[lv], t1, t2, m1, m2); t1 = m1; t2 = m2; }
@@ -274,8 +294,11 @@ __global__ __launch_bounds__(64) void k_dc_nodes(const double *__restrict__ G, d
         x1 = n1 + g[2 * c]; x2 = n2 + g[2 * c + 1];
       }
     }
-    // carry into the next pass = state after the last chunk of lane 63 (only used when the pass was full)
-    c1 = __shfl(x1, 63, 64); c2 = __shfl(x2, 63, 64);
+    // carry into the next pass = state after the last chunk of the last lane (only used when the pass was full)
+    if (wv == NW - 1 && lane == 63) { endst[0] = x1; endst[1] = x2; }
+    __syncthreads();
+    c1 = endst[0]; c2 = endst[1];
+    __syncthreads();
   }
 }
 
