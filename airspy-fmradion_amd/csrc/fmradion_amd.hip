@@ -10,6 +10,7 @@
 // the host derives from the resampler's integer output-count law.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <functional>
 #include <thread>
 
 #include <cstdarg>
@@ -777,7 +778,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   const int x_off = fir_enable ? 0 : H_if;
   // ---- IF AGC: Newton multiple shooting over chunks of C_AGC samples (kernels_par.hpp)
   const float *disc_gain = d_gain.p;      // gain sequence the discriminator multiplies in (nullptr = none)
-  bool agc_on_side = false;
+  bool agc_on_side = false, agc_deferred = false;
+  std::function<int()> enqueue_agc;
   const int agc_nc = (int)((N_if + C_AGC - 1) / C_AGC);
   hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, stream, d_flags.p,
                      (serial_mode || enable_mpf) ? (float *)nullptr : d_agc_nodes.p,
@@ -796,6 +798,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     // critical path (the two paths differ by 3.8e-8 RMS of float rounding).
     const bool agc_aside = (mode == FMR_MODE_FM);
     hipStream_t as = agc_aside ? side2 : stream;
+    // With the PLL on, the side-stream AGC starts only after the PLL's first (Jacobian) integration pass: that
+    // pass runs one wave per SIMD and every co-resident AGC wave stretches it (measured 118 -> 160 us).
+    agc_deferred = agc_aside && stereo && !getenv("FMR_AGC_EARLY");
+    enqueue_agc = [=, &disc_gain, &agc_on_side]() -> int {
     if (agc_aside) {
       HIPCHK(hipEventRecord(ev_if, stream));
       HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
@@ -811,7 +817,11 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,
                          d_gain.p, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
     });
-    if (agc_aside) { disc_gain = nullptr; HIPCHK(hipEventRecord(ev_agc, side2)); agc_on_side = true; }
+    if (agc_aside) { HIPCHK(hipEventRecord(ev_agc, side2)); }
+    return FMR_OK;
+    };
+    if (agc_aside) { disc_gain = nullptr; agc_on_side = true; }
+    if (!agc_deferred) { if (int rca = enqueue_agc()) return rca; }
   }
   if (mode == FMR_MODE_FM) {
     if (any_mpf) {
@@ -862,6 +872,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                                  base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
                                  d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p,
                                  d_pll_wgr.p);
+            if (it == 0 && agc_deferred) { agc_deferred = false; if (enqueue_agc()) return; }
             hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
                                (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
             if (it == K_PLL_ITERS - 1) break;      // nothing integrates the nodes a last update would give
@@ -894,6 +905,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         fin_on_side = true;
       }
     }
+    if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc()) return rca; }   // PLL path not taken
     const int nch = stereo ? 2 : 1;
     // ---------------------------------------------------- audio resampler + tail
     const int count_am = (int)(arsc.mA - amA_prev);
