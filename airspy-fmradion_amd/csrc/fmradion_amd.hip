@@ -812,7 +812,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                            (int)N_if, d_gain.p, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            agc_init, agc_max, agc_rate, d_flags.p);
         hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64), 0, as, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
-                           d_state.p, d_flags.p);
+                           d_state.p, d_flags.p, (int)(mode == FMR_MODE_FM));
       }
       hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,
                          d_gain.p, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);

@@ -398,7 +398,7 @@ __global__ void k_agc_shoot(const float2 *__restrict__ x, long long x_stride, in
 #define FMR_AGC_PER_LANE 8
 __global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, const float *__restrict__ G,
                                                   const double *__restrict__ M, int nc, StreamState *st,
-                                                  IterFlags *fl) {
+                                                  IterFlags *fl, int gain_invariant) {
   const int s = blockIdx.x;
   const int lane = threadIdx.x;
   if (fl[s].agc_converged) return;
@@ -461,8 +461,11 @@ __global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, con
     // and the reference's gain only random-walks inside a dead zone ~3e-4 wide; there
     // the chunk map has no usable slope and the rounds stagnate at a few 1e-5.  That
     // is also the level at which the reference's own gain depends on FMA contraction
-    // (hazard H7), and atan2 is invariant to it: accept <= 5e-5 from round 2 on.
-    if (maxrel <= 1.0e-6f || (fl[s].agc_iters >= 2 && maxrel <= 5.0e-5f)) {   // gains of the last shoot pass stand
+    // (hazard H7), and atan2 is invariant to it: accept <= 5e-5 from round 2 on -- only where the consumer
+    // is invariant to the gain (FM discriminator).  AM audio scales with the gain: there the rounds go on until
+    // no node moves by more than one float ulp.
+    const float tight = gain_invariant ? 1.0e-6f : 1.5e-7f;
+    if (maxrel <= tight || (gain_invariant && fl[s].agc_iters >= 2 && maxrel <= 5.0e-5f)) {   // gains of the last shoot pass stand
       fl[s].agc_converged = 1;
       st[s].agc_gain = nd[nc];
     }

@@ -254,6 +254,7 @@ def test_am_decoder_48k(mode, am_narrow):
     err = rms(got - ref)
     st = ch.status()
     _report(f"{mode}_48k", audio_rms_err=err, audio_rms=rms(ref), if_agc=st.if_agc_gain, ref_if_agc=am.get_if_agc_current_gain(),
+            agc_iters=st.agc_iterations, agc_fallback=st.agc_fallback, agc_hist=[float(v) for v in st.agc_residual_history[:st.agc_iterations]],
             af_agc=st.af_agc_gain, ref_af_agc=am.get_af_agc_current_gain())
     assert len(got) == len(ref) and err < 1e-6
     assert st.if_agc_gain == pytest.approx(am.get_if_agc_current_gain(), rel=1e-5)

@@ -1,0 +1,44 @@
+"""Copy the summaries tools/collect_profiles.sh left under gpurun_out/<tag>_* into profiles/ and refresh the
+measured rows of DESIGN.md section 7.   python tools/finish_profiles.py r01"""
+import csv, json, os, re, shutil, subprocess, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+g = lambda *a: os.path.join(root, "gpurun_out", *a)
+prof = lambda *a: os.path.join(root, "profiles", *a)
+os.makedirs(prof(), exist_ok=True)
+bench = None
+for line in open(g(f"{tag}_bench.json")):
+    if line.startswith("{"):
+        bench = json.loads(line)
+json.dump(bench, open(prof(f"{tag}_bench.json"), "w"), indent=1)
+stats = g(f"{tag}_stats", f"{tag}_kernel_stats.csv")
+shutil.copy(stats, prof(f"{tag}_kernel_stats.csv"))
+subprocess.check_call([sys.executable, os.path.join(root, "tools", "summarize_pmc.py"),
+                       g(f"{tag}_pmc_fetch", "f_counter_collection.csv"), g(f"{tag}_pmc_write", "w_counter_collection.csv"),
+                       prof(f"{tag}_pmc_traffic.json"), str(bench["config"]["blocks_per_step"])])
+for extra in (f"{tag}_pytest_gpu.log", f"{tag}_smoke.log"):
+    if os.path.exists(g(extra)):
+        shutil.copy(g(extra), prof(extra))
+if os.path.exists(g("parity_report.json")):
+    shutil.copy(g("parity_report.json"), prof(f"{tag}_parity_report.json"))
+dec = [r for r in csv.DictReader(open(stats)) if "k_ifr_decim" in r["Name"]][0]
+rocprof_us = float(dec["AverageNs"]) / 1e3
+# the stats run is the same command without the cpu baseline: its own bench line carries the in-region HIP-event time
+ev_ms = None
+for line in open(g(f"{tag}_stats.log")):
+    if line.startswith("{"):
+        ev_ms = json.loads(line)["roofline"]["avg_launch_ms"]
+rf = bench["roofline"]
+rows = {
+    "whole-job throughput, config 2 (1 stream)": f"{bench['value'] / 1e3:.1f} GS/s ({bench['ms_per_step']:.3f} ms per 2^27-sample step)",
+    "`k_ifr_decim2` average launch (HIP events in the timed region / rocprofv3)":
+        f"{rf['avg_launch_ms'] * 1e3:.1f} µs (bench run) / {ev_ms * 1e3:.1f} µs vs {rocprof_us:.1f} µs (events vs rocprofv3 --stats in the profiled run, {dec['Calls']} launches)",
+    "`roofline` (HBM, 8 B × 2^27 per launch ÷ launch time ÷ 8 TB/s)": f"{rf['achieved']:.0f} GB/s = {rf['frac']:.3f} of peak",
+}
+p = os.path.join(root, "DESIGN.md")
+s = open(p).read()
+for k, v in rows.items():
+    s, n = re.subn(r"^\| " + re.escape(k) + r" \|.*\|$", f"| {k} | {v} |", s, flags=re.M)
+    assert n == 1, k
+open(p, "w").write(s)
+print(json.dumps(rows, indent=1, ensure_ascii=False))
