@@ -559,6 +559,35 @@ __device__ __forceinline__ double wrap_pm_pi(double d) {
   return d;
 }
 
+// sin and cos of the PLL phase (PilotPhaseLock.cpp:78-79 calls std::sin / std::cos).  The phase lives in
+// (0, 2 pi + maxfreq], so the general-range machinery of the library sincos (about 100 of the ~200 instructions
+// of a sample step, all on the loop-carried chain) is not needed: two-constant Cody-Waite reduction by pi/2
+// (exact for |n| < 2^20) and the classic degree-13/14 minimax kernels on [-pi/4, pi/4].  Absolute error
+// <= 2.3e-16 (checked against a correctly rounded reference over the whole range), i.e. the same last-bit class as
+// the difference between two libm implementations.
+__device__ __forceinline__ void pll_sincos(double x, double &sn, double &cs) {
+  const double n = rint(x * 6.36619772367581382433e-01);            // 2/pi
+  double r = fma(-n, 1.57079632673412561417e+00, x);                // pi/2, first 33 bits
+  r = fma(-n, 6.07710050650619224932e-11, r);                       // pi/2 - the above
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sp = fma(r * z, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cp = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)n & 3;
+  const double a = (q & 1) ? cp : sp, b = (q & 1) ? sp : cp;
+  sn = (q & 2) ? -a : a;
+  cs = ((q + 1) & 2) ? -b : b;
+}
+
 // One PLL sample step, the reference's arithmetic (PilotPhaseLock.cpp:73-151);
 // JAC: also advance the 7x7 sensitivity Mx = d state / d start-state.
 template <bool JAC>
@@ -566,7 +595,7 @@ __device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc
                                         double &out, double (*Mx)[7]) {
   const double two_pi = 2.0 * 3.14159265358979323846;
   double psin, pcos;
-  sincos(S.v[0], &psin, &pcos);
+  pll_sincos(S.v[0], psin, pcos);
   const double carrier = pilot_shift ? (2 * pcos * pcos - 1) : (2 * psin * pcos);
   out = (carrier * x) * 2.0;
   const double phasor_i = psin * x, phasor_q = pcos * x;
