@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_DIR, "libfmradion_amd.so")
 SRC = os.path.join(_DIR, "csrc", "fmradion_amd.hip")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
-MODE_NONE, MODE_FM, MODE_AM, MODE_DSB = -1, 0, 2, 3
+MODE_NONE, MODE_FM, MODE_NBFM, MODE_AM, MODE_DSB = -1, 0, 1, 2, 3
 OK = 0
 
 EXPORTS = [
@@ -40,7 +40,7 @@ class Config(C.Structure):
         ("enable_resampler", C.c_int), ("enable_fourth_down", C.c_int), ("fmfilter_enable", C.c_int),
         ("filter_coeff", C.POINTER(C.c_float)), ("n_filter_coeff", C.c_int), ("stereo", C.c_int),
         ("deemphasis_us", C.c_double), ("pilot_shift", C.c_int), ("multipath_stages", C.c_uint),
-        ("max_block_len", C.c_size_t), ("max_blocks", C.c_int),
+        ("max_block_len", C.c_size_t), ("max_blocks", C.c_int), ("nbfm_freq_dev", C.c_double),
     ]
 
 
@@ -141,7 +141,7 @@ class Chain:
 
     def __init__(self, mode=MODE_FM, input_rate=384000.0, enable_resampler=False, fourth_down=False,
                  fmfilter_enable=False, filter_coeff=None, stereo=True, deemphasis_us=50.0, pilot_shift=False,
-                 multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0):
+                 multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0, nbfm_freq_dev=0.0):
         coeff = np.ascontiguousarray(DELAY_3TAPS if filter_coeff is None else filter_coeff, dtype=np.float32)
         self._coeff = coeff
         cfg = Config()
@@ -153,6 +153,7 @@ class Chain:
         cfg.stereo, cfg.deemphasis_us, cfg.pilot_shift = int(stereo), float(deemphasis_us), int(pilot_shift)
         cfg.multipath_stages = int(multipath_stages)
         cfg.max_block_len, cfg.max_blocks = int(max_block_len), int(max_blocks)
+        cfg.nbfm_freq_dev = float(nbfm_freq_dev)
         self.n_streams, self.mode, self.stereo = n_streams, mode, bool(stereo) and mode == MODE_FM
         self.h = C.c_void_p()
         rc = lib().fmr_create(C.byref(cfg), C.byref(self.h))

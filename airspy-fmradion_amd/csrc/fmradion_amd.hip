@@ -120,6 +120,7 @@ struct fmr_chain {
   DevBuf<float2> d_in, d_in_halo, d_mid, d_if, d_fir, d_mpf, d_mpf_coeff, d_mpf_state;
   DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
   int poly2_tile = 0;                  // staged mid samples per tile, 0 = v2 kernel not applicable
+  double nbfm_freq_dev = 8000.0;
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
   DevBuf<float> d_afrag;               // v4: constant A fragments
@@ -250,7 +251,7 @@ int fmr_chain::init(const fmr_config *c) {
   S = c->n_streams;
   mode = c->mode;
   if (S < 1 || c->max_block_len == 0 || c->max_blocks < 1) { set_err("bad capacity / n_streams"); return FMR_ERR_BAD_ARG; }
-  if (mode != FMR_MODE_FM && mode != FMR_MODE_AM && mode != FMR_MODE_DSB && mode != FMR_MODE_NONE) {
+  if (mode != FMR_MODE_FM && mode != FMR_MODE_NBFM && mode != FMR_MODE_AM && mode != FMR_MODE_DSB && mode != FMR_MODE_NONE) {
     set_err("mode %d is not on the hot path (FM, AM, DSB only)", mode);
     return FMR_ERR_UNSUPPORTED;
   }
@@ -530,6 +531,17 @@ int fmr_chain::init(const fmr_config *c) {
     if ((rc = upload(d_mpf_coeff, cf.data(), cf.size()))) return rc;
     if ((rc = d_mpf_state.alloc((size_t)S * mpf_N))) return rc;
     if (enable_mpf && (rc = d_mpf.alloc((size_t)S * max_if))) return rc;
+  } else if (mode == FMR_MODE_NBFM) {
+    nbfm_freq_dev = (c->nbfm_freq_dev > 0) ? c->nbfm_freq_dev : 8000.0;  // NbfmDecode.h:39 freq_dev_normal
+    agc_init = 1.0f; agc_max = 100000.0f; agc_rate = 0.0001f;           // NbfmDecode.cpp:43
+    disc_nf = (float)((nbfm_freq_dev / kAmRate) * 2.0 * M_PI);           // NbfmDecode.cpp:35, PhaseDiscriminator.cpp:28
+    disc_bound = (float)(1.0 / ((nbfm_freq_dev / kAmRate) * 2.0));
+    n_pilotcut = 63;                                                      // jj1bdx_48khz_nbfmaudio, NbfmDecode.cpp:39
+    H_b = n_pilotcut - 1;
+    max_au = max_if;
+    if ((rc = upload(d_pilotcut, k_jj1bdx_48khz_nbfmaudio, (size_t)n_pilotcut))) return rc;
+    if ((rc = d_base.alloc((size_t)S * (H_b + max_if)))) return rc;
+    if ((rc = d_audio.alloc((size_t)S * max_au))) return rc;
   } else {
     agc_init = 1.0f; agc_max = 1000000.0f; agc_rate = 0.0003f;          // AmDecode.cpp:71-77
     am_dcblock = highpass_iir(60 / kAmRate);                              // AmDecode.cpp:45
@@ -812,7 +824,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                            (int)N_if, d_gain.p, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            agc_init, agc_max, agc_rate, d_flags.p);
         hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64), 0, as, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
-                           d_state.p, d_flags.p, (int)(mode == FMR_MODE_FM));
+                           d_state.p, d_flags.p, (int)(mode == FMR_MODE_FM || mode == FMR_MODE_NBFM));
       }
       hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,
                          d_gain.p, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
@@ -972,7 +984,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       timed("pilotcut", [&] {
         if (n_pilotcut <= FMR_PCUT_MAXTAPS)
           hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, nch), dim3(320), 0, stream, d_a10.p, d_a11.p,
-                             a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
+                             a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au, 1.0);
         else
           hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch), dim3(128), 0, stream, d_a10.p, d_a11.p, a1_stride, H_pc,
                              bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
@@ -1016,6 +1028,28 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if (agc_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_agc, 0));
     if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
+  } else if (mode == FMR_MODE_NBFM) {
+    // NbfmDecoder (NbfmDecode.cpp:47-96): discriminator on the AGC'd IF, statistics, 63-tap audio FIR (same
+    // block-head path as the FM pilot cut: LowPassFilterFirAudio), -3 dB.  No resampling: audio block = IF block.
+    const long long base_stride = H_b + (long long)max_if;
+    timed("disc", [&] {
+      hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
+                         (long long)max_if, (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt, disc_nf, disc_bound,
+                         d_dec.p, (long long)max_if, d_base.p, base_stride, H_b, d_bb_mean_blk.p, d_bb_rms_blk.p,
+                         d_state.p);
+    });
+    timed("stats", [&] {
+      hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+                         d_bb_rms_blk.p, d_state.p, S, 1);
+    });
+    timed("nbfm_audio", [&] {
+      hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, 1), dim3(320), 0, stream, d_base.p, (double *)nullptr,
+                         base_stride, H_b, bt, d_pilotcut.p, n_pilotcut, d_aud, (double *)nullptr, (long long)astride,
+                         0.70794578438413791);          // std::pow(10.0, -3.0 / 20.0), NbfmDecode.cpp:91
+    });
+    add_halo(ifbuf, if_stride, H_if, N_if);
+    add_halo(d_base.p, base_stride, H_b, N_if);
+    if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)t_au_len[b];
   } else {
     timed("am_demod", [&] {
       hipLaunchKernelGGL(k_am_demod<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,

@@ -1341,7 +1341,7 @@ template <int BLOCK, int TILE>
 __global__ __launch_bounds__(BLOCK) void k_pilotcut2(
     const double *__restrict__ a0, const double *__restrict__ a1, long long a_stride, int a_halo,
     BlockTab bt, const double *__restrict__ coeff, int ntaps,
-    double *__restrict__ p0, double *__restrict__ p1, long long p_stride) {
+    double *__restrict__ p0, double *__restrict__ p1, long long p_stride, double out_gain) {
   __shared__ double cs[FMR_PCUT_MAXTAPS];
   __shared__ double xs[TILE + FMR_PCUT_MAXTAPS];
   const int b = blockIdx.x, s = blockIdx.y, ch = blockIdx.z;
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(BLOCK) void k_pilotcut2(
         for (int k = 0; k <= half_order; k++) acc += (xc[-k] + xc[-(order - k)]) * cs[k];
         if ((order % 2) == 0) acc += xc[-(order / 2)] * cs[order / 2];
       }
-      y[i] = acc;
+      y[i] = acc * out_gain;     // 1.0 for the FM pilot cut (exact); NbfmDecoder's -3 dB (Utility.h:307-312)
     }
   }
 }

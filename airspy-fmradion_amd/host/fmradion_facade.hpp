@@ -7,6 +7,7 @@
 //   IfResampler         include/IfResampler.h:28-44
 //   FmDecoder           include/FmDecode.h:35-164
 //   AmDecoder           include/AmDecode.h:33-103
+//   NbfmDecoder         include/NbfmDecode.h:30-95
 //   FilterParameters    include/FilterParameters.h:29-53
 //
 // Header-only; link with libfmradion_amd.so.  Every process() call is one
@@ -75,7 +76,12 @@ struct FilterParameters {
   static inline const IQSampleCoeff jj1bdx_am_48khz_medium = iq("jj1bdx_am_48khz_medium");
   static inline const IQSampleCoeff jj1bdx_am_48khz_default = iq("jj1bdx_am_48khz_default");
   static inline const IQSampleCoeff jj1bdx_am_48khz_wide = iq("jj1bdx_am_48khz_wide");
+  static inline const IQSampleCoeff jj1bdx_nbfm_48khz_default = iq("jj1bdx_nbfm_48khz_default");
+  static inline const IQSampleCoeff jj1bdx_nbfm_48khz_narrow = iq("jj1bdx_nbfm_48khz_narrow");
+  static inline const IQSampleCoeff jj1bdx_nbfm_48khz_medium = iq("jj1bdx_nbfm_48khz_medium");
+  static inline const IQSampleCoeff jj1bdx_nbfm_48khz_wide = iq("jj1bdx_nbfm_48khz_wide");
   static inline const SampleCoeff jj1bdx_48khz_fmaudio = audio("jj1bdx_48khz_fmaudio");
+  static inline const SampleCoeff jj1bdx_48khz_nbfmaudio = audio("jj1bdx_48khz_nbfmaudio");
 };
 
 // IfResampler::process(const IQSampleVector&, IQSampleVector&)  (IfResampler.h:35-38)
@@ -233,3 +239,49 @@ private:
   fmr_config m_cfg{};
   fmr_chain *m_chain = nullptr;
 };
+
+// NbfmDecoder (NbfmDecode.h:49-66)
+class NbfmDecoder {
+public:
+  static constexpr double sample_rate_pcm = 48000;
+  static constexpr double internal_rate_pcm = 48000;
+  static constexpr double freq_dev_normal = 8000;
+  static constexpr double freq_dev_wide = 17000;
+  NbfmDecoder(IQSampleCoeff &nbfmfilter_coeff, const double freq_dev, int device = 0) : m_freq_dev(freq_dev) {
+    m_cfg = fmr_config{};
+    m_cfg.device = device; m_cfg.n_streams = 1; m_cfg.mode = FMR_MODE_NBFM; m_cfg.input_rate = internal_rate_pcm;
+    m_cfg.filter_coeff = nbfmfilter_coeff.data(); m_cfg.n_filter_coeff = (int)nbfmfilter_coeff.size();
+    m_cfg.nbfm_freq_dev = freq_dev; m_cfg.max_block_len = 65536; m_cfg.max_blocks = 1;
+    m_chain = fmr_detail::make(m_cfg);
+  }
+  ~NbfmDecoder() { fmr_destroy(m_chain); }
+  NbfmDecoder(const NbfmDecoder &) = delete;
+  NbfmDecoder &operator=(const NbfmDecoder &) = delete;
+  void attach_front_end(double input_rate, bool fourth_down) {
+    fmr_destroy(m_chain);
+    m_cfg.input_rate = input_rate; m_cfg.enable_resampler = 1; m_cfg.enable_fourth_down = fourth_down;
+    m_chain = fmr_detail::make(m_cfg);
+  }
+  void process(const IQSampleVector &samples_in, SampleVector &audio) {
+    audio.resize(samples_in.size() + 64);
+    size_t n = 0;
+    fmr_detail::check(fmr_process(m_chain, reinterpret_cast<const float *>(samples_in.data()), samples_in.size(),
+                                  audio.data(), audio.size(), &n),
+                      "fmr_process");
+    audio.resize(n);
+  }
+  float get_tuning_offset() { return (float)(status().baseband_mean * m_freq_dev); }
+  float get_baseband_level() { return status().baseband_level; }
+  float get_if_rms() { return status().if_rms; }
+
+private:
+  fmr_status status() {
+    fmr_status st{};
+    fmr_detail::check(fmr_get_status(m_chain, 0, &st), "fmr_get_status");
+    return st;
+  }
+  const double m_freq_dev;
+  fmr_config m_cfg{};
+  fmr_chain *m_chain = nullptr;
+};
+

@@ -57,7 +57,7 @@ typedef struct {
 typedef struct {
   int device;                 /* HIP device ordinal */
   int n_streams;              /* >= 1 independent IQ streams (batch) */
-  int mode;                   /* FMR_MODE_FM | FMR_MODE_AM | FMR_MODE_DSB */
+  int mode;                   /* FMR_MODE_FM | FMR_MODE_NBFM | FMR_MODE_AM | FMR_MODE_DSB */
   double input_rate;          /* sample rate of the IQ handed to process */
   /* Front end.  0 = the decoder is fed at its own rate (384 kHz FM / 48 kHz
    * AM) and no IfResampler runs (main.cpp:778 enable_downsampling=false). */
@@ -74,6 +74,8 @@ typedef struct {
   /* capacity */
   size_t max_block_len;       /* largest input block (samples) per call */
   int max_blocks;             /* largest number of blocks per call */
+  /* NbfmDecoder ctor argument (include/NbfmDecode.h:49): full-scale deviation in Hz, 0 = freq_dev_normal (8000) */
+  double nbfm_freq_dev;
 } fmr_config;
 
 /* Per-stream status after the most recent call (getters of FmDecode.h:77-105 /

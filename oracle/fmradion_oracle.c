@@ -1008,3 +1008,63 @@ double ora_am_baseband_level(const ora_am *am) { return am->baseband_level; }
 float ora_am_af_agc_gain(const ora_am *am) { return (float)am->afagc.current_gain; }
 float ora_am_if_agc_gain(const ora_am *am) { return am->ifagc.current_gain; }
 float ora_am_if_rms(const ora_am *am) { return am->if_rms; }
+
+/* ---------------------------------------------------------------------------
+ * NbfmDecoder (sfmbase/NbfmDecode.cpp:24-96; include/NbfmDecode.h:30-95).
+ * audiocoeff = the jj1bdx_48khz_nbfmaudio table (FilterParameters.cpp), passed in as data.
+ * ------------------------------------------------------------------------- */
+struct ora_nbfm {
+  double freq_dev;
+  float baseband_mean, baseband_level, if_rms;
+  ora_firiq *nbfmfilter;
+  ora_disc disc;
+  ora_firaudio *audiofilter;
+  ora_ifagc ifagc;
+  int cap;
+  float *b2, *b3, *dec;
+  double *base;
+};
+ora_nbfm *ora_nbfm_create(const float *coeff, int n_coeff, double freq_dev, const double *audiocoeff, int n_audio) {
+  ora_nbfm *nb = (ora_nbfm *)calloc(1, sizeof(*nb));
+  nb->freq_dev = freq_dev;
+  nb->nbfmfilter = ora_firiq_create(coeff, n_coeff, 1);      /* NbfmDecode.cpp:31 */
+  ora_disc_init(&nb->disc, freq_dev / 48000.0);              /* :35 */
+  nb->audiofilter = ora_firaudio_create(audiocoeff, n_audio); /* :39 */
+  ora_ifagc_init(&nb->ifagc, 1.0f, 100000.0f, 0.0001f);      /* :43 */
+  return nb;
+}
+void ora_nbfm_destroy(ora_nbfm *nb) {
+  if (!nb) return;
+  ora_firiq_destroy(nb->nbfmfilter);
+  ora_firaudio_destroy(nb->audiofilter);
+  free(nb->b2); free(nb->b3); free(nb->dec); free(nb->base); free(nb);
+}
+int ora_nbfm_process(ora_nbfm *nb, const float *iq, int n, double *audio, int cap) { /* :47-96 */
+  if (n > nb->cap) {
+    nb->cap = n;
+    nb->b2 = (float *)realloc(nb->b2, sizeof(float) * 2 * n);
+    nb->b3 = (float *)realloc(nb->b3, sizeof(float) * 2 * n);
+    nb->dec = (float *)realloc(nb->dec, sizeof(float) * n);
+    nb->base = (double *)realloc(nb->base, sizeof(double) * n);
+  }
+  const int n2 = ora_firiq_process(nb->nbfmfilter, iq, n, nb->b2);   /* :51 */
+  nb->if_rms = ora_rms_level(nb->b2, n2);                            /* :54 */
+  ora_ifagc_process(&nb->ifagc, nb->b2, n2, nb->b3);                 /* :57 */
+  ora_disc_process(&nb->disc, nb->b3, n2, nb->dec);                  /* :60 */
+  if (n2 == 0) return 0;                                             /* :64-67 */
+  if (n2 > cap) return -1;
+  for (int i = 0; i < n2; i++) nb->base[i] = (double)nb->dec[i];     /* :70-72 */
+  float bmean, brms;
+  ora_mean_rms(nb->dec, n2, &bmean, &brms);                          /* :82-85 */
+  nb->baseband_mean = (float)(0.95 * nb->baseband_mean + 0.05 * bmean);
+  nb->baseband_level = (float)(0.95 * nb->baseband_level + 0.05 * brms);
+  const int n3 = ora_firaudio_process(nb->audiofilter, nb->base, n2, audio);   /* :88 */
+  const double audio_gain = pow(10.0, (-3.0 / 20.0));                /* :91 */
+  for (int i = 0; i < n3; i++) audio[i] = audio[i] * audio_gain;     /* Utility.h:307-312 */
+  return n3;
+}
+float ora_nbfm_tuning_offset(const ora_nbfm *nb) { return (float)(nb->baseband_mean * nb->freq_dev); }  /* NbfmDecode.h:62 */
+float ora_nbfm_baseband_level(const ora_nbfm *nb) { return nb->baseband_level; }
+float ora_nbfm_if_rms(const ora_nbfm *nb) { return nb->if_rms; }
+float ora_nbfm_if_agc_gain(const ora_nbfm *nb) { return nb->ifagc.current_gain; }
+

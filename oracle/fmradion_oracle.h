@@ -177,6 +177,17 @@ float ora_am_af_agc_gain(const ora_am *am);
 float ora_am_if_agc_gain(const ora_am *am);
 float ora_am_if_rms(const ora_am *am);
 
+/* NbfmDecoder (sfmbase/NbfmDecode.cpp:24-96).  audiocoeff = the jj1bdx_48khz_nbfmaudio table. */
+typedef struct ora_nbfm ora_nbfm;
+ora_nbfm *ora_nbfm_create(const float *nbfmfilter_coeff, int n_coeff, double freq_dev, const double *audiocoeff,
+                          int n_audio);
+void ora_nbfm_destroy(ora_nbfm *nb);
+int ora_nbfm_process(ora_nbfm *nb, const float *iq, int n, double *audio, int cap);
+float ora_nbfm_tuning_offset(const ora_nbfm *nb);
+float ora_nbfm_baseband_level(const ora_nbfm *nb);
+float ora_nbfm_if_rms(const ora_nbfm *nb);
+float ora_nbfm_if_agc_gain(const ora_nbfm *nb);
+
 #ifdef __cplusplus
 }
 #endif

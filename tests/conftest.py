@@ -36,3 +36,14 @@ def fm_medium():
 @pytest.fixture(scope="session")
 def am_narrow():
     return load_filter("jj1bdx_am_48khz_narrow")
+
+
+@pytest.fixture(scope="session")
+def nbfm_default():
+    return load_filter("jj1bdx_nbfm_48khz_default")
+
+
+@pytest.fixture(scope="session")
+def nbfm_audio():
+    return load_filter("jj1bdx_48khz_nbfmaudio")
+

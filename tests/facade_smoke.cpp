@@ -13,6 +13,12 @@ int main() {
     SampleVector audio;
     fm.process(blk, audio);
     std::printf("gpu path: %zu audio samples, if_rms %.4f\n", audio.size(), fm.get_if_rms());
+    IQSampleCoeff nbc = FilterParameters::jj1bdx_nbfm_48khz_default;
+    NbfmDecoder nbfm(nbc, NbfmDecoder::freq_dev_normal);
+    SampleVector a2;
+    nbfm.process(blk, a2);
+    std::printf("nbfm: %zu audio samples, if_rms %.4f\n", a2.size(), nbfm.get_if_rms());
+    if (a2.size() != blk.size()) return 3;
     return 0;
   } catch (const std::exception &e) {
     std::printf("no gpu: %s\n", e.what());

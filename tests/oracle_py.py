@@ -91,6 +91,13 @@ def lib():
         "ora_am_af_agc_gain": (C.c_float, [vp]),
         "ora_am_if_agc_gain": (C.c_float, [vp]),
         "ora_am_if_rms": (C.c_float, [vp]),
+        "ora_nbfm_create": (vp, [c_float_p, C.c_int, C.c_double, c_double_p, C.c_int]),
+        "ora_nbfm_destroy": (None, [vp]),
+        "ora_nbfm_process": (C.c_int, [vp, c_float_p, C.c_int, c_double_p, C.c_int]),
+        "ora_nbfm_tuning_offset": (C.c_float, [vp]),
+        "ora_nbfm_baseband_level": (C.c_float, [vp]),
+        "ora_nbfm_if_rms": (C.c_float, [vp]),
+        "ora_nbfm_if_agc_gain": (C.c_float, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -483,3 +490,40 @@ class AmDecoder:
 
     def get_if_rms(self):
         return lib().ora_am_if_rms(self.h)
+
+
+class NbfmDecoder:
+    """Mirror of NbfmDecoder (include/NbfmDecode.h:49-66)."""
+
+    freq_dev_normal = 8000.0
+    freq_dev_wide = 17000.0
+
+    def __init__(self, nbfmfilter_coeff, freq_dev, audio_coeff):
+        c = np.ascontiguousarray(nbfmfilter_coeff, dtype=np.float32)
+        a = np.ascontiguousarray(audio_coeff, dtype=np.float64)
+        self.h = lib().ora_nbfm_create(_fp(c), len(c), float(freq_dev), _dp(a), len(a))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ora_nbfm_destroy(self.h)
+            self.h = None
+
+    def process(self, iq):
+        iq = as_iq32(iq)
+        out = np.empty(len(iq) + 16, dtype=np.float64)
+        n = lib().ora_nbfm_process(self.h, _fp(iq), len(iq), _dp(out), len(out))
+        assert n >= 0
+        return out[:n].copy()
+
+    def get_tuning_offset(self):
+        return lib().ora_nbfm_tuning_offset(self.h)
+
+    def get_baseband_level(self):
+        return lib().ora_nbfm_baseband_level(self.h)
+
+    def get_if_rms(self):
+        return lib().ora_nbfm_if_rms(self.h)
+
+    def get_if_agc_current_gain(self):
+        return lib().ora_nbfm_if_agc_gain(self.h)
+

@@ -52,6 +52,16 @@ def am_iq(n, fs, offset=37.0, tone=1000.0, depth=0.5, level=0.1, sigma=1e-4, see
     return x.astype(np.complex64)
 
 
+def nbfm_iq(n, fs, tone=1000.0, dev=3000.0, offset=120.0, level=0.2, sigma=1e-4, seed=5):
+    """S-NBFM: voice-band tone at +-dev Hz deviation, carrier offset +offset Hz."""
+    t = np.arange(n, dtype=np.float64) / fs
+    phase = 2 * np.pi * offset * t - (dev / tone) * np.cos(2 * np.pi * tone * t)
+    x = level * np.exp(1j * phase)
+    if sigma > 0:
+        x = x + _noise(n, sigma, seed)
+    return x.astype(np.complex64)
+
+
 def two_ray(x, delay, gain=0.35, angle=1.1, renorm=True):
     """S-MP: x[n] + gain e^{j angle} x[n-delay], optionally renormalised to the input RMS."""
     x = np.asarray(x, dtype=np.complex128)

@@ -282,6 +282,61 @@ def test_am_config3_full_chain(am_narrow):
     ch.close()
 
 
+# ----------------------------------------------------------------- NbfmDecoder
+@pytest.mark.parametrize("dev", [8000.0, 17000.0])
+def test_nbfm_decoder_48k(dev, nbfm_default, nbfm_audio):
+    """NbfmDecoder at its own rate (48 kHz), 2048-sample blocks in batches of 8 plus ragged single blocks."""
+    x = siggen.nbfm_iq(200 * 2048, 48e3, dev=3000.0 if dev == 8000.0 else 9000.0)
+    ch = fmr.Chain(mode=fmr.MODE_NBFM, input_rate=48e3, enable_resampler=False, filter_coeff=nbfm_default,
+                   nbfm_freq_dev=dev, max_block_len=2048, max_blocks=8)
+    nb = ora.NbfmDecoder(nbfm_default, dev, nbfm_audio)
+    lens = [2048] * 8 * 20 + [1000, 1, 47, 2048, 999] * 8
+    got, ref, pos = [], [], 0
+    for i in range(0, len(lens), 8):
+        ll = lens[i:i + 8]
+        seg = x[pos:pos + sum(ll)]
+        pos += sum(ll)
+        a, alen = ch.process_blocks(seg[None, :], ll)
+        got.append(a[0])
+        o = 0
+        for n in ll:
+            ref.append(nb.process(seg[o:o + n]))
+            o += n
+        assert list(alen) == [len(r) for r in ref[-len(ll):]]
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    assert len(got) == len(ref) == pos
+    err = rms(got - ref)
+    st = ch.status()
+    _report(f"nbfm_48k_dev{int(dev)}", audio_rms_err=err, audio_rms=rms(ref), n=len(ref), agc_iters=st.agc_iterations,
+            agc_fallback=st.agc_fallback, if_rms=st.if_rms, ref_if_rms=nb.get_if_rms())
+    assert err < 1e-6
+    assert st.agc_fallback == 0
+    assert st.if_rms == pytest.approx(nb.get_if_rms(), rel=1e-5)
+    assert st.baseband_level == pytest.approx(nb.get_baseband_level(), rel=1e-4, abs=1e-7)
+    assert st.baseband_mean * dev == pytest.approx(nb.get_tuning_offset(), rel=1e-3, abs=1e-2)
+    assert st.if_agc_gain == pytest.approx(nb.get_if_agc_current_gain(), rel=1e-4)
+    ch.close()
+
+
+def test_nbfm_full_chain_from_384k(nbfm_default, nbfm_audio):
+    """384 kS/s IQ -> IfResampler(48 k) -> NbfmDecoder (the `-m nbfm` chain of main.cpp:718-719,828-829,959-962)."""
+    x = siggen.nbfm_iq(300 * 2048, 384e3)
+    ch = fmr.Chain(mode=fmr.MODE_NBFM, input_rate=384e3, enable_resampler=True, filter_coeff=nbfm_default,
+                   max_block_len=2048, max_blocks=10)
+    r, nb = ora.IfResampler(384e3, 48e3), ora.NbfmDecoder(nbfm_default, 8000.0, nbfm_audio)
+    got, ref = [], []
+    for i in range(0, 300, 10):
+        seg = x[i * 2048:(i + 10) * 2048]
+        got.append(ch.process_blocks(seg[None, :], [2048] * 10)[0][0])
+        ref += [nb.process(r.process(b)) for b in siggen.blocks(seg, 2048)]
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    assert len(got) == len(ref)
+    err = rms(got - ref)
+    _report("nbfm_from_384k", audio_rms_err=err, audio_rms=rms(ref))
+    assert err < 1e-5
+    ch.close()
+
+
 # ------------------------------------------------------- full chains from raw IQ
 def test_fm_mono_config1(pilotcut):
     """Config 1: 1 MS/s mono FM, FileSource block length 2048."""

@@ -89,3 +89,20 @@ def test_block_partition_changes_result_only_at_head_quirk_level(pilotcut):
     n = min(len(outs[0]), len(outs[1]))
     d = outs[0][:n] - outs[1][:n]
     assert 0 < np.max(np.abs(d)) < 1e-5
+
+
+def test_nbfm_oracle_tone(nbfm_default, nbfm_audio):
+    """NbfmDecoder restatement: a 1 kHz tone at +-3 kHz deviation comes out at (3000/8000) * 10^(-3/20), the
+    carrier offset shows up as the tuning offset, and the first block keeps the block-head quirk of the audio FIR."""
+    fs, n = 48e3, 60 * 2048
+    x = siggen.nbfm_iq(n, fs, tone=1000.0, dev=3000.0, offset=120.0, sigma=0.0)
+    nb = ora.NbfmDecoder(nbfm_default, 8000.0, nbfm_audio)
+    audio = np.concatenate([nb.process(b) for b in siggen.blocks(x, 2048)])
+    assert len(audio) == n
+    tail = audio[-8192:] - np.mean(audio[-8192:])
+    amp = np.sqrt(2) * np.sqrt(np.mean(tail ** 2))
+    assert amp == pytest.approx((3000.0 / 8000.0) * 10 ** (-3 / 20), rel=2e-3)
+    # 0.95/0.05 EMA over 60 blocks (NbfmDecode.cpp:84)
+    assert nb.get_tuning_offset() == pytest.approx(120.0 * (1 - 0.95 ** 60), rel=0.01)
+    assert nb.get_if_rms() == pytest.approx(0.2, rel=1e-3)
+
