@@ -20,6 +20,8 @@ SRC = os.path.join(_DIR, "csrc", "fmradion_amd.hip")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 MODE_NONE, MODE_FM, MODE_NBFM, MODE_AM, MODE_DSB = -1, 0, 1, 2, 3
+IQ_CF32, IQ_S16, IQ_U8, IQ_S8 = 0, 1, 2, 3
+_IQ_DTYPE = {0: np.complex64, 1: np.int16, 2: np.uint8, 3: np.int8}
 OK = 0
 
 EXPORTS = [
@@ -41,6 +43,7 @@ class Config(C.Structure):
         ("filter_coeff", C.POINTER(C.c_float)), ("n_filter_coeff", C.c_int), ("stereo", C.c_int),
         ("deemphasis_us", C.c_double), ("pilot_shift", C.c_int), ("multipath_stages", C.c_uint),
         ("max_block_len", C.c_size_t), ("max_blocks", C.c_int), ("nbfm_freq_dev", C.c_double),
+        ("input_format", C.c_int),
     ]
 
 
@@ -141,7 +144,7 @@ class Chain:
 
     def __init__(self, mode=MODE_FM, input_rate=384000.0, enable_resampler=False, fourth_down=False,
                  fmfilter_enable=False, filter_coeff=None, stereo=True, deemphasis_us=50.0, pilot_shift=False,
-                 multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0, nbfm_freq_dev=0.0):
+                 multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0, nbfm_freq_dev=0.0, input_format=0):
         coeff = np.ascontiguousarray(DELAY_3TAPS if filter_coeff is None else filter_coeff, dtype=np.float32)
         self._coeff = coeff
         cfg = Config()
@@ -154,6 +157,8 @@ class Chain:
         cfg.multipath_stages = int(multipath_stages)
         cfg.max_block_len, cfg.max_blocks = int(max_block_len), int(max_blocks)
         cfg.nbfm_freq_dev = float(nbfm_freq_dev)
+        cfg.input_format = int(input_format)
+        self.input_format = int(input_format)
         self.n_streams, self.mode, self.stereo = n_streams, mode, bool(stereo) and mode == MODE_FM
         self.h = C.c_void_p()
         rc = lib().fmr_create(C.byref(cfg), C.byref(self.h))
@@ -189,7 +194,11 @@ class Chain:
 
     def process_blocks(self, iq, block_len):
         """iq: (n_streams, N) complex64; block_len: consecutive block lengths. Returns (audio[S][total], audio_len)."""
-        iq = np.ascontiguousarray(np.atleast_2d(iq), dtype=np.complex64)
+        if self.input_format == IQ_CF32:
+            iq = np.ascontiguousarray(np.atleast_2d(iq), dtype=np.complex64)
+        else:   # raw formats: (n_streams, N, 2) interleaved I,Q of the format's integer type
+            iq = np.ascontiguousarray(iq, dtype=_IQ_DTYPE[self.input_format])
+            assert iq.ndim == 3 and iq.shape[2] == 2
         assert iq.shape[0] == self.n_streams
         bl = np.ascontiguousarray(block_len, dtype=np.uint32)
         assert int(bl.sum()) <= iq.shape[1]

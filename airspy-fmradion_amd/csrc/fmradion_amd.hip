@@ -121,6 +121,7 @@ struct fmr_chain {
   DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
   int poly2_tile = 0;                  // staged mid samples per tile, 0 = v2 kernel not applicable
   double nbfm_freq_dev = 8000.0;
+  int in_fmt = 0, in_bps = 8;          // source sample format (fmr_config.input_format) and its bytes per IQ sample
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
   DevBuf<float> d_afrag;               // v4: constant A fragments
@@ -270,6 +271,14 @@ int fmr_chain::init(const fmr_config *c) {
   has_rs = c->enable_resampler != 0;
   max_blocks = c->max_blocks;
   max_in = c->max_block_len * (size_t)c->max_blocks;
+  max_in = (max_in + 15) & ~(size_t)15;          // row pitch keeps every stream 16-byte aligned in every format
+  in_fmt = c->input_format;
+  if (in_fmt < 0 || in_fmt > 3) { set_err("input_format %d unknown", in_fmt); return FMR_ERR_BAD_ARG; }
+  in_bps = in_fmt == 0 ? 8 : in_fmt == 1 ? 4 : 2;
+  if (in_fmt != 0 && !c->enable_resampler) {
+    set_err("input_format != cf32 is converted inside the front-end kernel: enable_resampler must be set");
+    return FMR_ERR_UNSUPPORTED;
+  }
   if (has_rs) {
     if (!rs.design(c->input_rate, dec_rate, kIfAtten)) {
       set_err("resampling ratio %.9g -> %.9g is outside the supported design range", c->input_rate, dec_rate);
@@ -561,6 +570,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if (block_len[b] > cfg.max_block_len) { set_err("block %d longer than max_block_len", b); return FMR_ERR_CAPACITY; }
     N_in += block_len[b];
   }
+  if (in_fmt != 0 && ((stride * (size_t)in_bps) % 16 != 0 || ((uintptr_t)d_iq % 16) != 0)) {
+    set_err("raw-format input: the buffer and the stream stride must be 16-byte aligned");
+    return FMR_ERR_BAD_ARG;
+  }
   HIPCHK(hipSetDevice(cfg.device));
   const auto hp0 = std::chrono::steady_clock::now();
   auto hp1 = hp0, hp2 = hp0;
@@ -634,15 +647,23 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         const unsigned magic = (unsigned)((1u << 24) / (unsigned)rs.D + 1);
         const dim3 grid2((count_mid + T2 - 1) / T2, S);
         timed_on(fes, "ifr_decim", [&] {
-          if (cfg.enable_fourth_down)
-            hipLaunchKernelGGL((k_ifr_decim2<BL2, 16, 0, true>), grid2, dim3(BL2), lds2, fes, d_iq, (long long)stride,
-                               N_in, d_in_halo.p, H_in, d_hpA.p, rs.D, rs.ca(), top0 - rs.ca(), count_mid, d_mid.p,
-                               (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), 1, s_pad, magic);
-          else
-            hipLaunchKernelGGL((k_ifr_decim2<BL2, 16, 0, false>), grid2, dim3(BL2), lds2, fes, d_iq, (long long)stride,
-                               N_in, d_in_halo.p, H_in, d_hpA.p, rs.D, rs.ca(), top0 - rs.ca(), count_mid, d_mid.p,
-                               (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), 0, s_pad, magic);
+          auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid2, dim3(BL2), lds2, fes, d_iq, (long long)stride, N_in, d_in_halo.p, H_in,
+                               d_hpA.p, rs.D, rs.ca(), top0 - rs.ca(), count_mid, d_mid.p,
+                               (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u),
+                               (int)cfg.enable_fourth_down, s_pad, magic);
+          };
+          const bool f4 = cfg.enable_fourth_down != 0;
+          switch (in_fmt) {
+          case 1: f4 ? go(k_ifr_decim2<BL2, 16, 0, true, 1, 1>) : go(k_ifr_decim2<BL2, 16, 0, false, 1, 1>); break;
+          case 2: f4 ? go(k_ifr_decim2<BL2, 16, 0, true, 1, 2>) : go(k_ifr_decim2<BL2, 16, 0, false, 1, 2>); break;
+          case 3: f4 ? go(k_ifr_decim2<BL2, 16, 0, true, 1, 3>) : go(k_ifr_decim2<BL2, 16, 0, false, 1, 3>); break;
+          default: f4 ? go(k_ifr_decim2<BL2, 16, 0, true>) : go(k_ifr_decim2<BL2, 16, 0, false>); break;
+          }
         });
+      } else if (in_fmt != 0) {
+        set_err("input_format != cf32 needs the v2 front-end kernel (decimation ratio out of its range)");
+        return FMR_ERR_UNSUPPORTED;
       } else {
         timed_on(fes, "ifr_decim", [&] {
           if (256 * per_out + tail <= 60000) launch_decim(std::integral_constant<int, 256>{});
@@ -684,8 +705,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     }
     if (N_in > 0) {
       timed_on(fes, "in_halo", [&] {
-        hipLaunchKernelGGL(k_update_in_halo<256>, dim3(1, S), dim3(256), 0, fes, d_in_halo.p, H_in, d_iq,
-                           (long long)stride, N_in);
+        switch (in_fmt) {
+        case 1: hipLaunchKernelGGL((k_update_in_halo<256, 1>), dim3(1, S), dim3(256), 0, fes, d_in_halo.p, H_in, d_iq, (long long)stride, N_in); break;
+        case 2: hipLaunchKernelGGL((k_update_in_halo<256, 2>), dim3(1, S), dim3(256), 0, fes, d_in_halo.p, H_in, d_iq, (long long)stride, N_in); break;
+        case 3: hipLaunchKernelGGL((k_update_in_halo<256, 3>), dim3(1, S), dim3(256), 0, fes, d_in_halo.p, H_in, d_iq, (long long)stride, N_in); break;
+        default: hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, fes, d_in_halo.p, H_in, d_iq, (long long)stride, N_in); break;
+        }
       });
     }
   } else {
@@ -1133,8 +1158,8 @@ int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, cons
   if (N_in > c->max_in) { set_err("input longer than max_block_len*max_blocks"); return FMR_ERR_CAPACITY; }
   HIPCHK(hipSetDevice(c->cfg.device));
   if (N_in)
-    HIPCHK(hipMemcpy2DAsync(c->d_in.p, sizeof(float2) * c->max_in, iq, sizeof(float2) * stream_stride,
-                            sizeof(float2) * N_in, c->S, hipMemcpyHostToDevice, c->pipelined ? c->fe : c->stream));
+    HIPCHK(hipMemcpy2DAsync(c->d_in.p, (size_t)c->in_bps * c->max_in, iq, (size_t)c->in_bps * stream_stride,
+                            (size_t)c->in_bps * N_in, c->S, hipMemcpyHostToDevice, c->pipelined ? c->fe : c->stream));
   const size_t dstride = c->stereo ? 2 * c->max_au : c->max_au;
   std::vector<uint32_t> alen(n_blocks, 0);
   const int rc = c->run(c->d_in.p, c->max_in, block_len, n_blocks, c->d_audio.p, dstride, alen.data());
@@ -1169,7 +1194,7 @@ int fmr_resample(fmr_chain *c, const float *iq, size_t n, float *out_iq, size_t 
   if (n == 0) return FMR_OK;
   if (n > c->max_in) return FMR_ERR_CAPACITY;
   HIPCHK(hipSetDevice(c->cfg.device));
-  HIPCHK(hipMemcpyAsync(c->d_in.p, iq, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_in.p, iq, (size_t)c->in_bps * n, hipMemcpyHostToDevice, c->stream));
   uint32_t bl = (uint32_t)n;
   const int rc = c->run(c->d_in.p, c->max_in, &bl, 1, nullptr, 0, nullptr);
   if (rc) return rc;

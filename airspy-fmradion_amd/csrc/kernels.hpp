@@ -180,6 +180,40 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_decim(
 }
 
 // ---------------------------------------------------------------------------
+// Source sample formats the front end reads directly (fused ingest: the conversion the reference does on the
+// host -- RtlSdrSource.cpp:359-365 for offset-binary u8, libsndfile's sf_read_float for the FileSource formats
+// of FileSource.cpp:120-128 -- happens while the tile is staged, so HBM carries 4 or 2 bytes per IQ sample
+// instead of 8).  All scalings are powers of two: exact in float.
+//   0 cf32 (I, Q float)   1 s16 LE / 32768   2 u8 (b - 128) / 128   3 s8 / 128
+// ---------------------------------------------------------------------------
+template <int FMT> struct IqFmt;
+template <> struct IqFmt<0> { static constexpr int BPS = 8, G = 2; };
+template <> struct IqFmt<1> { static constexpr int BPS = 4, G = 4; };
+template <> struct IqFmt<2> { static constexpr int BPS = 2, G = 8; };
+template <> struct IqFmt<3> { static constexpr int BPS = 2, G = 8; };
+template <int FMT>
+__device__ __forceinline__ float2 iq_load1(const void *base, long long n) {      // sample n of a raw stream
+  if (FMT == 0) return reinterpret_cast<const float2 *>(base)[n];
+  if (FMT == 1) { const short2 v = reinterpret_cast<const short2 *>(base)[n]; return make_float2(v.x * (1.0f / 32768.0f), v.y * (1.0f / 32768.0f)); }
+  if (FMT == 2) { const uchar2 v = reinterpret_cast<const uchar2 *>(base)[n]; return make_float2(((int)v.x - 128) * (1.0f / 128.0f), ((int)v.y - 128) * (1.0f / 128.0f)); }
+  const char2 v = reinterpret_cast<const char2 *>(base)[n];
+  return make_float2(v.x * (1.0f / 128.0f), v.y * (1.0f / 128.0f));
+}
+// sample j (0 .. G-1) of one 16-byte group
+template <int FMT>
+__device__ __forceinline__ float2 iq_unpack(const uint4 &w, int j) {
+  const unsigned wd[4] = {w.x, w.y, w.z, w.w};
+  if (FMT == 0) return make_float2(__uint_as_float(wd[2 * j]), __uint_as_float(wd[2 * j + 1]));
+  if (FMT == 1) {
+    const unsigned u = wd[j];
+    return make_float2((float)(short)(u & 0xffffu) * (1.0f / 32768.0f), (float)(short)(u >> 16) * (1.0f / 32768.0f));
+  }
+  const unsigned u = wd[j >> 1] >> ((j & 1) * 16);
+  if (FMT == 2) return make_float2(((int)(u & 0xffu) - 128) * (1.0f / 128.0f), ((int)((u >> 8) & 0xffu) - 128) * (1.0f / 128.0f));
+  return make_float2((float)(signed char)(u & 0xffu) * (1.0f / 128.0f), (float)(signed char)((u >> 8) & 0xffu) * (1.0f / 128.0f));
+}
+
+// ---------------------------------------------------------------------------
 // K_A v2  ifr_decim2 : the HBM-bound front-end kernel, LDS traffic cut 4x.
 //   y[m] = sum_p sum_q hp[p][q] * X_p[m - q],   X_p[i] = x[D i + ca - p]   (polyphase form)
 // * the input tile is staged with coalesced 16-byte loads (all issued before the first
@@ -191,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_decim(
 // Q = taps per phase (even, zero padded), hp = [D][Q] on the host side.
 // ABL: ablation switch for tools/bench_decim.hip (0 = product, 1 = no compute, 2 = no loads).
 // ---------------------------------------------------------------------------
-template <int BLOCK, int Q, int ABL = 0, bool FOURTH = false, int CV = 1>
+template <int BLOCK, int Q, int ABL = 0, bool FOURTH = false, int CV = 1, int FMT = 0>
 __global__ __launch_bounds__(BLOCK) void k_ifr_decim2(
     const float2 *__restrict__ iq, long long iq_stride, long long n_valid,
     const float2 *__restrict__ halo, int H, const float *__restrict__ hp, int D, int ca,
@@ -206,11 +240,12 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_decim2(
   // X_p[i], i = i0 .. i0 + T + Q - 1, i0 = m0 - Q;  input index n = n0 + D*i + ca - p
   const long long n_base = n0 + (long long)D * (m0 - Q) + ca - (D - 1);   // smallest input index of the tile
   const int span = D * (T + Q);
-  const float2 *xs = iq + (long long)s * iq_stride;
+  constexpr int G = IqFmt<FMT>::G;                   // samples per 16-byte group
+  const char *xs = reinterpret_cast<const char *>(iq) + (long long)s * iq_stride * IqFmt<FMT>::BPS;
   const float2 *hs = halo + (long long)s * H;
-  const int par = (int)(n_base & 1);                 // make the pair address 16-byte aligned
+  const int par = (int)(((n_base % G) + G) % G);     // make the group address 16-byte aligned
   const long long n_al = n_base - par;
-  const int npairs = (span + par + 1) >> 1;
+  const int npairs = (span + par + G - 1) / G;       // 16-byte groups of the tile
   const unsigned dummy = (unsigned)(D * S_pad);      // one spare LDS slot swallows out-of-tile elements
   // branch-free scatter of one staged sample: element index ee -> (phase row p, column u)
   auto put = [&](int ee, float2 v, long long n) {
@@ -222,35 +257,35 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_decim2(
   };
   // ---- stage.  Interior tiles issue ALL their 16-byte loads before the first LDS write
   // (one HBM latency per tile); edge tiles (halo / end of the input) go element-wise.
-  if (n_al >= 0 && n_al + 2 * (long long)npairs <= n_valid) {
-    const float4 *src = reinterpret_cast<const float4 *>(xs + n_al);
-    const int full = npairs / BLOCK;                 // trips in which every lane has a pair
-    constexpr int MAXP = 16;
-    float4 w[MAXP];
+  if (n_al >= 0 && n_al + (long long)G * npairs <= n_valid) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(xs + n_al * IqFmt<FMT>::BPS);
+    const int full = npairs / BLOCK;                 // trips in which every lane has a group
+    constexpr int MAXP = 32 / G;                     // 16 groups of cf32 pairs, 8 of s16, 4 of 8-bit samples
+    uint4 w[MAXP];
 #pragma unroll
     for (int t = 0; t < MAXP; t++) {
       const int g = tid + t * BLOCK;
-      if (ABL == 2) w[t] = make_float4(1.f, 2.f, 3.f, 4.f);
+      if (ABL == 2) w[t] = make_uint4(0x3f800000u, 0x40000000u, 0x40400000u, 0x40800000u);
       else if (t < full || g < npairs) w[t] = src[g];
     }
 #pragma unroll
     for (int t = 0; t < MAXP; t++) {
       const int g = tid + t * BLOCK;
       if (t < full || g < npairs) {
-        const int e0 = 2 * g - par;
-        put(e0, make_float2(w[t].x, w[t].y), n_al + 2 * (long long)g);
-        put(e0 + 1, make_float2(w[t].z, w[t].w), n_al + 2 * (long long)g + 1);
+        const int e0 = G * g - par;
+#pragma unroll
+        for (int j = 0; j < G; j++) put(e0 + j, iq_unpack<FMT>(w[t], j), n_al + (long long)G * g + j);
       }
     }
   } else {
     for (int g = tid; g < npairs; g += BLOCK) {
-      const long long n = n_al + 2 * (long long)g;
-      float2 v0 = make_float2(0.f, 0.f), v1 = v0;
-      if (n < 0) { if (n >= -(long long)H) v0 = hs[H + n]; } else if (n < n_valid) v0 = xs[n];
-      const long long n1 = n + 1;
-      if (n1 < 0) { if (n1 >= -(long long)H) v1 = hs[H + n1]; } else if (n1 < n_valid) v1 = xs[n1];
-      put(2 * g - par, v0, n);
-      put(2 * g - par + 1, v1, n1);
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const long long n = n_al + (long long)G * g + j;
+        float2 v = make_float2(0.f, 0.f);
+        if (n < 0) { if (n >= -(long long)H) v = hs[H + n]; } else if (n < n_valid) v = iq_load1<FMT>(xs, n);
+        put(G * g - par + j, v, n);
+      }
     }
   }
   __syncthreads();
@@ -652,17 +687,17 @@ __global__ __launch_bounds__(BLOCK) void k_shift_halo(HaloTable tab) {
 
 // K_A's input halo lives in its own buffer because the caller owns the input:
 // newhalo[i] = concat(halo, iq[0..N))[i + N].
-template <int BLOCK>
+template <int BLOCK, int FMT = 0>
 __global__ __launch_bounds__(BLOCK) void k_update_in_halo(
     float2 *__restrict__ halo, int H, const float2 *__restrict__ iq, long long iq_stride, long long N) {
   float2 *hs = halo + (long long)blockIdx.y * H;
-  const float2 *xs = iq + (long long)blockIdx.y * iq_stride;
+  const char *xs = reinterpret_cast<const char *>(iq) + (long long)blockIdx.y * iq_stride * IqFmt<FMT>::BPS;
   for (int c = 0; c < H; c += BLOCK) {
     const int i = c + threadIdx.x;
     float2 v = make_float2(0.f, 0.f);
     if (i < H) {
       const long long j = (long long)i + N;  // index into concat(halo, iq)
-      v = (j < H) ? hs[j] : xs[j - H];
+      v = (j < H) ? hs[j] : iq_load1<FMT>(xs, j - H);
     }
     __syncthreads();
     if (i < H) hs[i] = v;

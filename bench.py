@@ -88,6 +88,8 @@ def main():
                     help="65536-sample blocks per step (2048 = 2^27 samples = 1 GiB of IQ, SURVEY.md 8d)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--input-format", choices=["cf32", "s16", "u8"], default="cf32",
+                    help="source sample format the front-end kernel reads (the headline metric is cf32)")
     ap.add_argument("--no-region-events", action="store_true",
                     help="diagnostic: no HIP events inside the timed region (roofline from the instrumented step)")
     args = ap.parse_args()
@@ -113,8 +115,14 @@ def main():
     iq = torch.stack([synth_fm_stereo_torch(n, FS, rank * S + s, dev) for s in range(S)])  # (S, n, 2)
     max_au = int(n * 0.0048) + 64
     audio = torch.zeros((S, 2 * max_au), dtype=torch.float64, device=dev)
+    fmt = {"cf32": 0, "s16": 1, "u8": 2}[args.input_format]
+    bps = {0: 8, 1: 4, 2: 2}[fmt]
+    if fmt == 1:      # quantise the same stream to the FileSource default format (S16_LE)
+        iq = torch.round(iq / 0.3 * 0.8 * 32767.0).to(torch.int16).contiguous()
+    elif fmt == 2:    # RTL-SDR offset binary
+        iq = (torch.round(iq / 0.3 * 0.8 * 127.0) + 128).to(torch.uint8).contiguous()
     ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=FS, enable_resampler=True, stereo=True, n_streams=S,
-                   max_block_len=BLK, max_blocks=B, device=local_rank)
+                   max_block_len=BLK, max_blocks=B, device=local_rank, input_format=fmt)
     block_len = [BLK] * B
     torch.cuda.synchronize()
 
@@ -169,11 +177,11 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pmc.get("blocks_per_step") == B and S == 1:
+            if pmc.get("blocks_per_step") == B and S == 1 and fmt == 0:
                 traffic = [v["hbm_bytes"] for k, v in pmc["kernels"].items() if "k_ifr_decim" in k][0]
         except Exception:
             traffic = None
-        bytes_per_launch = 8.0 * S * n            # algorithmic: 8 B per input IQ sample
+        bytes_per_launch = float(bps) * S * n     # algorithmic: 8 B per cf32 input IQ sample; 4 / 2 B for s16 / u8
         achieved = bytes_per_launch / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         out = {
             "metric": "IQ MS/s (FM stereo, 10 MS/s in), whole job",
@@ -182,7 +190,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 front end / f64 after the discriminator", "data": "synthetic",
             "config": {"workload": "configs[1]: single FM stereo stream per GPU, 10 MS/s complex-float IQ in HBM, "
                                    "PilotPhaseLock on, IfResampler+FmDecoder -> f64 stereo 48 kHz",
-                       "streams_per_gpu": S, "blocks_per_step": B, "block_len": BLK,
+                       "input_format": args.input_format, "streams_per_gpu": S, "blocks_per_step": B, "block_len": BLK,
                        "samples_per_step_per_gpu": S * n, "per_gpu_msps": round(value / world, 3),
                        "resampler": ch.resampler_info()},
             "roofline": {"bound": "hbm", "kernel": "ifr_decim (front-end stage A, reads every IQ sample)",

@@ -42,6 +42,7 @@ enum {
 
 /* ModType values follow include/SoftFM.h:49 */
 enum { FMR_MODE_FM = 0, FMR_MODE_NBFM = 1, FMR_MODE_AM = 2, FMR_MODE_DSB = 3 };
+enum { FMR_IQ_CF32 = 0, FMR_IQ_S16 = 1, FMR_IQ_U8 = 2, FMR_IQ_S8 = 3 };
 
 /* PilotPhaseLock::PpsEvent (include/PilotPhaseLock.h:40-44) + the index of the
  * block (within the call) that produced it. */
@@ -76,6 +77,13 @@ typedef struct {
   int max_blocks;             /* largest number of blocks per call */
   /* NbfmDecoder ctor argument (include/NbfmDecode.h:49): full-scale deviation in Hz, 0 = freq_dev_normal (8000) */
   double nbfm_freq_dev;
+  /* Source sample format of every `iq` argument (fused ingest: converted while the front-end kernel stages its
+   * tile; needs enable_resampler).  Conversions are the reference's: FMR_IQ_U8 = RTL-SDR offset binary
+   * (RtlSdrSource.cpp:359-365), the others = what sf_read_float delivers for the FileSource formats
+   * S16_LE / S8_LE / U8_LE / FLOAT (FileSource.cpp:120-128,491-531).  `iq` pointers are then pointers to
+   * interleaved I,Q samples of that type; counts and strides stay in IQ samples; raw-format device buffers and
+   * strides must be 16-byte aligned. */
+  int input_format;           /* FMR_IQ_CF32 (default) | FMR_IQ_S16 | FMR_IQ_U8 | FMR_IQ_S8 */
 } fmr_config;
 
 /* Per-stream status after the most recent call (getters of FmDecode.h:77-105 /

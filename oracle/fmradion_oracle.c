@@ -1068,3 +1068,23 @@ float ora_nbfm_baseband_level(const ora_nbfm *nb) { return nb->baseband_level; }
 float ora_nbfm_if_rms(const ora_nbfm *nb) { return nb->if_rms; }
 float ora_nbfm_if_agc_gain(const ora_nbfm *nb) { return nb->ifagc.current_gain; }
 
+/* ---------------------------------------------------------------------------
+ * Source sample formats -> IQSample (complex float).
+ *   fmt 1 S16_LE, 3 S8, 0 FLOAT: what sf_read_float() delivers for the FileSource formats
+ *     (sfmbase/FileSource.cpp:120-128 format names, :491-531 get_sf_read_float).  libsndfile is a third-party
+ *     dependency absent from the reference tree; its documented normalisation for integer PCM read as float is
+ *     value / 2^(bits-1) (pcm.c: s2f_array normfact 1/0x8000, sc2f_array 1/0x80, uc2f_array (x-128)/0x80).
+ *   fmt 2 U8: RTL-SDR offset binary, (b - 128) / 128 (sfmbase/RtlSdrSource.cpp:359-365) -- the same value as
+ *     libsndfile's unsigned 8-bit read.
+ * ------------------------------------------------------------------------- */
+int ora_iq_convert(int fmt, const void *raw, int n, float *out_iq) {
+  switch (fmt) {
+  case 0: memcpy(out_iq, raw, sizeof(float) * 2 * (size_t)n); return 0;
+  case 1: { const int16_t *p = (const int16_t *)raw; for (int i = 0; i < 2 * n; i++) out_iq[i] = (float)p[i] / 32768.0f; return 0; }
+  case 2: { const uint8_t *p = (const uint8_t *)raw;
+            for (int i = 0; i < 2 * n; i++) { int32_t v = (int32_t)p[i] - 128; out_iq[i] = v / 128.0f; } return 0; }
+  case 3: { const int8_t *p = (const int8_t *)raw; for (int i = 0; i < 2 * n; i++) out_iq[i] = (float)p[i] / 128.0f; return 0; }
+  default: return -1;
+  }
+}
+

@@ -188,6 +188,10 @@ float ora_nbfm_baseband_level(const ora_nbfm *nb);
 float ora_nbfm_if_rms(const ora_nbfm *nb);
 float ora_nbfm_if_agc_gain(const ora_nbfm *nb);
 
+/* Source sample formats (FileSource.cpp:120-128,491-531 via sf_read_float; RtlSdrSource.cpp:359-365):
+ * fmt 0 cf32, 1 s16, 2 u8 offset binary, 3 s8; n IQ samples, out_iq = 2n floats.  Returns 0, -1 for unknown fmt. */
+int ora_iq_convert(int fmt, const void *raw, int n, float *out_iq);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,7 @@ def lib():
         "ora_am_af_agc_gain": (C.c_float, [vp]),
         "ora_am_if_agc_gain": (C.c_float, [vp]),
         "ora_am_if_rms": (C.c_float, [vp]),
+        "ora_iq_convert": (C.c_int, [C.c_int, vp, C.c_int, c_float_p]),
         "ora_nbfm_create": (vp, [c_float_p, C.c_int, C.c_double, c_double_p, C.c_int]),
         "ora_nbfm_destroy": (None, [vp]),
         "ora_nbfm_process": (C.c_int, [vp, c_float_p, C.c_int, c_double_p, C.c_int]),
@@ -526,4 +527,14 @@ class NbfmDecoder:
 
     def get_if_agc_current_gain(self):
         return lib().ora_nbfm_if_agc_gain(self.h)
+
+
+def iq_convert(fmt, raw):
+    """raw: (N, 2) integer (or complex64 for fmt 0) -> complex64, the reference's source-side conversion."""
+    raw = np.ascontiguousarray(raw)
+    n = raw.shape[0]
+    out = np.empty(n, dtype=np.complex64)
+    rc = lib().ora_iq_convert(fmt, raw.ctypes.data_as(C.c_void_p), n, _fp(out.view(np.float32)))
+    assert rc == 0
+    return out
 

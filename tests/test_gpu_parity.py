@@ -282,6 +282,46 @@ def test_am_config3_full_chain(am_narrow):
     ch.close()
 
 
+# ------------------------------------------------------- fused ingest formats
+@pytest.mark.parametrize("fmt,dtype,scale,off", [(1, np.int16, 32767.0, 0), (2, np.uint8, 127.0, 128), (3, np.int8, 127.0, 0)])
+@pytest.mark.parametrize("fourth", [False, True])
+def test_raw_input_formats(fmt, dtype, scale, off, fourth, pilotcut):
+    """S16_LE / U8 / S8 IQ read by the front-end kernel itself (4 or 2 bytes per sample on HBM) against
+    oracle conversion -> [FourthConverterIQ] -> IfResampler -> FmDecoder; ragged blocks exercise the tile edges."""
+    lens = [65536, 65536, 4099, 1, 65536, 30001, 65536, 65536]
+    n = sum(lens)
+    x = siggen.fm_stereo_iq(n, 10e6)
+    if fourth:
+        x = (x * np.exp(2j * np.pi * 0.25 * np.arange(n))).astype(np.complex64)
+    raw = np.stack([np.round(x.real / 0.3 * 0.8 * scale) + off, np.round(x.imag / 0.3 * 0.8 * scale) + off], axis=1).astype(dtype)
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, fourth_down=fourth, stereo=True,
+                   max_block_len=65536, max_blocks=4, input_format=fmt)
+    r = ora.IfResampler(10e6, 384e3)
+    f4 = ora.FourthConverterIQ(False) if fourth else None
+    fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
+    xf = ora.iq_convert(fmt, raw)
+    got, ref, pos = [], [], 0
+    for i in range(0, len(lens), 4):
+        ll = lens[i:i + 4]
+        seg = raw[pos:pos + sum(ll)]
+        a, alen = ch.process_blocks(seg[None, :, :], ll)
+        got.append(a[0])
+        o = pos
+        for bl in ll:
+            b = xf[o:o + bl]
+            if f4 is not None:
+                b = f4.process(b)
+            ref.append(fm.process(r.process(b)))
+            o += bl
+        pos += sum(ll)
+        assert list(alen) == [len(q) for q in ref[-len(ll):]]
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    err = rms(got - ref)
+    _report(f"raw_fmt{fmt}_fourth{int(fourth)}", audio_rms_err=err, audio_rms=rms(ref), n=len(ref))
+    assert len(ref) > 1000 and err < 1e-5
+    ch.close()
+
+
 # ----------------------------------------------------------------- NbfmDecoder
 @pytest.mark.parametrize("dev", [8000.0, 17000.0])
 def test_nbfm_decoder_48k(dev, nbfm_default, nbfm_audio):

@@ -106,3 +106,15 @@ def test_nbfm_oracle_tone(nbfm_default, nbfm_audio):
     assert nb.get_tuning_offset() == pytest.approx(120.0 * (1 - 0.95 ** 60), rel=0.01)
     assert nb.get_if_rms() == pytest.approx(0.2, rel=1e-3)
 
+
+def test_source_format_conversions():
+    """RtlSdrSource.cpp:359-365 / sf_read_float semantics: exact power-of-two scalings."""
+    s16 = np.array([[-32768, 32767], [0, 1], [-1, 16384]], dtype=np.int16)
+    assert np.array_equal(ora.iq_convert(1, s16), (s16[:, 0] / 32768.0 + 1j * s16[:, 1] / 32768.0).astype(np.complex64))
+    u8 = np.array([[0, 255], [128, 127], [129, 1]], dtype=np.uint8)
+    assert np.array_equal(ora.iq_convert(2, u8), ((u8[:, 0].astype(int) - 128) / 128.0 + 1j * (u8[:, 1].astype(int) - 128) / 128.0).astype(np.complex64))
+    s8 = np.array([[-128, 127], [0, -1]], dtype=np.int8)
+    assert np.array_equal(ora.iq_convert(3, s8), (s8[:, 0] / 128.0 + 1j * s8[:, 1] / 128.0).astype(np.complex64))
+    x = np.array([0.25 - 0.5j, 1e-3 + 7j], dtype=np.complex64)
+    assert np.array_equal(ora.iq_convert(0, x.view(np.float32).reshape(-1, 2)), x)
+
