@@ -805,11 +805,15 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   const long long if_stride = H_if + (long long)max_if;
   hp2 = std::chrono::steady_clock::now();
   // ------------------------------------------------------- decoder, IF-rate part
-  timed("fm_block", [&] {
-    hipLaunchKernelGGL(k_fm_block<256>, dim3(nb, S), dim3(256), 0, stream, ifbuf, if_stride, H_if, bt, d_coeff.p,
-                       ntaps, (int)fir_enable, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if,
-                       d_if_rms_blk.p);
-  });
+  // FM without the IF FIR: the block RMS is taken inside the discriminator kernel (same samples, same lane order)
+  const bool rms_in_disc = (mode == FMR_MODE_FM) && !fir_enable && !serial_mode;
+  if (!rms_in_disc) {
+    timed("fm_block", [&] {
+      hipLaunchKernelGGL(k_fm_block<256>, dim3(nb, S), dim3(256), 0, stream, ifbuf, if_stride, H_if, bt, d_coeff.p,
+                         ntaps, (int)fir_enable, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if,
+                         d_if_rms_blk.p);
+    });
+  }
   const float2 *xin = fir_enable ? d_fir.p : ifbuf;
   const long long x_stride = fir_enable ? (long long)max_if : if_stride;
   const int x_off = fir_enable ? 0 : H_if;
@@ -875,7 +879,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
                          (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,
                          disc_nf, disc_bound, d_dec.p, (long long)max_if, d_base.p, base_stride, H_b,
-                         d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);
+                         d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p, rms_in_disc ? d_if_rms_blk.p : (float *)nullptr);
     });
     HIPCHK(hipEventRecord(ev_disc, stream));
     HIPCHK(hipStreamWaitEvent(side, ev_disc, 0));
@@ -1061,7 +1065,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
                          (long long)max_if, (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt, disc_nf, disc_bound,
                          d_dec.p, (long long)max_if, d_base.p, base_stride, H_b, d_bb_mean_blk.p, d_bb_rms_blk.p,
-                         d_state.p);
+                         d_state.p, (float *)nullptr);
     });
     timed("stats", [&] {
       hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,

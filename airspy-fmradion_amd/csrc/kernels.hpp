@@ -954,7 +954,8 @@ __global__ __launch_bounds__(BLOCK) void k_disc(
     const float2 *__restrict__ mpfb, long long m_stride, const int *__restrict__ mpf_ok,
     BlockTab bt, float nf, float bound, float *__restrict__ dec, long long dec_stride,
     double *__restrict__ base, long long base_stride, int base_off,
-    float *__restrict__ bb_mean_blk, float *__restrict__ bb_rms_blk, StreamState *st) {
+    float *__restrict__ bb_mean_blk, float *__restrict__ bb_rms_blk, StreamState *st,
+    float *__restrict__ if_rms_blk /* non-null: also the IF RMS of the block (k_fm_block's job when no IF FIR runs) */) {
   __shared__ float scratch[BLOCK / 64];
   const int b = blockIdx.x, s = blockIdx.y;
   const int n = bt.if_len[b];
@@ -964,9 +965,10 @@ __global__ __launch_bounds__(BLOCK) void k_disc(
   const float *gs = gain ? gain + (long long)s * g_stride : nullptr;
   const float2 *ms = mpfb ? mpfb + (long long)s * m_stride : nullptr;
   const int use_mpf = mpfb ? mpf_ok[(long long)s * bt.nb + b] : 0;
-  float vsum = 0.f, vsq = 0.f;
+  float vsum = 0.f, vsq = 0.f, rsq = 0.f;
   for (int i = threadIdx.x; i < n; i += BLOCK) {
     const float2 v = disc_src(xs, gs, ms, use_mpf, off + i);
+    if (if_rms_blk) { const float2 raw = xs[off + i]; rsq += raw.x * raw.x + raw.y * raw.y; }   // same lane order as k_fm_block
     const float ph = atan2f(v.y, v.x) / nf;                      // V4
     float prev;
     if (i > 0) {
@@ -1000,6 +1002,10 @@ __global__ __launch_bounds__(BLOCK) void k_disc(
   }
   const float ts = block_sum<BLOCK>(vsum, scratch);
   const float tq = block_sum<BLOCK>(vsq, scratch);
+  if (if_rms_blk) {
+    const float tr = block_sum<BLOCK>(rsq, scratch);
+    if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tr / (float)(unsigned)n);
+  }
   if (threadIdx.x == 0) {
     bb_mean_blk[(long long)s * bt.nb + b] = ts / (float)(unsigned)n;
     bb_rms_blk[(long long)s * bt.nb + b] = sqrtf(tq / (float)(unsigned)n);
