@@ -235,6 +235,9 @@ struct fmr_chain {
     return FMR_OK;
   }
   int init(const fmr_config *c);
+  bool cold = true;                     // no call yet: AGC at its initial gain, PLL unlocked
+  int run_cold_aware(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
+                     size_t astride, uint32_t *audio_len);
   int run(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
           size_t astride, uint32_t *audio_len);
 };
@@ -559,6 +562,35 @@ int fmr_chain::init(const fmr_config *c) {
     if ((rc = d_base.alloc((size_t)S * max_if))) return rc;
     if ((rc = d_audio.alloc((size_t)S * max_au))) return rc;
   }
+  return FMR_OK;
+}
+
+// A chain's first call starts from the initial AGC gain and an unlocked PLL; over that transient the Newton
+// iterations of the time-parallel recurrences diverge and the serial kernels take over -- 2 s for a 2048-block
+// call.  A call is by construction equal to its blocks processed one after the other, so a long first call is
+// cut after ~0.8 s of signal: the head pays the serial price (~0.1 s), the rest starts locked and runs parallel.
+int fmr_chain::run_cold_aware(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
+                              size_t astride, uint32_t *audio_len) {
+  const bool was_cold = cold;
+  cold = false;
+  if (!was_cold || mode != FMR_MODE_FM || !has_rs || nb < 2) return run(d_iq, stride, block_len, nb, d_aud, astride, audio_len);
+  const double target = 0.8 * cfg.input_rate;
+  double total = 0;
+  for (int b = 0; b < nb; b++) total += block_len[b];
+  if (total < 2.0 * target) return run(d_iq, stride, block_len, nb, d_aud, astride, audio_len);
+  size_t in_off = 0;
+  int k = 0;
+  while (k < nb - 1 && (double)in_off < target) in_off += block_len[k++];
+  if (in_fmt != 0 && (in_off * (size_t)in_bps) % 16 != 0) return run(d_iq, stride, block_len, nb, d_aud, astride, audio_len);
+  std::vector<uint32_t> al((size_t)nb, 0);
+  int rc = run(d_iq, stride, block_len, k, d_aud, astride, al.data());
+  if (rc) return rc;
+  size_t au_off = 0;
+  for (int b = 0; b < k; b++) au_off += al[b];
+  const float2 *iq2 = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(d_iq) + in_off * (size_t)in_bps);
+  rc = run(iq2, stride, block_len + k, nb - k, d_aud ? d_aud + au_off : nullptr, astride, al.data() + k);
+  if (rc) return rc;
+  if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = al[b];
   return FMR_OK;
 }
 
@@ -1148,7 +1180,7 @@ int fmr_synchronize(fmr_chain *c) {
 int fmr_process_blocks_device(fmr_chain *c, const float *d_iq, size_t stream_stride, const uint32_t *block_len,
                               int n_blocks, double *d_audio, size_t audio_stride, uint32_t *audio_len, int sync) {
   if (!c || !d_iq || !block_len) return FMR_ERR_BAD_ARG;
-  const int rc = c->run((const float2 *)d_iq, stream_stride, block_len, n_blocks, d_audio, audio_stride, audio_len);
+  const int rc = c->run_cold_aware((const float2 *)d_iq, stream_stride, block_len, n_blocks, d_audio, audio_stride, audio_len);
   if (rc) return rc;
   if (sync) HIPCHK(hipStreamSynchronize(c->stream));
   return FMR_OK;
@@ -1166,7 +1198,7 @@ int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, cons
                             (size_t)c->in_bps * N_in, c->S, hipMemcpyHostToDevice, c->pipelined ? c->fe : c->stream));
   const size_t dstride = c->stereo ? 2 * c->max_au : c->max_au;
   std::vector<uint32_t> alen(n_blocks, 0);
-  const int rc = c->run(c->d_in.p, c->max_in, block_len, n_blocks, c->d_audio.p, dstride, alen.data());
+  const int rc = c->run_cold_aware(c->d_in.p, c->max_in, block_len, n_blocks, c->d_audio.p, dstride, alen.data());
   if (rc) return rc;
   size_t total = 0;
   for (int b = 0; b < n_blocks; b++) { total += alen[b]; if (audio_len) audio_len[b] = alen[b]; }

@@ -1190,7 +1190,8 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
   unsigned long long pps_cnt = S.pps_cnt, sample_cnt = S.sample_cnt;
   int n_pps = 0;
   long long wr = 0, ns = 0;
-  const double ph_start = S.pll_phase;
+  double ph_start = S.pll_phase;
+  bool favg_locked = (S.lock_cnt >= pc.lock_delay);
   const double *xin = base + (long long)s * base_stride + base_off;
   double *out = raw + (long long)s * raw_stride + raw_off;
   for (int b = 0; b < bt.nb; b++) {
@@ -1198,6 +1199,11 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
     if (n == 0) { stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay); continue; }
     const int off = bt.if_off[b];
     const bool was_locked = (lock_cnt >= pc.lock_delay);
+    // the mean phase increment that seeds the next call's node guess is measured over locked signal only, and over
+    // the last quarter of a long call: the pull-in transient would put it off by far more than the ~1e-9
+    // rad/sample the ramp guess tolerates over millions of samples
+    if ((was_locked && !favg_locked) || b == (bt.nb * 3) / 4) { wr = 0; ns = 0; ph_start = R.v[0]; }
+    favg_locked = was_locked;
     const int pps_blk_start = n_pps;
     for (int i = 0; i < n; i++) {
       double o;

@@ -129,6 +129,13 @@ def main():
     def step():
         return ch.process_blocks_device(iq.data_ptr(), n, block_len, audio.data_ptr(), audio.shape[1], sync=False)
 
+    # Set-up, not warm-up: one call brings the chain from its cold state (initial AGC gain, PLL unlocked) into
+    # lock -- the metric's configuration is "PilotPhaseLock on", i.e. the locked steady state.  The cold call is
+    # reported separately (cold_first_call_ms); the W warm-up steps below are ordinary locked steps.
+    t_c = time.perf_counter()
+    step()
+    ch.synchronize()
+    cold_ms = (time.perf_counter() - t_c) * 1e3
     for _ in range(args.warmup):
         step()
     ch.synchronize()
@@ -199,6 +206,7 @@ def main():
                          "avg_launch_ms": round(dec_ms, 5), "algorithmic_bytes_per_launch": bytes_per_launch},
             "kernel_ms_per_step": {k: round(v, 5) for k, v in kavg.items()},
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
+            "cold_first_call_ms": round(cold_ms, 2),
             "audio_check": {"stereo_locked": int(st.stereo_detected), "pilot_level": round(st.pilot_level, 6)},
             "recurrences": {"agc_newton_rounds": st.agc_iterations, "pll_newton_rounds": st.pll_iterations,
                             "pll_residuals": [float("%.3g" % v) for v in st.pll_residual_history[:st.pll_iterations]],

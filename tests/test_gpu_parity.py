@@ -432,6 +432,29 @@ def test_fm_stereo_config2(pilotcut):
     ch.close()
 
 
+def test_cold_first_call_is_split(pilotcut):
+    """A chain's first call covering > 1.6 s of signal is cut after ~0.8 s (fmradion_amd.hip run_cold_aware): the head
+    goes through the serial fallback, the rest -- starting locked -- through the time-parallel path.  Same audio as
+    260 sequential process() calls."""
+    nblk, blk = 260, 65536
+    x = siggen.fm_stereo_iq(nblk * blk, 10e6)
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=nblk)
+    a, alen = ch.process_blocks(x[None, :], [blk] * nblk)
+    st = ch.status()
+    r = ora.IfResampler(10e6, 384e3)
+    fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
+    ref = [fm.process(r.process(b)) for b in siggen.blocks(x, blk)]
+    assert list(alen) == [len(q) for q in ref]
+    ref = np.concatenate(ref)
+    err = rms(a[0] - ref)
+    _report("cold_first_call", audio_rms_err=err, n=len(ref), pll_iters=st.pll_iterations, pll_fallback=st.pll_fallback,
+            agc_fallback=st.agc_fallback, locked=st.stereo_detected)
+    assert st.pll_fallback == 0 and st.agc_fallback == 0       # status of the second part
+    assert st.stereo_detected == 1 and fm.stereo_detected()
+    assert err < 1e-5
+    ch.close()
+
+
 def test_multi_stream_batch(pilotcut):
     """Three independent streams in one chain (the sharding unit of config 5)."""
     S, nblk, blk = 3, 12, 65536
