@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_DIR, "libfmradion_amd.so")
 SRC = os.path.join(_DIR, "csrc", "fmradion_amd.hip")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
-MODE_NONE, MODE_FM, MODE_NBFM, MODE_AM, MODE_DSB = -1, 0, 1, 2, 3
+MODE_NONE, MODE_FM, MODE_NBFM, MODE_AM, MODE_DSB, MODE_USB, MODE_LSB, MODE_CW, MODE_WSPR = -1, 0, 1, 2, 3, 4, 5, 6, 7
 IQ_CF32, IQ_S16, IQ_U8, IQ_S8 = 0, 1, 2, 3
 _IQ_DTYPE = {0: np.complex64, 1: np.int16, 2: np.uint8, 3: np.int8}
 OK = 0

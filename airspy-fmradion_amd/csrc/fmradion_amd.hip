@@ -121,6 +121,11 @@ struct fmr_chain {
   DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
   int poly2_tile = 0;                  // staged mid samples per tile, 0 = v2 kernel not applicable
   double nbfm_freq_dev = 8000.0;
+  // SSB / CW / WSPR (AmDecode.cpp:83-90,107-136): mixers before and after the 2049-tap filter
+  bool ssb_like = false;
+  DevBuf<float2> d_ft_pre, d_ft_post;   // FineTuner tables (480 entries), empty = no mixer at that place
+  unsigned ft_index = 0;                 // FineTuner::m_index, the same for every tuner of the chain
+  double af_ref = 0.6, af_rate = 0.001;  // AfSimpleAgc reference / rate (AmDecode.cpp:54-66)
   int in_fmt = 0, in_bps = 8;          // source sample format (fmr_config.input_format) and its bytes per IQ sample
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
@@ -179,7 +184,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_afrag.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_afrag.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -255,7 +260,7 @@ int fmr_chain::init(const fmr_config *c) {
   S = c->n_streams;
   mode = c->mode;
   if (S < 1 || c->max_block_len == 0 || c->max_blocks < 1) { set_err("bad capacity / n_streams"); return FMR_ERR_BAD_ARG; }
-  if (mode != FMR_MODE_FM && mode != FMR_MODE_NBFM && mode != FMR_MODE_AM && mode != FMR_MODE_DSB && mode != FMR_MODE_NONE) {
+  if (mode != FMR_MODE_NONE && (mode < FMR_MODE_FM || mode > FMR_MODE_WSPR)) {
     set_err("mode %d is not on the hot path (FM, AM, DSB only)", mode);
     return FMR_ERR_UNSUPPORTED;
   }
@@ -370,8 +375,14 @@ int fmr_chain::init(const fmr_config *c) {
   int rc;
   if ((rc = d_in.alloc((size_t)S * max_in))) return rc;
   ntaps = c->n_filter_coeff;
+  ssb_like = (mode == FMR_MODE_USB || mode == FMR_MODE_LSB || mode == FMR_MODE_CW || mode == FMR_MODE_WSPR);
+  const float *filter_src = c->filter_coeff;
+  if (ssb_like) {     // AmDecoder's own filters: m_ssbfilter for USB/LSB, m_cwfilter for CW/WSPR (AmDecode.cpp:36,40)
+    filter_src = (mode == FMR_MODE_USB || mode == FMR_MODE_LSB) ? k_jj1bdx_ssb_48khz_1500hz : k_jj1bdx_cw_48khz_500hz;
+    ntaps = 2049;
+  }
   fir_enable = (mode == FMR_MODE_FM) ? (c->fmfilter_enable != 0) : (mode != FMR_MODE_NONE);
-  if (has_dec && (ntaps < 1 || !c->filter_coeff)) { set_err("filter_coeff missing"); return FMR_ERR_BAD_ARG; }
+  if (has_dec && (ntaps < 1 || !filter_src)) { set_err("filter_coeff missing"); return FMR_ERR_BAD_ARG; }
   H_if = has_dec ? (ntaps > 1 ? ntaps - 1 : 1) : 1;
   if ((rc = d_if.alloc((size_t)S * (H_if + max_if)))) return rc;
   last_if = d_if.p;
@@ -425,7 +436,7 @@ int fmr_chain::init(const fmr_config *c) {
   }
   if (!has_dec) return FMR_OK;
 
-  if ((rc = upload(d_coeff, c->filter_coeff, (size_t)ntaps))) return rc;
+  if ((rc = upload(d_coeff, filter_src, (size_t)ntaps))) return rc;
   if (fir_enable && (rc = d_fir.alloc((size_t)S * max_if))) return rc;
   if ((rc = d_gain.alloc((size_t)S * max_if))) return rc;
   if ((rc = d_dec.alloc((size_t)S * max_if))) return rc;
@@ -555,7 +566,31 @@ int fmr_chain::init(const fmr_config *c) {
     if ((rc = d_base.alloc((size_t)S * (H_b + max_if)))) return rc;
     if ((rc = d_audio.alloc((size_t)S * max_au))) return rc;
   } else {
-    agc_init = 1.0f; agc_max = 1000000.0f; agc_rate = 0.0003f;          // AmDecode.cpp:71-77
+    const bool cw_like = (mode == FMR_MODE_CW || mode == FMR_MODE_WSPR);
+    agc_init = 1.0f; agc_max = 1000000.0f; agc_rate = cw_like ? 0.0006f : 0.0003f;   // AmDecode.cpp:71-77
+    af_ref = ssb_like ? 0.24 : 0.6;                                       // AmDecode.cpp:54-66
+    af_rate = cw_like ? 0.00125 : 0.001;
+    if (ssb_like) {
+      // FineTuner(table_size 480 = 48000/100, freq_shift) tables: FineTuner.cpp:25-52 with m_index = 0, phase offset 0
+      auto table = [](int freq_shift) {
+        const int ts = 480;
+        std::vector<float2> t((size_t)ts);
+        const double phase_step = 2.0 * M_PI / double(ts);
+        for (int i = 0; i < ts; i++) {
+          const double phi = (double)(((int64_t)freq_shift * i) % ts) * phase_step;
+          t[(size_t)i] = make_float2((float)std::cos(phi), (float)std::sin(phi));
+        }
+        return t;
+      };
+      const auto up = table(15), down = table(-15), cw = table(5);       // AmDecode.cpp:83-90
+      switch (mode) {
+      case FMR_MODE_USB: rc = upload(d_ft_pre, down.data(), down.size()); if (!rc) rc = upload(d_ft_post, up.data(), up.size()); break;
+      case FMR_MODE_LSB: rc = upload(d_ft_pre, up.data(), up.size()); if (!rc) rc = upload(d_ft_post, down.data(), down.size()); break;
+      case FMR_MODE_CW: rc = upload(d_ft_post, cw.data(), cw.size()); break;
+      default: rc = upload(d_ft_pre, down.data(), down.size()); if (!rc) rc = upload(d_ft_post, up.data(), up.size()); break;   // WSPR
+      }
+      if (rc) return rc;
+    }
     am_dcblock = highpass_iir(60 / kAmRate);                              // AmDecode.cpp:45
     am_deemph = lowpass_rc(100 * kPcmRate * 1.0e-6);                      // AmDecode.cpp:49
     max_au = max_if;
@@ -837,6 +872,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   const long long if_stride = H_if + (long long)max_if;
   hp2 = std::chrono::steady_clock::now();
   // ------------------------------------------------------- decoder, IF-rate part
+  // SSB / WSPR: mix the new IF samples in place before the filter (the filter history in the halo is already mixed)
+  if (ssb_like && d_ft_pre.p)
+    timed("finetune_pre", [&] {
+      hipLaunchKernelGGL(k_finetune<256>, dim3(nb, S), dim3(256), 0, stream, ifbuf, if_stride, H_if, bt, d_ft_pre.p,
+                         480, ft_index, (float *)nullptr);
+    });
   // FM without the IF FIR: the block RMS is taken inside the discriminator kernel (same samples, same lane order)
   const bool rms_in_disc = (mode == FMR_MODE_FM) && !fir_enable && !serial_mode;
   if (!rms_in_disc) {
@@ -845,6 +886,13 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          ntaps, (int)fir_enable, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if,
                          d_if_rms_blk.p);
     });
+  }
+  if (ssb_like) {    // mix the filter output in place; the IF level is measured after it (AmDecode.cpp:114,122,128,136,154)
+    timed("finetune_post", [&] {
+      hipLaunchKernelGGL(k_finetune<256>, dim3(nb, S), dim3(256), 0, stream, d_fir.p, (long long)max_if, 0, bt,
+                         d_ft_post.p, 480, ft_index, d_if_rms_blk.p);
+    });
+    ft_index = (unsigned)((ft_index + (unsigned long long)N_if) % 480u);
   }
   const float2 *xin = fir_enable ? d_fir.p : ifbuf;
   const long long x_stride = fir_enable ? (long long)max_if : if_stride;
@@ -1114,7 +1162,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   } else {
     timed("am_demod", [&] {
       hipLaunchKernelGGL(k_am_demod<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
-                         (long long)max_if, bt, (int)(mode == FMR_MODE_DSB), d_dec.p, (long long)max_if, d_base.p,
+                         (long long)max_if, bt, (int)(mode != FMR_MODE_AM), d_dec.p, (long long)max_if, d_base.p,
                          (long long)max_if, d_bb_mean_blk.p, d_bb_rms_blk.p);
     });
     timed("stats", [&] {
@@ -1123,9 +1171,9 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     });
     timed("am_tail", [&] {
       hipLaunchKernelGGL(k_am_tail, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
-                         am_dcblock.b0, am_dcblock.b1, am_dcblock.b2, am_dcblock.a1, am_dcblock.a2, 1.0, 1.5, 0.6,
-                         0.001, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
-                         d_state.p, S);   // AfSimpleAgc(1.0, 1.5, 0.6, 0.001): AmDecode.cpp:54-66
+                         am_dcblock.b0, am_dcblock.b1, am_dcblock.b2, am_dcblock.a1, am_dcblock.a2, 1.0, 1.5, af_ref,
+                         af_rate, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
+                         d_state.p, S);   // AfSimpleAgc(1.0, 1.5, reference, rate): AmDecode.cpp:54-66
     });
     add_halo(ifbuf, if_stride, H_if, N_if);
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)t_au_len[b];

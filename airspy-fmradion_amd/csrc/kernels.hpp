@@ -777,6 +777,37 @@ __global__ __launch_bounds__(BLOCK) void k_fm_block(
 }
 
 // ---------------------------------------------------------------------------
+// K_finetune : FineTuner::process (FineTuner.cpp:55-73), the table-driven mixer of the SSB / CW / WSPR modes
+// (AmDecode.cpp:107-136), in place, one workgroup per block.  idx0 = table index of the call's first sample
+// (the reference's m_index).  With if_rms_blk it also takes the block RMS of its output (AmDecode.cpp:154 measures
+// the IF level after the last mixer), same lane order as k_fm_block.
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_finetune(float2 *__restrict__ buf, long long stride, int off0, BlockTab bt,
+                                                    const float2 *__restrict__ table, int table_size, unsigned idx0,
+                                                    float *__restrict__ if_rms_blk) {
+  __shared__ float scratch[BLOCK / 64];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int n = bt.if_len[b];
+  if (n == 0) return;
+  float2 *x = buf + (long long)s * stride + off0 + bt.if_off[b];
+  const unsigned base = (idx0 + (unsigned)bt.if_off[b]) % (unsigned)table_size;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += BLOCK) {
+    const float2 v = x[i];
+    const float2 t = table[(base + (unsigned)i) % (unsigned)table_size];
+    const float re = v.x * t.x - v.y * t.y;       // std::complex<float> operator*
+    const float im = v.x * t.y + v.y * t.x;
+    x[i] = make_float2(re, im);
+    acc += re * re + im * im;
+  }
+  if (if_rms_blk) {
+    const float tot = block_sum<BLOCK>(acc, scratch);
+    if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K_agc : IfSimpleAgc (IfSimpleAgc.cpp:37-57), nonlinear serial recurrence,
 // one lane per stream.  Emits the gain applied to each sample; consumers form
 // x*g themselves (same two float multiplies as the reference).

@@ -196,15 +196,15 @@ private:
   std::vector<std::complex<float>> m_coeff;
 };
 
-// AmDecoder (AmDecode.h:48-65), modes AM and DSB
+// AmDecoder (AmDecode.h:48-65), all of its modes: AM, DSB, USB, LSB, CW, WSPR
 class AmDecoder {
 public:
   static constexpr double sample_rate_pcm = 48000;
   static constexpr double internal_rate_pcm = 48000;
   AmDecoder(IQSampleCoeff &amfilter_coeff, const ModType mode, int device = 0) {
-    if (mode != ModType::AM && mode != ModType::DSB) throw std::runtime_error("AmDecoder facade: AM and DSB only");
+    if (mode == ModType::FM || mode == ModType::NBFM) throw std::runtime_error("AmDecoder: FM modes have their own decoders");
     m_cfg = fmr_config{};
-    m_cfg.device = device; m_cfg.n_streams = 1; m_cfg.mode = (mode == ModType::AM) ? FMR_MODE_AM : FMR_MODE_DSB;
+    m_cfg.device = device; m_cfg.n_streams = 1; m_cfg.mode = static_cast<int>(mode);   // FMR_MODE_* follow ModType
     m_cfg.input_rate = internal_rate_pcm; m_cfg.filter_coeff = amfilter_coeff.data();
     m_cfg.n_filter_coeff = (int)amfilter_coeff.size(); m_cfg.max_block_len = 65536; m_cfg.max_blocks = 1;
     m_chain = fmr_detail::make(m_cfg);

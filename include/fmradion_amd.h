@@ -41,7 +41,9 @@ enum {
 };
 
 /* ModType values follow include/SoftFM.h:49 */
-enum { FMR_MODE_FM = 0, FMR_MODE_NBFM = 1, FMR_MODE_AM = 2, FMR_MODE_DSB = 3 };
+/* ModType order of the reference (include/SoftFM.h:49) */
+enum { FMR_MODE_FM = 0, FMR_MODE_NBFM = 1, FMR_MODE_AM = 2, FMR_MODE_DSB = 3, FMR_MODE_USB = 4, FMR_MODE_LSB = 5,
+       FMR_MODE_CW = 6, FMR_MODE_WSPR = 7 };
 enum { FMR_IQ_CF32 = 0, FMR_IQ_S16 = 1, FMR_IQ_U8 = 2, FMR_IQ_S8 = 3 };
 
 /* PilotPhaseLock::PpsEvent (include/PilotPhaseLock.h:40-44) + the index of the
@@ -58,7 +60,8 @@ typedef struct {
 typedef struct {
   int device;                 /* HIP device ordinal */
   int n_streams;              /* >= 1 independent IQ streams (batch) */
-  int mode;                   /* FMR_MODE_FM | FMR_MODE_NBFM | FMR_MODE_AM | FMR_MODE_DSB */
+  int mode;                   /* FMR_MODE_FM | _NBFM | _AM | _DSB | _USB | _LSB | _CW | _WSPR (the last four ignore
+                               * filter_coeff: AmDecoder uses its built-in 2049-tap SSB / CW tables there) */
   double input_rate;          /* sample rate of the IQ handed to process */
   /* Front end.  0 = the decoder is fed at its own rate (384 kHz FM / 48 kHz
    * AM) and no IfResampler runs (main.cpp:778 enable_downsampling=false). */

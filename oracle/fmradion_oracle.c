@@ -947,9 +947,37 @@ int ora_fm_debug_vector(const ora_fm *fm, int which, double *out, int cap) {
 /* ======================================================================== */
 /* AmDecoder (AM, DSB) -- sfmbase/AmDecode.cpp:25-234                         */
 /* ======================================================================== */
+/* FineTuner (sfmbase/FineTuner.cpp:25-73): table-driven complex mixer, phase-continuous across calls */
+void ora_finetuner_init(ora_finetuner *ft, unsigned table_size, int freq_shift) {   /* :25-52 */
+  ft->index = 0;
+  ft->size = table_size;
+  ft->tab = (float *)malloc(sizeof(float) * 2 * table_size);
+  const double phase_offset = fmod(0.0, 2.0 * M_PI);      /* m_phase_table[0] == 0 at construction */
+  const double phase_step = 2.0 * M_PI / (double)table_size;
+  for (unsigned i = 0; i < table_size; i++) {
+    const double phi = (double)(((int64_t)freq_shift * (int64_t)i) % (int64_t)table_size) * phase_step + phase_offset;
+    ft->tab[2 * i] = (float)cos(phi);                      /* IQSample(pcos, psin): double -> float */
+    ft->tab[2 * i + 1] = (float)sin(phi);
+  }
+}
+void ora_finetuner_free(ora_finetuner *ft) { free(ft->tab); ft->tab = NULL; }
+void ora_finetuner_process(ora_finetuner *ft, const float *iq, int n, float *out) { /* :55-73 */
+  unsigned idx = ft->index;
+  for (int i = 0; i < n; i++) {
+    const float a = iq[2 * i], b = iq[2 * i + 1], c = ft->tab[2 * idx], d = ft->tab[2 * idx + 1];
+    out[2 * i] = a * c - b * d;                            /* std::complex<float> operator* */
+    out[2 * i + 1] = a * d + b * c;
+    if (++idx == ft->size) idx = 0;
+  }
+  ft->index = idx;
+}
+
 struct ora_am {
   int mode;
   float baseband_mean, baseband_level, if_rms;
+  ora_firiq *cwfilter, *ssbfilter;
+  ora_finetuner cw_ft, up_ft, down_ft;
+  float *b1a, *b1b;
   ora_firiq *amfilter;
   ora_biquad dcblock;
   ora_iir1 deemph;
@@ -959,19 +987,34 @@ struct ora_am {
   float *b2, *b3, *dec;
   double *demod;
 };
-ora_am *ora_am_create(const float *coeff, int n_coeff, int mode) {
+ora_am *ora_am_create2(const float *coeff, int n_coeff, int mode, const float *cwcoeff, int n_cw,
+                       const float *ssbcoeff, int n_ssb) {
   ora_am *am = (ora_am *)calloc(1, sizeof(*am));
   am->mode = mode;
+  const int ssb_like = (mode == ORA_MODE_USB || mode == ORA_MODE_LSB || mode == ORA_MODE_CW || mode == ORA_MODE_WSPR);
+  const int cw_like = (mode == ORA_MODE_CW || mode == ORA_MODE_WSPR);
   am->amfilter = ora_firiq_create(coeff, n_coeff, 1);       /* :32 */
+  if (cwcoeff) am->cwfilter = ora_firiq_create(cwcoeff, n_cw, 1);     /* :36 jj1bdx_cw_48khz_500hz */
+  if (ssbcoeff) am->ssbfilter = ora_firiq_create(ssbcoeff, n_ssb, 1); /* :40 jj1bdx_ssb_48khz_1500hz */
   ora_highpass_init(&am->dcblock, 60 / 48000.0);            /* :45 */
   ora_lowpass_rc_init(&am->deemph, 100 * 48000.0 * 1.0e-6); /* :49 */
-  ora_afagc_init(&am->afagc, 1.0, 1.5, 0.6, 0.001);         /* :54-66 (AM/DSB) */
-  ora_ifagc_init(&am->ifagc, 1.0f, 1000000.0f, 0.0003f);    /* :71-77 (AM/DSB) */
+  ora_afagc_init(&am->afagc, 1.0, 1.5, ssb_like ? 0.24 : 0.6, cw_like ? 0.00125 : 0.001);   /* :54-66 */
+  ora_ifagc_init(&am->ifagc, 1.0f, 1000000.0f, cw_like ? 0.0006f : 0.0003f);                /* :71-77 */
+  ora_finetuner_init(&am->cw_ft, 480, 5);                   /* :83  48000/100, 500/100 */
+  ora_finetuner_init(&am->up_ft, 480, 15);                  /* :89  +1500 Hz */
+  ora_finetuner_init(&am->down_ft, 480, -15);               /* :90  -1500 Hz */
   return am;
+}
+ora_am *ora_am_create(const float *coeff, int n_coeff, int mode) {
+  return ora_am_create2(coeff, n_coeff, mode, NULL, 0, NULL, 0);
 }
 void ora_am_destroy(ora_am *am) {
   if (!am) return;
   ora_firiq_destroy(am->amfilter);
+  if (am->cwfilter) ora_firiq_destroy(am->cwfilter);
+  if (am->ssbfilter) ora_firiq_destroy(am->ssbfilter);
+  ora_finetuner_free(&am->cw_ft); ora_finetuner_free(&am->up_ft); ora_finetuner_free(&am->down_ft);
+  free(am->b1a); free(am->b1b);
   free(am->b2); free(am->b3); free(am->dec); free(am->demod); free(am);
 }
 int ora_am_process(ora_am *am, const float *iq, int n, double *audio, int cap) { /* :96-218 */
@@ -981,8 +1024,34 @@ int ora_am_process(ora_am *am, const float *iq, int n, double *audio, int cap) {
     am->b3 = (float *)realloc(am->b3, sizeof(float) * 2 * n);
     am->dec = (float *)realloc(am->dec, sizeof(float) * n);
     am->demod = (double *)realloc(am->demod, sizeof(double) * n);
+    am->b1a = (float *)realloc(am->b1a, sizeof(float) * 2 * n);
+    am->b1b = (float *)realloc(am->b1b, sizeof(float) * 2 * n);
   }
-  int n2 = ora_firiq_process(am->amfilter, iq, n, am->b2);  /* :101 */
+  int n2;
+  switch (am->mode) {                                       /* :96-151 */
+  case ORA_MODE_USB:                                        /* shift down 1500 Hz, SSB filter, shift up (:107-114) */
+    ora_finetuner_process(&am->down_ft, iq, n, am->b1a);
+    n2 = ora_firiq_process(am->ssbfilter, am->b1a, n, am->b1b);
+    ora_finetuner_process(&am->up_ft, am->b1b, n2, am->b2);
+    break;
+  case ORA_MODE_LSB:                                        /* :115-122 */
+    ora_finetuner_process(&am->up_ft, iq, n, am->b1a);
+    n2 = ora_firiq_process(am->ssbfilter, am->b1a, n, am->b1b);
+    ora_finetuner_process(&am->down_ft, am->b1b, n2, am->b2);
+    break;
+  case ORA_MODE_CW:                                         /* CW LPF, then up to a 500 Hz pitch (:123-128) */
+    n2 = ora_firiq_process(am->cwfilter, iq, n, am->b1a);
+    ora_finetuner_process(&am->cw_ft, am->b1a, n2, am->b2);
+    break;
+  case ORA_MODE_WSPR:                                       /* :129-136 */
+    ora_finetuner_process(&am->down_ft, iq, n, am->b1a);
+    n2 = ora_firiq_process(am->cwfilter, am->b1a, n, am->b1b);
+    ora_finetuner_process(&am->up_ft, am->b1b, n2, am->b2);
+    break;
+  default:
+    n2 = ora_firiq_process(am->amfilter, iq, n, am->b2);    /* :101 */
+    break;
+  }
   am->if_rms = ora_rms_level(am->b2, n2);                   /* :154 */
   ora_ifagc_process(&am->ifagc, am->b2, n2, am->b3);        /* :157 */
   if (am->mode == ORA_MODE_AM) {

@@ -136,6 +136,12 @@ double ora_mpf_error(const ora_mpf *m);
 int ora_mpf_order(const ora_mpf *m);
 const float *ora_mpf_coeff(const ora_mpf *m); /* interleaved re,im */
 
+/* FineTuner (sfmbase/FineTuner.cpp:25-73) */
+typedef struct { unsigned index, size; float *tab; } ora_finetuner;
+void ora_finetuner_init(ora_finetuner *ft, unsigned table_size, int freq_shift);
+void ora_finetuner_free(ora_finetuner *ft);
+void ora_finetuner_process(ora_finetuner *ft, const float *iq, int n, float *out);
+
 /* FourthConverterIQ (include/FourthConverterIQ.h:30-82) */
 typedef struct { unsigned index; unsigned t0, t1, t2, t3; } ora_fourth;
 void ora_fourth_init(ora_fourth *f, int up);
@@ -167,9 +173,12 @@ const float *ora_fm_multipath_coeff(const ora_fm *fm, int *order);
 int ora_fm_debug_vector(const ora_fm *fm, int which, double *out, int cap);
 
 /* AmDecoder, modes AM and DSB (sfmbase/AmDecode.cpp:25-234) */
-enum { ORA_MODE_AM = 2, ORA_MODE_DSB = 3 }; /* ModType order, SoftFM.h:49 */
+enum { ORA_MODE_AM = 2, ORA_MODE_DSB = 3, ORA_MODE_USB = 4, ORA_MODE_LSB = 5, ORA_MODE_CW = 6, ORA_MODE_WSPR = 7 }; /* ModType order, SoftFM.h:49 */
 typedef struct ora_am ora_am;
 ora_am *ora_am_create(const float *amfilter_coeff, int n_coeff, int mode);
+/* all modes: cwcoeff / ssbcoeff = the jj1bdx_cw_48khz_500hz / jj1bdx_ssb_48khz_1500hz tables (AmDecode.cpp:36,40) */
+ora_am *ora_am_create2(const float *amfilter_coeff, int n_coeff, int mode, const float *cwcoeff, int n_cw,
+                       const float *ssbcoeff, int n_ssb);
 void ora_am_destroy(ora_am *am);
 int ora_am_process(ora_am *am, const float *iq, int n, double *audio, int cap);
 double ora_am_baseband_level(const ora_am *am);

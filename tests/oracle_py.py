@@ -85,6 +85,7 @@ def lib():
         "ora_fm_multipath_coeff": (c_float_p, [vp, C.POINTER(C.c_int)]),
         "ora_fm_debug_vector": (C.c_int, [vp, C.c_int, c_double_p, C.c_int]),
         "ora_am_create": (vp, [c_float_p, C.c_int, C.c_int]),
+        "ora_am_create2": (vp, [c_float_p, C.c_int, C.c_int, c_float_p, C.c_int, c_float_p, C.c_int]),
         "ora_am_destroy": (None, [vp]),
         "ora_am_process": (C.c_int, [vp, c_float_p, C.c_int, c_double_p, C.c_int]),
         "ora_am_baseband_level": (C.c_double, [vp]),
@@ -458,15 +459,20 @@ class FmDecoder:
         return np.ctypeslib.as_array(p, shape=(2 * n.value,)).copy().view(np.complex64)
 
 
-MODE_AM, MODE_DSB = 2, 3
+MODE_AM, MODE_DSB, MODE_USB, MODE_LSB, MODE_CW, MODE_WSPR = 2, 3, 4, 5, 6, 7
 
 
 class AmDecoder:
     """Mirror of AmDecoder (include/AmDecode.h:48-65), modes AM and DSB."""
 
-    def __init__(self, amfilter_coeff, mode=MODE_AM):
+    def __init__(self, amfilter_coeff, mode=MODE_AM, cw_coeff=None, ssb_coeff=None):
         c = np.ascontiguousarray(amfilter_coeff, dtype=np.float32)
-        self.h = lib().ora_am_create(_fp(c), len(c), mode)
+        if cw_coeff is None and ssb_coeff is None:
+            self.h = lib().ora_am_create(_fp(c), len(c), mode)
+        else:   # USB / LSB / CW / WSPR need the 2049-tap tables of AmDecode.cpp:36,40
+            cw = np.ascontiguousarray(cw_coeff, dtype=np.float32)
+            ssb = np.ascontiguousarray(ssb_coeff, dtype=np.float32)
+            self.h = lib().ora_am_create2(_fp(c), len(c), mode, _fp(cw), len(cw), _fp(ssb), len(ssb))
 
     def __del__(self):
         if getattr(self, "h", None):

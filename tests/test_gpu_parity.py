@@ -263,6 +263,41 @@ def test_am_decoder_48k(mode, am_narrow):
     ch.close()
 
 
+@pytest.mark.parametrize("mode", ["usb", "lsb", "cw", "wspr"])
+def test_am_decoder_ssb_cw_modes(mode, am_narrow):
+    """AmDecoder USB / LSB / CW / WSPR (AmDecode.cpp:103-147): FineTuner mixers around the 2049-tap filters."""
+    fs, blk, nblk, batch = 48e3, 2048, 96, 8
+    n = nblk * blk
+    t = np.arange(n) / fs
+    rng = np.random.default_rng(11)
+    # a two-tone upper-sideband signal (+700 Hz, +1900 Hz), a weaker lower-sideband tone and noise
+    x = (0.05 * np.exp(2j * np.pi * 700 * t) + 0.03 * np.exp(2j * np.pi * 1900 * t) + 0.02 * np.exp(-2j * np.pi * 1100 * t)
+         + 1e-4 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    gm = {"usb": fmr.MODE_USB, "lsb": fmr.MODE_LSB, "cw": fmr.MODE_CW, "wspr": fmr.MODE_WSPR}[mode]
+    om = {"usb": ora.MODE_USB, "lsb": ora.MODE_LSB, "cw": ora.MODE_CW, "wspr": ora.MODE_WSPR}[mode]
+    ch = fmr.Chain(mode=gm, input_rate=fs, enable_resampler=False, filter_coeff=am_narrow, max_block_len=blk, max_blocks=batch)
+    am = ora.AmDecoder(am_narrow, om, load_filter("jj1bdx_cw_48khz_500hz"), load_filter("jj1bdx_ssb_48khz_1500hz"))
+    got, ref = [], []
+    for i in range(0, nblk, batch):
+        seg = x[i * blk:(i + batch) * blk]
+        a, alen = ch.process_blocks(seg[None, :], [blk] * batch)
+        got.append(a[0])
+        ref += [am.process(b) for b in siggen.blocks(seg, blk)]
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    assert len(got) == len(ref) == n
+    err = rms(got - ref)
+    st = ch.status()
+    _report(f"am_{mode}", audio_rms_err=err, audio_rms=rms(ref), if_rms=st.if_rms, ref_if_rms=am.get_if_rms(),
+            if_agc=st.if_agc_gain, ref_if_agc=am.get_if_agc_current_gain(), af_agc=st.af_agc_gain,
+            ref_af_agc=am.get_af_agc_current_gain(), agc_iters=st.agc_iterations, agc_fallback=st.agc_fallback)
+    assert rms(ref) > 1e-3
+    assert err < 1e-6
+    assert st.if_rms == pytest.approx(am.get_if_rms(), rel=1e-5)
+    assert st.if_agc_gain == pytest.approx(am.get_if_agc_current_gain(), rel=1e-4)
+    assert st.af_agc_gain == pytest.approx(am.get_af_agc_current_gain(), rel=1e-6)
+    ch.close()
+
+
 def test_am_config3_full_chain(am_narrow):
     """Config 3: 384 kS/s IQ -> IfResampler(48 k) -> AmDecoder narrow."""
     x = siggen.am_iq(300 * 2048, 384e3)

@@ -118,3 +118,26 @@ def test_source_format_conversions():
     x = np.array([0.25 - 0.5j, 1e-3 + 7j], dtype=np.complex64)
     assert np.array_equal(ora.iq_convert(0, x.view(np.float32).reshape(-1, 2)), x)
 
+
+def test_ssb_oracle_sideband_selection(am_narrow):
+    """AmDecoder USB / LSB restatement: a tone 1 kHz above the carrier survives USB and is rejected by LSB (and the
+    mirror image), CW turns the carrier into a 500 Hz pitch (AmDecode.cpp:103-136)."""
+    from conftest import load_filter
+    fs, n = 48e3, 40 * 2048
+    t = np.arange(n) / fs
+    cw, ssb = load_filter("jj1bdx_cw_48khz_500hz"), load_filter("jj1bdx_ssb_48khz_1500hz")
+    up = (0.1 * np.exp(2j * np.pi * 1000 * t)).astype(np.complex64)
+
+    def run(mode, x):
+        am = ora.AmDecoder(am_narrow, mode, cw, ssb)
+        return np.concatenate([am.process(b) for b in siggen.blocks(x, 2048)])[-16384:], am.get_if_rms()
+
+    (usb, usb_if), (lsb, lsb_if) = run(ora.MODE_USB, up), run(ora.MODE_LSB, up)
+    assert usb_if == pytest.approx(0.1, rel=0.02)          # IF level after the sideband filter, before the AGCs
+    assert lsb_if < usb_if / 300.0
+    f = np.fft.rfftfreq(16384, 1 / fs)
+    assert abs(f[np.argmax(np.abs(np.fft.rfft(usb * np.hanning(16384))))] - 1000.0) < 6.0
+    carrier = (0.1 * np.ones(n)).astype(np.complex64)
+    pitch, _ = run(ora.MODE_CW, carrier)
+    assert abs(f[np.argmax(np.abs(np.fft.rfft(pitch * np.hanning(16384))))] - 500.0) < 6.0
+
