@@ -932,12 +932,13 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       HIPCHK(hipEventRecord(ev_if, stream));
       HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
     }
+    const int agc_nw = std::max(1, std::min(16, (agc_nc + 64 * FMR_AGC_PER_LANE - 1) / (64 * FMR_AGC_PER_LANE)));
     timed_on(as, "if_agc", [&] {
       for (int it = 0; it < K_AGC_ITERS; it++) {
         hipLaunchKernelGGL(k_agc_shoot<C_AGC>, dim3((agc_nc + 63) / 64, S), dim3(64), 0, as, xin, x_stride, x_off,
                            (int)N_if, d_gain.p, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            agc_init, agc_max, agc_rate, d_flags.p);
-        hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64), 0, as, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
+        hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64 * agc_nw), 0, as, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            d_state.p, d_flags.p, (int)(mode == FMR_MODE_FM || mode == FMR_MODE_NBFM));
       }
       hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,

@@ -396,11 +396,16 @@ __global__ void k_agc_shoot(const float2 *__restrict__ x, long long x_stride, in
 // consecutive chunk maps serially, one wave scan covers 512 chunks, then every lane
 // replays its 8 maps from its scanned start value.
 #define FMR_AGC_PER_LANE 8
-__global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, const float *__restrict__ G,
-                                                  const double *__restrict__ M, int nc, StreamState *st,
-                                                  IterFlags *fl, int gain_invariant) {
+__global__ __launch_bounds__(1024) void k_agc_nodes(float *__restrict__ nodes, const float *__restrict__ G,
+                                                    const double *__restrict__ M, int nc, StreamState *st,
+                                                    IterFlags *fl, int gain_invariant) {
+  // blockDim.x = 64 * NW: the NW waves take consecutive 64*K-chunk segments of a pass, scan their maps with an
+  // identity carry in parallel, chain the NW segment maps and replay with the true carries (as k_dc_nodes).
+  __shared__ double segA[16], segB[16];
+  __shared__ double pass_end;
+  __shared__ float wmax[16];
   const int s = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
   if (fl[s].agc_converged) return;
   float *nd = nodes + (long long)s * (nc + 1);
   const float *g = G + (long long)s * nc;
@@ -408,8 +413,8 @@ __global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, con
   constexpr int K = FMR_AGC_PER_LANE;
   double carry = (double)nd[0];   // v[0] is the carried state, fixed
   float maxrel = 0.f;
-  for (int c0 = 0; c0 < nc; c0 += 64 * K) {
-    const int cb = c0 + lane * K;
+  for (int c0 = 0; c0 < nc; c0 += 64 * K * NW) {
+    const int cb = c0 + (wv * 64 + lane) * K;
     double a[K], b[K];
     float oldn[K];
     // maps of this lane: v' = a v + b with b = G - a*old (old read before any write of this tile)
@@ -432,11 +437,14 @@ __global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, con
       const double pa = __shfl_up(sa, o, 64), pb = __shfl_up(sb, o, 64);
       if (lane >= o) { sb = sa * pb + sb; sa = sa * pa; }
     }
+    if (lane == 63) { segA[wv] = sa; segB[wv] = sb; }
+    __syncthreads();                          // segment maps published; all old values of the pass are in registers
+    double cw = carry;                        // carry entering my wave's segment
+    for (int u = 0; u < wv; u++) cw = segA[u] * cw + segB[u];
     // exclusive value = start of this lane's first chunk
     double ea = __shfl_up(sa, 1, 64), eb = __shfl_up(sb, 1, 64);
     if (lane == 0) { ea = 1.0; eb = 0.0; }
-    double v = ea * carry + eb;
-    __syncthreads();                          // all old values of the tile are in registers
+    double v = ea * cw + eb;
 #pragma unroll
     for (int j = 0; j < K; j++) {
       const int c = cb + j;
@@ -447,11 +455,19 @@ __global__ __launch_bounds__(64) void k_agc_nodes(float *__restrict__ nodes, con
         maxrel = fmaxf(maxrel, fabsf(vf - oldn[j]) / fmaxf(fabsf(vf), 1e-30f));
       }
     }
-    carry = (double)(float)(__shfl(sa, 63, 64) * carry + __shfl(sb, 63, 64));
+    if (wv == NW - 1 && lane == 63) pass_end = (double)(float)(sa * cw + sb);
+    __syncthreads();
+    carry = pass_end;
+    __syncthreads();
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) maxrel = fmaxf(maxrel, __shfl_xor(maxrel, o, 64));
-  if (lane == 0) {
+  if (lane == 0) wmax[wv] = maxrel;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int u = 1; u < NW; u++) maxrel = fmaxf(maxrel, wmax[u]);
+  if (threadIdx.x != 0) return;
+  {
     if (fl[s].agc_iters < 16) fl[s].agc_hist[fl[s].agc_iters] = maxrel;
     fl[s].agc_iters++;
     fl[s].agc_resid = maxrel;
