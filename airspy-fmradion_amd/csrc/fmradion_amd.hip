@@ -110,7 +110,7 @@ struct fmr_chain {
   hipEvent_t ev_fe[kPipe] = {};
   hipStream_t side = nullptr, side2 = nullptr;   // side2: the IF AGC when it is off the critical path
   hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr,
-             ev_tab = nullptr;
+             ev_tab = nullptr, ev_mono = nullptr;
   // designs + counters
   ResamplerDesign rs, ars;
   ResamplerCounter rsc, arsc;
@@ -206,6 +206,7 @@ struct fmr_chain {
     for (auto &b : d_if_pp) b.release();
     if (ev_agc) (void)hipEventDestroy(ev_agc);
     if (ev_tab) (void)hipEventDestroy(ev_tab);
+    if (ev_mono) (void)hipEventDestroy(ev_mono);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -279,6 +280,7 @@ int fmr_chain::init(const fmr_config *c) {
   HIPCHK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&ev_agc, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ev_tab, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ev_mono, hipEventDisableTiming));
   for (hipEvent_t *e : {&ev_disc, &ev_pll, &ev_stats, &ev_fin, &ev_if}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   const double dec_rate = (mode == FMR_MODE_FM || mode == FMR_MODE_NONE) ? kFmRate : kAmRate;
   has_rs = c->enable_resampler != 0;
@@ -975,6 +977,97 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     });
     HIPCHK(hipEventRecord(ev_stats, side));
     bool fin_on_side = false;
+    const int nch = stereo ? 2 : 1;
+    // ---------------------------------------------------- audio resampler + tail
+    const int count_am = (int)(arsc.mA - amA_prev);
+    const long long am_stride = H_am + (long long)max_amid;
+    const long long a1_stride = H_pc + (long long)max_au;
+    if ((size_t)count_am > max_amid || (size_t)N_au > max_au) { set_err("internal audio capacity exceeded"); return FMR_ERR_CAPACITY; }
+    const long long a_top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
+    // fused de-emphasis + stage A: the tile (warm-up + (TOUT-1) D + NA samples) must fit BLOCK * LPL LDS slots
+    constexpr int DE_BLOCK = 256, DE_SLOTS = DE_BLOCK * FMR_DE_LPL;
+    // at most 4 * DE_BLOCK outputs per tile: every lane then owns exactly one run of 4 outputs in the FIR phase
+    const int de_tout = std::min(4 * DE_BLOCK, ((DE_SLOTS - FMR_DE_WARMUP - ars.NA - ars.D) / ars.D) & ~3);
+    const bool de_fused = !serial_mode && de_tout >= 64;
+    const int dc_nc = (int)((N_au + C_DC - 1) / C_DC);
+    DcCoef dk{};
+    dk.b0 = dcblock.b0; dk.b1 = dcblock.b1; dk.b2 = dcblock.b2; dk.a1 = dcblock.a1; dk.a2 = dcblock.a2;
+    for (int j = 0; j < 4; j++) dk.ac[j] = dc_ac[j];
+    for (int lv = 0; lv < 6; lv++) for (int j = 0; j < 4; j++) dk.agp[lv][j] = dc_agp[lv][j];
+    // Per-channel part of the audio tail (de-emphasis + audio resampler + pilot cut + DC-block pass 1) for channels
+    // ch_base .. ch_base + nch_l - 1.  Channel 0 (mono = L+R) does not depend on the PLL: with stereo on it runs on
+    // the AGC stream while the PLL iterates, and only L-R stays behind the PLL on the decoder stream.
+    auto enqueue_tail_channels = [&](hipStream_t st, int ch_base, int nch_l) {
+      if (de_fused) {
+        if (count_am > 0) {
+          timed_on(st, "deemph_decim", [&] {
+            const int tiles = (count_am + de_tout - 1) / de_tout;
+            const size_t lds = sizeof(double) * (size_t)(DE_SLOTS + DE_SLOTS / 16 + 1);
+            auto go = [&](auto kern) {
+              hipLaunchKernelGGL(kern, dim3(tiles, S, nch_l), dim3(DE_BLOCK), lds, st, d_base.p, d_raw.p, base_stride, H_b,
+                                 (int)N_if, deemph.b0, deemph.a1, de_scan, 1, (int)(stereo && !pilot_shift), d_ahA.p,
+                                 ars.NA, ars.D, a_top0, count_am, de_tout, d_am0.p, d_am1.p, am_stride, H_am,
+                                 debug_taps ? d_base_de.p : (double *)nullptr,
+                                 debug_taps ? d_raw_de.p : (double *)nullptr, de_stride, H_a, ch_base);
+            };
+            if (ars.NA == 59 && ars.D == 3) go(k_deemph_decim<DE_BLOCK, 59, 3>);     // 384 kHz -> 48 kHz
+            else go(k_deemph_decim<DE_BLOCK, 0, 0>);
+          });
+        }
+      } else {
+        // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
+        timed_on(st, "deemph", [&] {
+          const int nt = (int)((N_if + C_DE - 1) / C_DE);
+          hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch_l), dim3(64), 0, st, d_base.p, d_raw.p,
+                             base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
+                             (int)(stereo && !pilot_shift));
+        });
+        if (count_am > 0) {
+          timed_on(st, "aud_decim", [&] {
+            hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch_l), dim3(128), 0, st, d_base_de.p,
+                               d_raw_de.p, de_stride, H_a, d_ahA.p, ars.NA, ars.D, a_top0, count_am, d_am0.p, d_am1.p,
+                               am_stride, H_am);
+          });
+        }
+      }
+      if (N_au > 0) {
+        timed_on(st, "aud_poly", [&] {
+          if (ars.LB == 3 && ars.MB == 8) {
+            // period form: one lane per period (3 outputs), taps through the scalar cache
+            constexpr int BLP = 256;
+            const long long P_first = akB_prev / 3, P_last = (akB_prev + N_au - 1) / 3;
+            const int tiles = (int)((P_last - P_first) / BLP + 1);
+            const int lx = (BLP - 1) * (int)ars.MB + (int)((2 * ars.MB) / 3) + ars.TB;
+            int ni_pad = (lx + (int)ars.MB - 1) / (int)ars.MB + 1;
+            if ((ni_pad & 1) == 0) ni_pad++;
+            hipLaunchKernelGGL((k_aud_poly2<BLP, 3, 8>), dim3(tiles, S, nch_l), dim3(BLP), sizeof(double) * (size_t)ars.MB * ni_pad,
+                               st, d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB,
+                               akB_prev, (int)N_au, d_a10.p, d_a11.p, a1_stride, H_pc, ni_pad, H_am + count_am, ch_base);
+          } else {
+            hipLaunchKernelGGL(k_aud_poly<128>, dim3((unsigned)((N_au + 127) / 128), S, nch_l), dim3(128), 0, st,
+                               d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB, (unsigned)ars.LB,
+                               (unsigned)ars.MB, (unsigned long long)akB_prev * ars.MB, (int)N_au, d_a10.p, d_a11.p,
+                               a1_stride, H_pc);
+          }
+        });
+        timed_on(st, "pilotcut", [&] {
+          if (n_pilotcut <= FMR_PCUT_MAXTAPS)
+            hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, nch_l), dim3(320), 0, st, d_a10.p, d_a11.p,
+                               a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au, 1.0, ch_base);
+          else
+            hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch_l), dim3(128), 0, st, d_a10.p, d_a11.p, a1_stride, H_pc,
+                               bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
+        });
+      }
+      if (N_au > 0 && !serial_mode)
+        timed_on(st, "dc_pass1", [&] {
+          hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch_l), dim3(64), 0, st, d_pc0.p, d_pc1.p,
+                             (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc, ch_base);
+        });
+    };
+    const bool split_mono = stereo && !serial_mode && de_fused && (ars.LB == 3 && ars.MB == 8) &&
+                            n_pilotcut <= FMR_PCUT_MAXTAPS && !getenv("FMR_NO_SPLIT");
+    bool mono_enqueued = false;
     if (stereo) {
       if (serial_mode) {
         timed("pll", [&] {
@@ -999,6 +1092,14 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                                  base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
                                  d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p,
                                  d_pll_wgr.p);
+            if (it == 0 && split_mono && agc_deferred) {
+              // side2: [after the first integration pass] mono tail, then the AGC
+              (void)hipEventRecord(ev_if, stream);
+              (void)hipStreamWaitEvent(side2, ev_if, 0);
+              enqueue_tail_channels(side2, 0, 1);
+              (void)hipEventRecord(ev_mono, side2);
+              mono_enqueued = true;
+            }
             if (it == 0 && agc_deferred) { agc_deferred = false; if (enqueue_agc()) return; }
             hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
                                (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
@@ -1033,77 +1134,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       }
     }
     if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc()) return rca; }   // PLL path not taken
-    const int nch = stereo ? 2 : 1;
-    // ---------------------------------------------------- audio resampler + tail
-    const int count_am = (int)(arsc.mA - amA_prev);
-    const long long am_stride = H_am + (long long)max_amid;
-    const long long a1_stride = H_pc + (long long)max_au;
-    if ((size_t)count_am > max_amid || (size_t)N_au > max_au) { set_err("internal audio capacity exceeded"); return FMR_ERR_CAPACITY; }
-    const long long a_top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
-    // fused de-emphasis + stage A: the tile (warm-up + (TOUT-1) D + NA samples) must fit BLOCK * LPL LDS slots
-    constexpr int DE_BLOCK = 256, DE_SLOTS = DE_BLOCK * FMR_DE_LPL;
-    const int de_tout = ((DE_SLOTS - FMR_DE_WARMUP - ars.NA - ars.D) / ars.D) & ~3;
-    const bool de_fused = !serial_mode && de_tout >= 64;
-    if (de_fused) {
-      if (count_am > 0) {
-        timed("deemph_decim", [&] {
-          const int tiles = (count_am + de_tout - 1) / de_tout;
-          const size_t lds = sizeof(double) * (size_t)(DE_SLOTS + DE_SLOTS / 16 + 1);
-          auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(tiles, S, nch), dim3(DE_BLOCK), lds, stream, d_base.p, d_raw.p, base_stride, H_b,
-                               (int)N_if, deemph.b0, deemph.a1, de_scan, 1, (int)(stereo && !pilot_shift), d_ahA.p,
-                               ars.NA, ars.D, a_top0, count_am, de_tout, d_am0.p, d_am1.p, am_stride, H_am,
-                               debug_taps ? d_base_de.p : (double *)nullptr,
-                               debug_taps ? d_raw_de.p : (double *)nullptr, de_stride, H_a);
-          };
-          if (ars.NA == 59 && ars.D == 3) go(k_deemph_decim<DE_BLOCK, 59, 3>);     // 384 kHz -> 48 kHz
-          else go(k_deemph_decim<DE_BLOCK, 0, 0>);
-        });
-      }
-    } else {
-      // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
-      timed("deemph", [&] {
-        const int nt = (int)((N_if + C_DE - 1) / C_DE);
-        hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch), dim3(64), 0, stream, d_base.p, d_raw.p,
-                           base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
-                           (int)(stereo && !pilot_shift));
-      });
-      if (count_am > 0) {
-        timed("aud_decim", [&] {
-          hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch), dim3(128), 0, stream, d_base_de.p,
-                             d_raw_de.p, de_stride, H_a, d_ahA.p, ars.NA, ars.D, a_top0, count_am, d_am0.p, d_am1.p,
-                             am_stride, H_am);
-        });
-      }
-    }
+    if (mono_enqueued) enqueue_tail_channels(stream, 1, 1);
+    else enqueue_tail_channels(stream, 0, nch);
+    if (mono_enqueued) HIPCHK(hipStreamWaitEvent(stream, ev_mono, 0));   // DC-block node pass needs both channels
     if (N_au > 0) {
-      timed("aud_poly", [&] {
-        if (ars.LB == 3 && ars.MB == 8) {
-          // period form: one lane per period (3 outputs), taps through the scalar cache
-          constexpr int BLP = 256;
-          const long long P_first = akB_prev / 3, P_last = (akB_prev + N_au - 1) / 3;
-          const int tiles = (int)((P_last - P_first) / BLP + 1);
-          const int lx = (BLP - 1) * (int)ars.MB + (int)((2 * ars.MB) / 3) + ars.TB;
-          int ni_pad = (lx + (int)ars.MB - 1) / (int)ars.MB + 1;
-          if ((ni_pad & 1) == 0) ni_pad++;
-          hipLaunchKernelGGL((k_aud_poly2<BLP, 3, 8>), dim3(tiles, S, nch), dim3(BLP), sizeof(double) * (size_t)ars.MB * ni_pad,
-                             stream, d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB,
-                             akB_prev, (int)N_au, d_a10.p, d_a11.p, a1_stride, H_pc, ni_pad, H_am + count_am);
-        } else {
-          hipLaunchKernelGGL(k_aud_poly<128>, dim3((unsigned)((N_au + 127) / 128), S, nch), dim3(128), 0, stream,
-                             d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB, (unsigned)ars.LB,
-                             (unsigned)ars.MB, (unsigned long long)akB_prev * ars.MB, (int)N_au, d_a10.p, d_a11.p,
-                             a1_stride, H_pc);
-        }
-      });
-      timed("pilotcut", [&] {
-        if (n_pilotcut <= FMR_PCUT_MAXTAPS)
-          hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, nch), dim3(320), 0, stream, d_a10.p, d_a11.p,
-                             a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au, 1.0);
-        else
-          hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch), dim3(128), 0, stream, d_a10.p, d_a11.p, a1_stride, H_pc,
-                             bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
-      });
       if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
       if (serial_mode) {
         timed("fm_out", [&] {
@@ -1113,14 +1147,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         });
       } else {
         // ---- DC block by linear multiple shooting + output mux
-        const int dc_nc = (int)((N_au + C_DC - 1) / C_DC);
-        DcCoef dk{};
-        dk.b0 = dcblock.b0; dk.b1 = dcblock.b1; dk.b2 = dcblock.b2; dk.a1 = dcblock.a1; dk.a2 = dcblock.a2;
-        for (int j = 0; j < 4; j++) dk.ac[j] = dc_ac[j];
-        for (int lv = 0; lv < 6; lv++) for (int j = 0; j < 4; j++) dk.agp[lv][j] = dc_agp[lv][j];
         timed("fm_out", [&] {
-          hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
-                             (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc);
           const int dc_nw = std::max(1, std::min(16, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
           hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
                              d_state.p, S, nch);
@@ -1160,7 +1187,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     timed("nbfm_audio", [&] {
       hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, 1), dim3(320), 0, stream, d_base.p, (double *)nullptr,
                          base_stride, H_b, bt, d_pilotcut.p, n_pilotcut, d_aud, (double *)nullptr, (long long)astride,
-                         0.70794578438413791);          // std::pow(10.0, -3.0 / 20.0), NbfmDecode.cpp:91
+                         0.70794578438413791, 0);       // std::pow(10.0, -3.0 / 20.0), NbfmDecode.cpp:91
     });
     add_halo(ifbuf, if_stride, H_if, N_if);
     add_halo(d_base.p, base_stride, H_b, N_if);

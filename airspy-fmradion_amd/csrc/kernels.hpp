@@ -1313,9 +1313,10 @@ template <int BLOCK, int LBT, int MB>
 __global__ __launch_bounds__(BLOCK) void k_aud_poly2(
     const double *__restrict__ m0, const double *__restrict__ m1, long long m_stride, long long mid_abs0,
     const double *__restrict__ hB, int TB, long long k0, int count,
-    double *__restrict__ y0, double *__restrict__ y1, long long y_stride, int y_off, int ni_pad, int mid_valid) {
+    double *__restrict__ y0, double *__restrict__ y1, long long y_stride, int y_off, int ni_pad, int mid_valid,
+    int ch_base) {
   extern __shared__ __attribute__((aligned(16))) double lds_ap[];
-  const int s = blockIdx.y, ch = blockIdx.z;
+  const int s = blockIdx.y, ch = blockIdx.z + ch_base;
   const int tid = threadIdx.x;
   const double *mid = (ch ? m1 : m0) + (long long)s * m_stride;
   double *y = (ch ? y1 : y0) + (long long)s * y_stride + y_off;
@@ -1413,10 +1414,10 @@ template <int BLOCK, int TILE>
 __global__ __launch_bounds__(BLOCK) void k_pilotcut2(
     const double *__restrict__ a0, const double *__restrict__ a1, long long a_stride, int a_halo,
     BlockTab bt, const double *__restrict__ coeff, int ntaps,
-    double *__restrict__ p0, double *__restrict__ p1, long long p_stride, double out_gain) {
+    double *__restrict__ p0, double *__restrict__ p1, long long p_stride, double out_gain, int ch_base) {
   __shared__ double cs[FMR_PCUT_MAXTAPS];
   __shared__ double xs[TILE + FMR_PCUT_MAXTAPS];
-  const int b = blockIdx.x, s = blockIdx.y, ch = blockIdx.z;
+  const int b = blockIdx.x, s = blockIdx.y, ch = blockIdx.z + ch_base;
   const int n = bt.au_len[b];
   if (n == 0) return;
   const double *x = (ch ? a1 : a0) + (long long)s * a_stride + a_halo + bt.au_off[b];
@@ -1436,9 +1437,10 @@ __global__ __launch_bounds__(BLOCK) void k_pilotcut2(
         for (int j = i + 1; j <= order; j++) acc += xc[-j] * cs[j];
         for (int j = 1; j <= i; j++) acc += xc[-j] * cs[j];
       } else {
+        // body taps are wave-uniform: scalar loads, not LDS traffic (the kernel is LDS-bandwidth bound)
 #pragma unroll 8
-        for (int k = 0; k <= half_order; k++) acc += (xc[-k] + xc[-(order - k)]) * cs[k];
-        if ((order % 2) == 0) acc += xc[-(order / 2)] * cs[order / 2];
+        for (int k = 0; k <= half_order; k++) acc += (xc[-k] + xc[-(order - k)]) * coeff[k];
+        if ((order % 2) == 0) acc += xc[-(order / 2)] * coeff[order / 2];
       }
       y[i] = acc * out_gain;     // 1.0 for the FM pilot cut (exact); NbfmDecoder's -3 dB (Utility.h:307-312)
     }

@@ -100,10 +100,10 @@ __global__ __launch_bounds__(BLOCK) void k_deemph_decim(
     double b0, double a1, DeScan sc, int filt0, int filt1,
     const double *__restrict__ hA, int NA, int D, long long top0, int count, int tout,
     double *__restrict__ y0, double *__restrict__ y1, long long y_stride, int y_off,
-    double *__restrict__ dbg0, double *__restrict__ dbg1, long long dbg_stride, int dbg_off) {
+    double *__restrict__ dbg0, double *__restrict__ dbg1, long long dbg_stride, int dbg_off, int ch_base) {
   extern __shared__ double de_xs[];
   __shared__ double wave_tot[BLOCK / 64];
-  const int s = blockIdx.y, ch = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = blockIdx.y, ch = blockIdx.z + ch_base, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int m0 = blockIdx.x * tout;
   const int cnt = min(tout, count - m0);
   if (cnt <= 0) return;
@@ -197,9 +197,9 @@ struct DcCoef {
 
 template <int C>
 __global__ void k_dc_pass1(const double *__restrict__ p0, const double *__restrict__ p1, long long p_stride, int n,
-                           DcCoef k, double *__restrict__ G, int nc) {
+                           DcCoef k, double *__restrict__ G, int nc, int ch_base) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const int s = blockIdx.y, ch = blockIdx.z;
+  const int s = blockIdx.y, ch = blockIdx.z + ch_base;
   if (c >= nc) return;
   const double *p = (ch ? p1 : p0) + (long long)s * p_stride;
   const int start = c * C, end = min(start + C, n);
