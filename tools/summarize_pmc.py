@@ -10,15 +10,15 @@ def per_kernel(fn):
         if "fmr::" not in r["Kernel_Name"]:
             continue
         n = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        a = agg.setdefault(n, [0, 0.0])
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
-    return {k: v[1] / v[0] for k, v in agg.items()}
+        agg.setdefault(n, []).append(float(r["Counter_Value"]))
+    # median over launches: the bench's set-up call is cut in two shorter launches (cold start), every other
+    # launch has the full batch
+    return {k: sorted(v)[len(v) // 2] for k, v in agg.items()}
 
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
-       "blocks_per_step": blocks, "units": "bytes per launch",
+       "blocks_per_step": blocks, "units": "bytes per launch (median over launches)",
        "correction": "read bytes = 2 * FETCH_SIZE * 1024 (gfx950 wide-read under-count), write bytes = WRITE_SIZE * 1024",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
