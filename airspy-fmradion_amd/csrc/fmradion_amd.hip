@@ -132,6 +132,7 @@ struct fmr_chain {
   unsigned ft_index = 0;                 // FineTuner::m_index, the same for every tuner of the chain
   double af_ref = 0.6, af_rate = 0.001;  // AfSimpleAgc reference / rate (AmDecode.cpp:54-66)
   int in_fmt = 0, in_bps = 8;          // source sample format (fmr_config.input_format) and its bytes per IQ sample
+  int decim_bl = 128;
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
   DevBuf<float> d_afrag;               // v4: constant A fragments
@@ -394,6 +395,7 @@ int fmr_chain::init(const fmr_config *c) {
   if ((rc = d_if.alloc((size_t)S * (H_if + max_if)))) return rc;
   last_if = d_if.p;
   { const char *e = getenv("FMR_HOST_PROF"); host_prof = e && e[0] == '1'; }
+  { const char *e = getenv("FMR_DECIM_BL"); if (e && atoi(e) == 256) decim_bl = 256; }
   { const char *e = getenv("FMR_DEBUG_TAPS"); debug_taps = e && e[0] == '1'; }
   { const char *e = getenv("FMR_PLL_RTOL"); if (e && e[0]) pll_rtol = atof(e); }
   { const char *e = getenv("FMR_PLL_JAC"); if (e && e[0] >= '1' && e[0] <= '9') pll_jac_rounds = e[0] - '0'; }
@@ -713,11 +715,15 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                            (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), cfg.enable_fourth_down);
       };
       const size_t per_out = sizeof(float2) * (size_t)rs.D, tail = sizeof(float2) * (size_t)(rs.NA - 1);
-      constexpr int BL2 = 128, T2 = 2 * BL2;
-      int s_pad = T2 + 16;
-      while ((s_pad & 15) != 2) s_pad++;
-      const size_t lds2 = sizeof(float2) * ((size_t)rs.D * s_pad + 2);   // + the spare slot
-      if (qa == 16 && lds2 <= 64000 && (size_t)rs.D * (T2 + 16) <= (size_t)2 * 16 * BL2) {
+      // v2 kernel, 128 (default) or 256 lanes per workgroup (FMR_DECIM_BL=256: half the tile-halo over-fetch, twice the
+      // LDS per workgroup)
+      bool v2_done = false;
+      auto launch_decim2 = [&](auto bl_tag) {
+        constexpr int BL2 = decltype(bl_tag)::value, T2 = 2 * BL2;
+        int s_pad = T2 + 16;
+        while ((s_pad & 15) != 2) s_pad++;
+        const size_t lds2 = sizeof(float2) * ((size_t)rs.D * s_pad + 2);   // + the spare slot
+        if (!(qa == 16 && lds2 <= 64000 && (size_t)rs.D * (T2 + 16) <= (size_t)2 * 16 * BL2)) return;
         const unsigned magic = (unsigned)((1u << 24) / (unsigned)rs.D + 1);
         const dim3 grid2((count_mid + T2 - 1) / T2, S);
         timed_on(fes, "ifr_decim", [&] {
@@ -735,6 +741,11 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
           default: f4 ? go(k_ifr_decim2<BL2, 16, 0, true>) : go(k_ifr_decim2<BL2, 16, 0, false>); break;
           }
         });
+        v2_done = true;
+      };
+      if (decim_bl == 256) launch_decim2(std::integral_constant<int, 256>{});
+      if (!v2_done) launch_decim2(std::integral_constant<int, 128>{});
+      if (v2_done) {
       } else if (in_fmt != 0) {
         set_err("input_format != cf32 needs the v2 front-end kernel (decimation ratio out of its range)");
         return FMR_ERR_UNSUPPORTED;
