@@ -59,7 +59,7 @@ constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
 constexpr int C_AGC = 256, C_DC = 64, C_DE = 256;
 constexpr int C_PLL_MIN = 64;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
-constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 5;
+constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 4;   // PLL: 2 rounds in lock, 2 spare (each unused round costs ~18 us of launches)
 
 template <class T>
 struct DevBuf {
@@ -539,8 +539,7 @@ int fmr_chain::init(const fmr_config *c) {
       if ((rc = d_pll_PQ2.alloc((size_t)S * max_grp2 * 56))) return rc;
       if ((rc = d_pll_dstart2.alloc((size_t)S * max_grp2 * 7))) return rc;
     }
-    c_pll = ((c_pll + 63) / 64) * 64;
-    mask_words = c_pll / 64;
+    mask_words = (std::max(c_pll, 128) + 63) / 64;   // wrap bit masks: one word per 64 samples of a chunk
     if ((rc = d_ck_mask.alloc((size_t)S * max_ck * mask_words))) return rc;
     if ((rc = d_blk_wraps.alloc((size_t)S * max_blocks))) return rc;
     if ((rc = d_blk_level.alloc((size_t)S * max_blocks))) return rc;
