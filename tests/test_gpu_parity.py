@@ -493,6 +493,49 @@ def test_cold_first_call_is_split(pilotcut):
     ch.close()
 
 
+def test_randomised_block_partition(pilotcut):
+    """Seeded random block lengths (1 .. 65536) and batch sizes over ~3.3 s of 10 MS/s FM stereo, two streams: the
+    chain must equal block-by-block process() calls whatever the partition (count law, halos, tile edges)."""
+    rng = np.random.default_rng(20260927)
+    lens = []
+    while sum(lens) < 33_000_000:
+        r = rng.random()
+        lens.append(int(rng.integers(1, 300)) if r < 0.15 else int(rng.integers(300, 65537)))
+    n = sum(lens)
+    xs = np.stack([siggen.fm_stereo_iq(n, 10e6, stream_id=s) for s in range(2)])
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, n_streams=2,
+                   max_block_len=65536, max_blocks=64)
+    got = [[], []]
+    alens = []
+    i = pos = 0
+    while i < len(lens):
+        k = int(rng.integers(1, 65))
+        ll = lens[i:i + k]
+        m = sum(ll)
+        a, alen = ch.process_blocks(xs[:, pos:pos + m], ll)
+        for s in range(2):
+            got[s].append(a[s])
+        alens += list(alen)
+        i += k
+        pos += m
+    for s in range(2):
+        r = ora.IfResampler(10e6, 384e3)
+        fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
+        ref, o = [], 0
+        for bl in lens:
+            ref.append(fm.process(r.process(xs[s, o:o + bl])))
+            o += bl
+        if s == 0:
+            assert alens == [len(q) for q in ref]
+        ref, g = np.concatenate(ref), np.concatenate(got[s])
+        assert len(g) == len(ref)
+        err = rms(g - ref)
+        _report(f"random_partition_{s}", audio_rms_err=err, n=len(ref), blocks=len(lens))
+        assert err < 1e-5
+        assert ch.status(s).stereo_detected == int(fm.stereo_detected()) == 1
+    ch.close()
+
+
 def test_multi_stream_batch(pilotcut):
     """Three independent streams in one chain (the sharding unit of config 5)."""
     S, nblk, blk = 3, 12, 65536
