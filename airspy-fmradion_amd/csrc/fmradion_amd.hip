@@ -964,7 +964,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   }
   if (mode == FMR_MODE_FM) {
     if (any_mpf) {
-      const size_t lds = sizeof(float2) * ((size_t)2 * mpf_N + FMR_MPF_CH);
+      const size_t lds = sizeof(float2) * ((size_t)2 * mpf_N + FMR_MPF_CH + 4);
       timed("mpf", [&] {
         hipLaunchKernelGGL(k_mpf, dim3(S), dim3(64), lds, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
                            bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,

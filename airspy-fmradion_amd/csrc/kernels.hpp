@@ -867,6 +867,22 @@ __device__ __forceinline__ float2 wave_sum2(float2 v) {
   return v;
 }
 
+// Wave sum without the LDS crossbar: four DPP steps sum each row of 16 lanes (quad_perm xor 1, xor 2, then the
+// row_half_mirror / row_mirror pairings), four v_readlane add the rows.  Every lane returns the total.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp_add = [](float x, auto ctrl) {
+    constexpr int C = decltype(ctrl)::value;
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), C, 0xF, 0xF, true));
+  };
+  v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  auto rl = [](float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); };
+  const float r0 = rl(v, 0), r1 = rl(v, 16), r2 = rl(v, 32), r3 = rl(v, 48);
+  return (r0 + r1) + (r2 + r3);
+}
+
 __global__ __launch_bounds__(64) void k_mpf(
     const float2 *__restrict__ xin, long long x_stride, int x_off,
     const float *__restrict__ gain, long long g_stride, BlockTab bt,
@@ -903,34 +919,57 @@ __global__ __launch_bounds__(64) void k_mpf(
         const float g = gs[off + c0 + i];
         xw[N + i] = make_float2(v.x * g, v.y * g);
       }
+      if (lane < 4) xw[N + cn + lane] = make_float2(0.f, 0.f);      // slack read by the last (partial) group
       __syncthreads();
       int pushed = 0;
-      for (int q = 0; q < cn; q++) {
-        // state after the push = xw[q+1 .. q+N]; y = sum state[i]*coeff[i] (V9)
-        float2 acc = make_float2(0.f, 0.f);
+      // The taps only change after every fourth sample of a block (MultipathFilter.cpp:176,186), so the outputs
+      // idx+1 .. idx+4 behind an update at idx share their coefficients: their dot products and wave reductions run
+      // together (one reduction latency per four samples), then the update at idx+4 follows.
+      int q = 0;
+      while (q < cn) {
+        const int jg = c0 + q;                                  // index inside the block
+        const int glen = min(((jg + 3) & ~3) - jg + 1, cn - q);  // up to and including the next update sample
+        float2 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = make_float2(0.f, 0.f);
+        // state after the push of sample q+t = xw[q+t+1 .. q+t+N]; y = sum state[i]*coeff[i] (V9)
         for (int i = lane; i < N; i += 64) {
-          const float2 sv = xw[q + 1 + i], cv = c[i];
-          acc.x = fmaf(sv.x, cv.x, acc.x); acc.x = fmaf(-sv.y, cv.y, acc.x);
-          acc.y = fmaf(sv.x, cv.y, acc.y); acc.y = fmaf(sv.y, cv.x, acc.y);
+          const float2 cv = c[i];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const float2 sv = xw[q + 1 + t + i];                // beyond the group: staged samples or the zeroed slack, unused
+            acc[t].x = fmaf(sv.x, cv.x, acc[t].x); acc[t].x = fmaf(-sv.y, cv.y, acc[t].x);
+            acc[t].y = fmaf(sv.x, cv.y, acc[t].y); acc[t].y = fmaf(sv.y, cv.x, acc[t].y);
+          }
         }
-        const float2 y = wave_sum2(acc);
-        pushed = q + 1;
-        if (!isfinite(y.x) || !isfinite(y.y)) { ok = 0; break; }   // :182-184
-        if (lane == 0) os[off + c0 + q] = y;
-        if ((((c0 + q) & 3) == 0)) {                                // :176,186
+#pragma unroll
+        for (int t = 0; t < 4; t++) { acc[t].x = wave_sum_dpp(acc[t].x); acc[t].y = wave_sum_dpp(acc[t].y); }
+        int bad = -1;
+#pragma unroll
+        for (int t = 3; t >= 0; t--)
+          if (t < glen && (!isfinite(acc[t].x) || !isfinite(acc[t].y))) bad = t;   // first non-finite output
+        if (bad >= 0) { pushed = q + bad + 1; ok = 0; break; }                      // :182-184
+        pushed = q + glen;
+        if (lane < glen) {
+          const float2 yv = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+          os[off + c0 + q + lane] = yv;
+        }
+        const int qlast = q + glen - 1;
+        if ((((c0 + qlast) & 3) == 0)) {                        // :176,186
+          const float2 y = glen == 1 ? acc[0] : glen == 2 ? acc[1] : glen == 3 ? acc[2] : acc[3];
           const double env = (double)(y.x * y.x + y.y * y.y);
           const double error = 1.0 - env;
           float ms = 0.f;
           for (int i = lane; i < N; i += 64) {
-            const float2 sv = xw[q + 1 + i];
+            const float2 sv = xw[qlast + 1 + i];
             ms += sv.x * sv.x + sv.y * sv.y;
           }
-          const float sum = wave_sum(ms);
+          const float sum = wave_sum_dpp(ms);
           const float mu = (float)(0.1 / ((double)sum + 1e-10));   // :130
           const float factor = (float)(error * (double)mu);         // :133
           const float fr = factor * y.x, fi = factor * y.y;
-          for (int i = lane; i < N; i += 64) {                       // V10
-            const float2 sv = xw[q + 1 + i];
+          for (int i = lane; i < N; i += 64) {                       // V10: lane i only ever touches its own taps
+            const float2 sv = xw[qlast + 1 + i];
             float2 cv = c[i];
             cv.x += sv.x * fr + sv.y * fi;
             cv.y += sv.x * fi - sv.y * fr;
@@ -938,9 +977,9 @@ __global__ __launch_bounds__(64) void k_mpf(
             c[i] = cv;
           }
           err_last = error;
-          __syncthreads();
           if (!isfinite(error)) { ok = 0; break; }                   // :190-192
         }
+        q += glen;
       }
       // new state = last N entries pushed so far
       __syncthreads();

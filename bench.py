@@ -88,6 +88,8 @@ def main():
                     help="65536-sample blocks per step (2048 = 2^27 samples = 1 GiB of IQ, SURVEY.md 8d)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multipath-stages", type=int, default=0,
+                    help="configs[3]: FM stereo with the MultipathFilter equaliser (-E N); 0 = configs[1], the headline")
     ap.add_argument("--input-format", choices=["cf32", "s16", "u8"], default="cf32",
                     help="source sample format the front-end kernel reads (the headline metric is cf32)")
     ap.add_argument("--no-region-events", action="store_true",
@@ -122,7 +124,8 @@ def main():
     elif fmt == 2:    # RTL-SDR offset binary
         iq = (torch.round(iq / 0.3 * 0.8 * 127.0) + 128).to(torch.uint8).contiguous()
     ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=FS, enable_resampler=True, stereo=True, n_streams=S,
-                   max_block_len=BLK, max_blocks=B, device=local_rank, input_format=fmt)
+                   max_block_len=BLK, max_blocks=B, device=local_rank, input_format=fmt,
+                   multipath_stages=args.multipath_stages)
     block_len = [BLK] * B
     torch.cuda.synchronize()
 
@@ -195,8 +198,9 @@ def main():
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 front end / f64 after the discriminator", "data": "synthetic",
-            "config": {"workload": "configs[1]: single FM stereo stream per GPU, 10 MS/s complex-float IQ in HBM, "
-                                   "PilotPhaseLock on, IfResampler+FmDecoder -> f64 stereo 48 kHz",
+            "config": {"workload": ("configs[1]: single FM stereo stream per GPU, 10 MS/s complex-float IQ in HBM, "
+                                    "PilotPhaseLock on, IfResampler+FmDecoder -> f64 stereo 48 kHz") if not args.multipath_stages
+                       else f"configs[3]: as configs[1] with the MultipathFilter equaliser -E {args.multipath_stages}",
                        "input_format": args.input_format, "streams_per_gpu": S, "blocks_per_step": B, "block_len": BLK,
                        "samples_per_step_per_gpu": S * n, "per_gpu_msps": round(value / world, 3),
                        "resampler": ch.resampler_info()},
