@@ -82,8 +82,8 @@ def cpu_baseline(target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--blocks", type=int, default=2048,
                     help="65536-sample blocks per step (2048 = 2^27 samples = 1 GiB of IQ, SURVEY.md 8d)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU")
