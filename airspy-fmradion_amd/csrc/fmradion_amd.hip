@@ -939,7 +939,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     // With the PLL on, the side-stream AGC starts only after the PLL's first (Jacobian) integration pass: that
     // pass runs one wave per SIMD and every co-resident AGC wave stretches it (measured 118 -> 160 us).
     agc_deferred = agc_aside && stereo && !getenv("FMR_AGC_EARLY");
-    enqueue_agc = [=, &disc_gain, &agc_on_side]() -> int {
+    enqueue_agc = [=]() -> int {
     if (agc_aside) {
       HIPCHK(hipEventRecord(ev_if, stream));
       HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
