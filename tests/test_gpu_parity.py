@@ -493,6 +493,34 @@ def test_cold_first_call_is_split(pilotcut):
     ch.close()
 
 
+@pytest.mark.parametrize("pilot,sigma,amp", [(0.04, 1e-3, 0.3), (0.10, 3e-2, 0.3), (0.10, 1e-3, 0.02)])
+def test_fm_stereo_hard_signals(pilot, sigma, amp, pilotcut):
+    """Weak pilot (4 %), 20 dB carrier-to-noise, and a weak carrier (AGC near 50x): the time-parallel PLL / AGC must
+    either converge or fall back, and match the serial oracle either way; with these inputs no fallback is needed."""
+    nblk, blk, batch = 120, 65536, 30
+    x = siggen.fm_stereo_iq(nblk * blk, 10e6, amplitude=amp, sigma=sigma, pilot=pilot)
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=batch)
+    r = ora.IfResampler(10e6, 384e3)
+    fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
+    got, ref, its = [], [], []
+    for i in range(0, nblk, batch):
+        seg = x[i * blk:(i + batch) * blk]
+        a, alen = ch.process_blocks(seg[None, :], [blk] * batch)
+        got.append(a[0])
+        ref += [fm.process(r.process(b)) for b in siggen.blocks(seg, blk)]
+        st = ch.status()
+        its.append((st.pll_iterations, st.pll_fallback, st.agc_iterations, st.agc_fallback))
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    assert len(got) == len(ref)
+    err = rms(got - ref)
+    st = ch.status()
+    _report(f"fm_hard_p{pilot}_s{sigma}_a{amp}", audio_rms_err=err, audio_rms=rms(ref), rounds=its, locked=st.stereo_detected,
+            ref_locked=int(fm.stereo_detected()), pilot=st.pilot_level, ref_pilot=fm.get_pilot_level())
+    assert st.stereo_detected == int(fm.stereo_detected())
+    assert err < 1e-5
+    assert all(f == 0 for _, f, _, _ in its[1:]), its     # after the first (cold) call no serial PLL fallback
+
+
 def test_randomised_block_partition(pilotcut):
     """Seeded random block lengths (1 .. 65536) and batch sizes over ~3.3 s of 10 MS/s FM stereo, two streams: the
     chain must equal block-by-block process() calls whatever the partition (count law, halos, tile edges)."""
