@@ -114,7 +114,16 @@ __global__ __launch_bounds__(BLOCK) void k_deemph_decim(
   if (dbg && blockIdx.x == gridDim.x - 1) hi = n_if - 1;    // debug tap: cover the call to its last sample
   const long long r0 = lo - FMR_DE_WARMUP;
   const int n_t = (int)(hi - r0 + 1);                       // <= BLOCK * FMR_DE_LPL (host-checked)
-  for (int j = tid; j < BLOCK * FMR_DE_LPL; j += BLOCK) de_xs[de_idx(j)] = (j < n_t) ? x[r0 + j] : 0.0;
+  {   // all FMR_DE_LPL loads of a lane are in flight before the first LDS write (one memory latency per tile)
+    double stage[FMR_DE_LPL];
+#pragma unroll
+    for (int u = 0; u < FMR_DE_LPL; u++) {
+      const int j = tid + u * BLOCK;
+      stage[u] = (j < n_t) ? x[r0 + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < FMR_DE_LPL; u++) de_xs[de_idx(tid + u * BLOCK)] = stage[u];
+  }
   __syncthreads();
   if (ch ? filt1 : filt0) {
     double *mine = de_xs + tid * (FMR_DE_LPL + 1);
