@@ -762,7 +762,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       timed_on(fes, "ifr_poly", [&] {
         if (poly4)
           hipLaunchKernelGGL((k_ifr_poly4<48, 125, 210>), dim3(std::min(tiles, 512), S), dim3(256),
-                             sizeof(float2) * (size_t)(poly2_tile + 4 * 8 * 48), fes, d_mid.p,
+                             sizeof(float2) * (size_t)(((poly2_tile + 127) / 128) * 128 + 4 * 8 * 48), fes, d_mid.p,
                              (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag.p, kB_prev,
                              (int)N_if, ifbuf, (long long)(H_if + max_if), H_if, poly2_tile, tiles);
         else if (poly3)

@@ -589,7 +589,8 @@ __global__ __launch_bounds__(256, 2) void k_ifr_poly4(
   static_assert(LB == 48, "three 16-row tiles");
   typedef float v4f __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float2 lds_b4[];
-  float2 *stage = lds_b4 + tile_len;                         // 4 waves x (8 periods x LB) float2
+  const int x_len = ((tile_len + 127) / 128) * 128;          // the x region holds whole 1 KB wave chunks
+  float2 *stage = lds_b4 + x_len;                            // 4 waves x (8 periods x LB) float2
   const int s = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
@@ -607,6 +608,15 @@ __global__ __launch_bounds__(256, 2) void k_ifr_poly4(
     const long long P0 = k0 / LB + (long long)tile * 64;
     const long long a0 = P0 * MB - W + 1;
     __syncthreads();                                          // previous tile fully consumed
+    const long long src0 = a0 - mid_abs0;
+    if (src0 >= 0 && src0 + x_len <= mid_valid) {
+      // interior tile: direct global -> LDS copies (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16 B), all
+      // of a wave's ~17 chunks in flight at once and no staging registers; edge tiles need the zero fill below
+      const float2 *src = ms + src0;
+      for (int c = wave; c < x_len / 128; c += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c * 128 + lane * 2),
+                                         (__attribute__((address_space(3))) void *)(lds_b4 + c * 128), 16, 0, 0);
+    } else
     for (int i0 = 0; i0 < tile_len; i0 += 8 * 256) {
       float2 v[8];
 #pragma unroll
