@@ -68,7 +68,8 @@ class PpsEvent(C.Structure):
 
 def build_library(force=False, verbose=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    deps = [SRC] + [os.path.join(_DIR, "csrc", f) for f in ("kernels.hpp", "design.hpp", "filter_tables.inc")]
+    import glob
+    deps = sorted(glob.glob(os.path.join(_DIR, "csrc", "*")))      # every header of the translation unit
     deps.append(os.path.join(os.path.dirname(_DIR), "include", "fmradion_amd.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH

@@ -214,7 +214,10 @@ struct fmr_chain {
   // ---- kernel launch with optional HIP-event timing on the chain's stream ----
   template <class F>
   void timed_on(hipStream_t st, const char *name, F &&launch) {
-    if (timing == 2 && std::strcmp(name, "ifr_decim") == 0) {
+    // mode 2: only the kernels of the FIR+discriminator stage carry events (two per kernel per call)
+    const bool stage_kernel = std::strcmp(name, "ifr_decim") == 0 || std::strcmp(name, "ifr_poly") == 0 ||
+                              std::strcmp(name, "disc") == 0 || std::strcmp(name, "ifr_fused") == 0;
+    if (timing == 2 && stage_kernel) {
       KernelTime kt{name, nullptr, nullptr};
       (void)hipEventCreate(&kt.a);
       (void)hipEventCreate(&kt.b);

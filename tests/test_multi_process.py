@@ -56,3 +56,27 @@ def test_two_ranks_shard_streams_without_exchange():
     assert t0 == t1 == 2.0                    # max over ranks
     assert tot0 == tot1 == 2 * 4 * 65536      # whole-job sample count = sum over ranks (weak scaling)
     assert rms0 == pytest.approx(rms1, rel=1e-3)
+
+
+def test_bench_launch_contract_two_ranks_gloo():
+    """bench.py under the driver's own launcher (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py
+    --gpus 2`) with the --cpu-dry-run hook: RANK / WORLD_SIZE / MASTER_* from the env, barrier on both sides of the
+    timed region, max over ranks, ONE JSON line from rank 0 with the whole-job aggregate.  (The HIP step itself needs
+    a GPU; N > 1 GPUs are only available to the driver.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--streams", "2", "--cpu-dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    # whole-job aggregate: 2 ranks x 2 streams x 2 blocks x 65536 samples x 2 steps
+    assert out["config"]["samples_per_step_per_gpu"] == 2 * 2 * 65536
+    assert out["value"] == pytest.approx(2 * 2 * 2 * 65536 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6, rel=1e-2)
+    assert "DRY RUN" in out["data"]
