@@ -1,0 +1,517 @@
+// kernels_fused.hpp -- the fused front end: IfResampler stage A -> stage B -> PhaseDiscriminator in ONE
+// persistent, wave-specialised kernel, so that the 1 MHz `mid` signal (and, with the discriminator epilogue, the
+// 384 kHz IF's second read) never goes through HBM.  Rows a1 + a7 (+ a3/a8 partial sums) of SURVEY.md 8a:
+// sfmbase/IfResampler.cpp:37-78, sfmbase/PhaseDiscriminator.cpp:33-46, sfmbase/FmDecode.cpp:95,141-150.
+//
+// Shape: source rates whose stage A lands on 1 MHz with D = 2 (mod 4) -- 10 MS/s (D = 10, NA = 151) and
+// 6 MS/s -- followed by the LB/MB = 48/125, TB = 210 polyphase stage (the k_ifr_poly4 shape).
+//
+// One 512-lane workgroup per CU owns a CONTIGUOUS run of "macro tiles" (8 periods of stage B = 384 IF samples
+// = 1000 mid samples = 10 000 input samples) of one stream and walks it in EPOCHS of a quarter macro tile
+// (250 mid samples, 2 500 input samples, 20 KB).  Wave roles (one s_barrier per epoch, nothing else synchronises):
+//   wave 0      loader   : LDS-DMA (global_load_lds_dwordx4) of the input region of epoch e+4 into a 5-slot ring,
+//                          60-80 KB in flight per CU; it never reads LDS, so the compiler puts no wait in its
+//                          path and its loads stay in flight across the barriers (s_waitcnt vmcnt(63) by hand)
+//   waves 4..7  stage A  : one output per lane out of the natural-order slot: lane stride D / 2 = 5 sixteen-byte
+//                          words (odd => conflict-free ds_read_b128), two packed FMAs per word, the 76 distinct
+//                          taps of the symmetric filter live in VGPRs; results go to a 3-window `mid` ring in LDS
+//   waves 1, 2  stage B  : the 48 x 332 banded polyphase matrix as v_mfma_f32_16x16x4_f32 (rows = 16 positions,
+//                          columns = 8 periods x (re, im)); wave 1 holds row tiles 0-1, wave 2 row tile 2; the 83
+//                          k-steps of a macro tile are spread over the four epochs that follow its last input
+//   wave 3      epilogue : IF samples of the finished macro tile: atan2 / wrapped difference (the
+//                          discriminator), float -> double widening, per-block partial sums, coalesced stores
+// Arithmetic: every stage-A output is two fp32 FMA chains (even / odd samples of the window) in tap order; stage B
+// is bit-identical to k_ifr_poly4 (an f32 MFMA is a k-ordered fmaf chain).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fmr {
+
+// Per-block statistics travel as partial sums over the 128 IF samples a stage-B wave finishes at a time, cut at the
+// (at most one) block boundary inside them; k_fused_blk_reduce adds the pieces of a block in index order.
+struct FusedPart {
+  int blk[2];            // block of the samples before / after the cut (-1: none)
+  float sum[2][3];       // sum d, sum d^2 (discriminator output), sum |x|^2 (IF) of each piece
+};
+
+// Everything is call-relative and 32-bit on the device: the host folds the absolute stream positions into a few
+// reference values of the call's first epoch (E_ref = 4 T_first - 1).
+struct FusedArgs {
+  const float2 *iq; long long iq_stride; long long n_valid;   // this call's input (per stream: iq + s * iq_stride)
+  const float2 *in_halo; int H_in;                            // last H_in input samples of the previous call
+  long long nbase;            // region start (local input index, even) of an epoch whose first output is j = 0:
+                              //   nb(E) = nbase + D * jE(E),  nbase = n0 + ca - (NA - 1) - par
+  int j_ref;                  // jE(E_ref): call-relative index (m - mA_prev) of the first mid sample of epoch E_ref
+  int pos_ref;                // mid-ring position of that sample: (m + 104) mod 3000
+  int t3_ref;                 // T_first mod 3 (which of the three ring windows the first macro tile reads)
+  int kb_ref;                 // 384 T_first - kB_prev: call-relative IF index of the first sample of the first macro tile
+  int count_mid;              // this call produces mid samples j = 0 .. count_mid-1
+  float2 *mid; long long mid_stride; int H_mid;               // d_mid = [H_mid halo | data]; only the next call's halo is written
+  const float *afrag;                                         // stage-B A fragments (layout of k_ifr_poly4)
+  int n_if;                                                   // this call produces IF samples 0 .. n_if-1
+  float2 *out; long long out_stride; int out_off;             // IF buffer ([halo | data])
+  int n_tiles; int tiles_per_wg;                              // macro tiles of the call and their split over workgroups
+  // discriminator epilogue (base == nullptr: IF only)
+  double *base; long long base_stride; int base_off;          // MPX as doubles ([halo | data]), FmDecode.cpp:143
+  float *dec; long long dec_stride;                           // float copy of the discriminator output (debug tap), may be null
+  float nf, bound;                                            // PhaseDiscriminator.cpp:28-30
+  StreamState *st;                                            // disc_save in, disc_save_next / disc_save_valid out
+  const float *hB_last;                                       // stage-B tap row of position 47 (TB taps): the IF sample before a run
+  FusedPart *part;                                            // [S][3 n_tiles] partial sums per 128-sample third of a macro tile
+  const int *if_off; const int *if_len; int nb;               // block table (IF index space, this call)
+  unsigned long long *dbg;                                    // tools/bench_fused.hip: per wave {busy, total} shader cycles of workgroup 0
+};
+
+#ifndef FUSED_DMA_AUX
+#define FUSED_DMA_AUX 2      // cache policy bits of the LDS-DMA loads: nt, the input is streamed once (168 vs 190 us for the
+                             // bare DMA ring on 1 GiB, tools/bench_fused.hip)
+#endif
+// cycle counters only in the instrumented ablation builds (s_memtime costs ~100 cycles of latency per read)
+#define FUSED_CLK() (DBG ? __builtin_readcyclecounter() : 0ull)
+#define FUSED_TAP_PAD 8
+#define FUSED_TAP_LEN 96
+// Stage-A taps travel in the kernel-argument segment; the filter is symmetric (linear phase), so only the first
+// half is sent: h[FUSED_TAP_PAD + k] = hA[k], k = 0 .. (NA-1)/2.
+struct FusedTaps { float h[FUSED_TAP_LEN]; };
+
+template <int D, int NA>
+struct FusedShape {
+  static constexpr int ME = 250;                 // mid samples per epoch (2 periods)
+  static constexpr int EPT = 1000 / ME;          // epochs per macro tile
+  static constexpr int RS = D * ME + 144;        // input samples per ring slot (pre-roll NA - D + parity + slack), even
+  static constexpr int NPIECE = RS / 2;          // 16-byte pieces per slot
+  static constexpr int NDMA = (NPIECE + 63) / 64;
+  static constexpr int NSLOT = 5, AHEAD = NSLOT - 1;   // ring slots; the loader runs AHEAD epochs in front of stage A
+  static constexpr int NWORDS = (NA + 2) / 2;    // 16-byte words a stage-A lane reads
+  static constexpr int MIDR = 3000, MIDM = 207;  // mid ring: three macro-tile windows + mirror of the first 207
+  static constexpr int LDS_BYTES = NSLOT * RS * 8 + (MIDR + MIDM + 1) * 8 + 384 * 8 + 64;
+  static constexpr int NT = (NA + 1) / 2;        // distinct taps of the symmetric filter
+  static_assert((D % 2) == 0 && ((D / 2) & 1) == 1, "lane stride must be an odd number of 16-byte words");
+  static_assert(NA - D + 1 + D * ME <= RS, "slot too small");
+  static_assert((NA & 1) == 1 && NT + FUSED_TAP_PAD <= FUSED_TAP_LEN, "odd symmetric filter");
+  static_assert((AHEAD - 1) * NDMA <= 63, "vmcnt is a 6-bit counter");
+  static_assert(4 * 64 >= ME, "four stage-A waves cover an epoch");
+};
+
+// The distinct taps, two per 64-bit VGPR pair.  A packed FMA broadcasts either half of the pair through op_sel, so
+// a tap costs half a register pair and is never copied; the compiler does not form this operand by itself (it
+// materialises {h, h}), hence the two one-instruction asm statements.
+template <int NT>
+struct FusedTapRegs {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f p[(NT + 1) / 2];
+  __device__ __forceinline__ void load(const float *h) {
+#pragma unroll
+    for (int j = 0; j < (NT + 1) / 2; j++) {
+      p[j] = (v2f){h[2 * j], (2 * j + 1 < NT) ? h[2 * j + 1] : 0.f};
+      asm volatile("" : "+v"(p[j]));
+    }
+  }
+  // acc += tap[k] * x   (x = (re, im) of one sample)
+  template <int K>
+  __device__ __forceinline__ void fma(v2f &acc, v2f x) const {
+    if (K & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p[K >> 1]), "v"(x));
+    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(p[K >> 1]), "v"(x));
+  }
+};
+
+// one barrier per epoch.  LDS traffic only: no wave waits here for its global stores, and the loader's DMA stays
+// in flight (a __syncthreads() would drain vmcnt)
+__device__ __forceinline__ void fused_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- role: loader ---------------------------------------------------------------------------------------
+template <int D, int NA>
+__device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, const float2 *hs, int jE,
+                                          unsigned char *slot, int lane) {
+  using SH = FusedShape<D, NA>;
+  const long long nb = a.nbase + (long long)D * jE;
+  if (nb >= 0 && nb + SH::RS <= a.n_valid) {
+    const float2 *src = xs + nb + 2 * lane;
+#pragma unroll
+    for (int c = 0; c < SH::NDMA; c++) {
+      if (c < SH::NDMA - 1 || 64 * c + lane < SH::NPIECE)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 128 * c),
+                                         (__attribute__((address_space(3))) void *)(slot + 1024 * c), 16, 0, FUSED_DMA_AUX);
+    }
+    return SH::NDMA;
+  }
+  // edge region (start / end of the call): guarded element loads, previous call's tail from in_halo, zeros elsewhere
+  float4 *dst = reinterpret_cast<float4 *>(slot);
+  for (int p = lane; p < SH::NPIECE; p += 64) {
+    float2 v[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const long long n = nb + 2 * p + e;
+      v[e] = make_float2(0.f, 0.f);
+      if (n < 0) { if (n >= -(long long)a.H_in) v[e] = hs[a.H_in + n]; }
+      else if (n < a.n_valid) v[e] = xs[n];
+    }
+    dst[p] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  return 0;
+}
+
+// wait until at most `young` DMA instructions are outstanding (young = those issued for later epochs)
+__device__ __forceinline__ void fused_wait_dma(int young, int ndma) {
+  if (young >= 3 * ndma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(63) : "memory");   // 3 * NDMA = 63 for the 10 MS/s shape
+  else if (young >= 2 * ndma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(42) : "memory");
+  else if (young >= ndma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(21) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// One group of G steps of the stage-A loop (compile-time recursion: the tap index of every FMA is a template constant).
+// Six accumulator chains (even / odd sample of the word x word index mod 3): a dependent v_pk_fma_f32 issues only
+// every ~27 cycles, an independent one every ~6 (measured, tools/bench_pkfma.hip), so two chains would run at half rate.
+template <int D, int NA, int PAR, int I, int IEND>
+__device__ __forceinline__ void fused_a_steps(const FusedTapRegs<FusedShape<D, NA>::NT> &tv, const float __attribute__((ext_vector_type(4))) *x,
+                                              float __attribute__((ext_vector_type(2))) (&acc)[6]) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  if constexpr (I < IEND) {
+    constexpr int NT = FusedShape<D, NA>::NT;
+    constexpr int k0 = PAR + NA - 1 - 2 * I, k1 = k0 - 1;        // taps of the even / odd sample of word I
+    if constexpr (k0 >= 0 && k0 < NA) tv.template fma<(k0 < NT ? k0 : NA - 1 - k0)>(acc[2 * (I % 3)], (v2f){x[I].x, x[I].y});
+    if constexpr (k1 >= 0 && k1 < NA) tv.template fma<(k1 < NT ? k1 : NA - 1 - k1)>(acc[2 * (I % 3) + 1], (v2f){x[I].z, x[I].w});
+    fused_a_steps<D, NA, PAR, I + 1, IEND>(tv, x, acc);
+  }
+}
+template <int D, int NA, int PAR, int G, int PF, int GI>
+__device__ __forceinline__ void fused_a_groups(const FusedTapRegs<FusedShape<D, NA>::NT> &tv, const float __attribute__((ext_vector_type(4))) *w,
+                                               float __attribute__((ext_vector_type(4))) *x,
+                                               float __attribute__((ext_vector_type(2))) (&acc)[6]) {
+  constexpr int NSTEP = (PAR + NA - 1) / 2 + 1, NGRP = (NSTEP + G - 1) / G;
+  if constexpr (GI < NGRP) {
+#pragma unroll
+    for (int t = 0; t < G; t++) {              // words first used PF / G groups from now
+      const int i = PF + G * GI + t;
+      if (i < NSTEP) x[i] = w[i];
+    }
+    fused_a_steps<D, NA, PAR, G * GI, (G * GI + G < NSTEP ? G * GI + G : NSTEP)>(tv, x, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    fused_a_groups<D, NA, PAR, G, PF, GI + 1>(tv, w, x, acc);
+  }
+}
+
+// ---- role: stage A --------------------------------------------------------------------------------------
+// Lane L owns output L of the epoch (four waves x 64 lanes >= ME).  Sample q = D L + 2 i + e of the slot meets
+// tap k = PAR + NA - 1 - 2 i - e (PAR: parity of the region start); lane stride D / 2 words.  Loads run PF words
+// ahead of the FMAs; the loop has no scalar loads, so LDS data return in order and the waits are partial.
+template <int D, int NA, int PAR>
+__device__ __forceinline__ void fused_stage_a(const FusedArgs &a, const FusedTapRegs<FusedShape<D, NA>::NT> &tv, int s, int jE,
+                                              int pos0, const unsigned char *slot, float2 *midr, int aw, int lane,
+                                              bool no_math, int abl = 0) {
+  using SH = FusedShape<D, NA>;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int L = 64 * aw + lane;
+  if (L >= SH::ME) return;
+  const v4f *w = reinterpret_cast<const v4f *>(__builtin_assume_aligned(slot, 16)) + (D / 2) * L;
+  constexpr int NSTEP = (PAR + NA - 1) / 2 + 1, G = 8, PF = 16;
+  static_assert(NSTEP <= SH::NWORDS, "word window");
+  v2f acc[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) acc[c] = (v2f){0.f, 0.f};
+  if (!no_math) {
+    v4f x[SH::NWORDS + G + PF];
+    if (abl & 8) {               // ablation: FMAs on whatever the registers hold, no LDS reads
+#pragma unroll
+      for (int i = 0; i < NSTEP; i++) { x[i] = (v4f){1.f, 2.f, 3.f, (float)lane}; asm volatile("" : "+v"(x[i])); }
+      fused_a_groups<D, NA, PAR, G, 1000, 0>(tv, w, x, acc);
+    } else if (abl & 16) {       // ablation: the LDS reads alone
+      v4f sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NSTEP; i++) { const v4f t = w[i]; sum += t; }
+      acc[0] = (v2f){sum.x + sum.z, sum.y + sum.w};
+    } else {
+#pragma unroll
+    for (int i = 0; i < PF && i < NSTEP; i++) x[i] = w[i];
+    fused_a_groups<D, NA, PAR, G, PF, 0>(tv, w, x, acc);
+    }
+  }
+  const v2f ys = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + (acc[4] + acc[5]);
+  float2 y = make_float2(ys.x, ys.y);
+  const int j = jE + L;
+  if (j < 0) {                     // produced by an earlier call: its tail is the prefix halo of d_mid, older samples are never used
+    const int h = j + a.H_mid;
+    y = (h >= 0) ? a.mid[(long long)s * a.mid_stride + h] : make_float2(0.f, 0.f);
+  }
+  int pos = pos0 + L;
+  if (pos >= SH::MIDR) pos -= SH::MIDR;
+  midr[pos] = y;
+  if (pos < SH::MIDM) midr[pos + SH::MIDR] = y;
+  // the next call's stage-B history: the last H_mid mid samples of this call, at their d_mid positions (k_shift_halo re-seats them)
+  if (j >= a.count_mid - a.H_mid && j < a.count_mid && j >= 0) a.mid[(long long)s * a.mid_stride + a.H_mid + j] = y;
+}
+
+// ---- role: stage B (a quarter of the k-steps of a macro tile per epoch) -----------------------------------
+template <int MT0, int NMT>
+struct FusedB {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  using SHB = Poly4Shape<48, 125, 210>;
+  float afr[NMT][SHB::NK];
+  v4f acc[NMT];
+  __device__ __forceinline__ void load(const float *afrag, int lane) {
+#pragma unroll
+    for (int t = 0; t < NMT; t++)
+#pragma unroll
+      for (int i = 0; i < SHB::NK; i++) afr[t][i] = afrag[((MT0 + t) * SHB::NK + i) * 64 + lane];
+  }
+  template <int KS0, int KS1>
+  __device__ __forceinline__ void run(const float *xb) {
+#pragma unroll
+    for (int ks = KS0; ks < KS1; ks++) {
+      const float b = xb[8 * ks];
+#pragma unroll
+      for (int t = 0; t < NMT; t++)
+        if (ks >= SHB::ks_lo(MT0 + t) && ks <= SHB::ks_hi(MT0 + t))
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[t][ks - SHB::ks_lo(MT0 + t)], b, acc[t], 0, 0, 0);
+    }
+  }
+  // quarter q = 0 .. 3 of the macro tile whose window starts at ring position p: 16 + 16 + 16 + 15 of the row
+  // tile's 63 live k-steps.  One accumulator, k ascending: bit-identical to k_ifr_poly4.
+  __device__ __forceinline__ void epoch(int q, int p, const float2 *midr, float2 *stage, int lane) {
+    static_assert(NMT == 1, "one row tile per wave");
+    constexpr int LO = SHB::ks_lo(MT0), HI = SHB::ks_hi(MT0) + 1;
+    const int n = lane & 15, kq = lane >> 4;
+    const float *xb = reinterpret_cast<const float *>(midr) + 2 * (p + (n >> 1) * 125 + kq) + (n & 1);
+    if (q == 0) {
+      acc[0] = (v4f){0.f, 0.f, 0.f, 0.f};
+      run<LO, LO + 16>(xb);
+    } else if (q == 1) {
+      run<LO + 16, LO + 32>(xb);
+    } else if (q == 2) {
+      run<LO + 32, LO + 48>(xb);
+    } else {
+      run<LO + 48, HI>(xb);
+      float *sf = reinterpret_cast<float *>(stage);
+#pragma unroll
+      for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * 48 + 16 * MT0 + 4 * kq + v) + (n & 1)] = acc[0][v];
+    }
+  }
+};
+
+// Epochs e = 0 .. NE-1 of a workgroup, relative to its warm-up epoch (absolute 4 T0 - 1):
+//   stage A: e = 0 .. 4 nt        stage B of its tile i: e = 4 i + 5 .. 4 i + 8        epilogue of tile i: e = 4 i + 9
+// The discriminator of one staged third (PhaseDiscriminator.cpp:33-46, FmDecode.cpp:141-150): lane l owns samples
+// idx0 + l and idx0 + 64 + l.  prev0 = normalised phase of the sample before idx0 (wave-uniform).
+template <int MT0>
+__device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const float2 *stage, int kb, int tile_g, int &blk,
+                                               float prev0, float2 *os, int lane) {
+  const int idx0 = 128 * MT0, k0 = kb + idx0;
+  if (k0 >= a.n_if || k0 + 128 <= 0) return;
+  const float2 x0 = stage[idx0 + lane], x1 = stage[idx0 + 64 + lane];
+  const float ph0 = atan2f(x0.y, x0.x) / a.nf, ph1 = atan2f(x1.y, x1.x) / a.nf;     // V4
+  float pv0 = __shfl_up(ph0, 1, 64), pv1 = __shfl_up(ph1, 1, 64);
+  const float ph0_last = __shfl(ph0, 63, 64);
+  if (lane == 0) { pv0 = prev0; pv1 = ph0_last; }
+  const int ka = k0 + lane, kc = k0 + 64 + lane;
+  if (ka == 0) pv0 = a.st[s].disc_save;            // the call's first sample follows the previous call's last one (m_save_value)
+  if (kc == 0) pv1 = a.st[s].disc_save;
+  auto diff = [&](float ph, float pv) {
+    float d = ph - pv;                                                              // V5
+    if (d > a.bound) d -= 2 * a.bound;
+    if (d < -a.bound) d += 2 * a.bound;
+    if (isnan(d)) d = 0.f;                                                          // Utility.h:336-343
+    return d;
+  };
+  const float d0 = diff(ph0, pv0), d1 = diff(ph1, pv1);
+  const bool va = ka >= 0 && ka < a.n_if, vc = kc >= 0 && kc < a.n_if;
+  double *bs = a.base + (long long)s * a.base_stride + a.base_off;
+  if (va) { os[ka] = x0; bs[ka] = (double)d0; if (a.dec) a.dec[(long long)s * a.dec_stride + ka] = d0; }
+  if (vc) { os[kc] = x1; bs[kc] = (double)d1; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
+  if (ka == a.n_if - 1) { a.st[s].disc_save_next = ph0; a.st[s].disc_save_valid = 1; }
+  if (kc == a.n_if - 1) { a.st[s].disc_save_next = ph1; a.st[s].disc_save_valid = 1; }
+  // ---- per-block partial sums: walk the block table to the block of the first valid sample, cut at its end
+  const int kf = k0 < 0 ? 0 : k0;
+  while (blk < a.nb && a.if_off[blk] + a.if_len[blk] <= kf) blk++;
+  int cut = 0x7fffffff, blk1 = -1;
+  if (blk < a.nb) {
+    cut = a.if_off[blk] + a.if_len[blk];
+    if (cut < k0 + 128 && cut < a.n_if) { blk1 = blk + 1; while (blk1 < a.nb && a.if_len[blk1] == 0) blk1++; if (blk1 >= a.nb) blk1 = -1; }
+  }
+  float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+  auto add = [&](bool valid, int k, float d, float2 x) {
+    if (!valid) return;
+    const float e = x.x * x.x + x.y * x.y;
+    if (k < cut) { sa[0] += d; sa[1] += d * d; sa[2] += e; } else { sb[0] += d; sb[1] += d * d; sb[2] += e; }
+  };
+  add(va, ka, d0, x0);
+  add(vc, kc, d1, x1);
+#pragma unroll
+  for (int c = 0; c < 3; c++) { sa[c] = wave_sum(sa[c]); sb[c] = wave_sum(sb[c]); }
+  if (lane == 0) {
+    FusedPart pt;
+    pt.blk[0] = blk < a.nb ? blk : -1; pt.blk[1] = blk1;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { pt.sum[0][c] = sa[c]; pt.sum[1][c] = sb[c]; }
+    a.part[((long long)s * a.n_tiles + tile_g) * 3 + MT0] = pt;
+  }
+}
+
+// normalised phase of IF sample k = (first sample of macro tile at ring window p) - 1: position 47 of the period before
+// the tile, a plain k-ordered fmaf chain over the TB taps of its row (bit-equal to the MFMA form), on lane 0
+__device__ __forceinline__ float fused_prev_phase(const FusedArgs &a, const float2 *midr, int p) {
+  float re = 0.f, im = 0.f;
+  int pos = p - 3; if (pos < 0) pos += 3000;           // mid sample 1000 T - 107 (the window starts at 1000 T - 104)
+  for (int j = 0; j < 210; j++) {
+    const float h = a.hB_last[j];
+    const float2 x = midr[pos];
+    re = fmaf(h, x.x, re); im = fmaf(h, x.y, im);
+    if (++pos == 3000) pos = 0;
+  }
+  return atan2f(im, re) / a.nf;
+}
+
+template <int MT0, bool OFF, bool DBG>
+__device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, int t3, int nt, int NE, const float2 *midr, float2 *stage, int lane, int wave) {
+  FusedB<MT0, 1> b;
+  b.load(a.afrag, lane);
+  float2 *os = a.out + (long long)s * a.out_stride + a.out_off;
+  fused_barrier();
+  int p = 1000 * t3, q = 0;
+  int kb = a.kb_ref + 384 * i0;                      // call-relative IF index of the first staged sample
+  int tile_g = i0, blk = 0;
+  float prev_tile = 0.f;                              // phase of the last sample of the previous tile (wave 1's first sample needs it)
+  unsigned long long busy = 0, t_begin = FUSED_CLK();
+  for (int e = 0; e < NE; e++) {
+    const unsigned long long tb = FUSED_CLK();
+    if (e == 5 && a.base && MT0 == 0) {
+      // the sample before this workgroup's first one: previous call (disc_save), or recomputed from the warm-up mid samples
+      if (kb <= 0) prev_tile = a.st[s].disc_save;
+      else { float v = 0.f; if (lane == 0) v = fused_prev_phase(a, midr, p); prev_tile = __shfl(v, 0, 64); }
+    }
+    if (e >= 9 && ((e - 9) & 3) == 0) {              // epilogue of the tile staged at the end of the previous epoch
+      if (a.base) {
+        // phase of the sample before this wave's third: the previous tile's last sample (wave 0) or staged sample 128 MT0 - 1
+        float prev0;
+        if (MT0 == 0) prev0 = (kb == 0) ? a.st[s].disc_save : prev_tile;
+        else { const float2 xp = stage[128 * MT0 - 1]; prev0 = (kb + 128 * MT0 == 0) ? a.st[s].disc_save : atan2f(xp.y, xp.x) / a.nf; }
+        if (MT0 == 0) { const float2 xl = stage[383]; prev_tile = atan2f(xl.y, xl.x) / a.nf; }
+        fused_epilogue<MT0>(a, s, stage, kb, tile_g, blk, prev0, os, lane);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const int idx = 128 * MT0 + t * 64 + lane;
+          const int k = kb + idx;
+          if (k >= 0 && k < a.n_if) os[k] = stage[idx];
+        }
+      }
+      kb += 384; tile_g++;
+    }
+    if (!OFF && e >= 5 && e <= 4 * nt + 4) {
+      b.epoch(q, p, midr, stage, lane);
+      if (++q == 4) { q = 0; p = (p == 2000) ? 0 : p + 1000; }
+    }
+    if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    busy += FUSED_CLK() - tb;
+    fused_barrier();
+  }
+  if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[2 * wave] = busy; a.dbg[2 * wave + 1] = FUSED_CLK() - t_begin; }
+}
+
+// Sum the pieces of every block (index order: deterministic) into the per-block statistics k_disc used to write:
+// mean / rms of the discriminator output (Utility.h:135-152) and the IF RMS (Utility.h:118-132, FmDecode.cpp:95).
+__global__ void k_fused_blk_reduce(const FusedPart *__restrict__ part, int n_tiles, int kb_ref, const int *__restrict__ if_off,
+                                   const int *__restrict__ if_len, int nb, float *__restrict__ bb_mean_blk,
+                                   float *__restrict__ bb_rms_blk, float *__restrict__ if_rms_blk) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+  if (b >= nb) return;
+  const int n = if_len[b];
+  if (n == 0) return;
+  const int lo = if_off[b], hi = lo + n - 1;
+  int g0 = (lo - kb_ref) / 128, g1 = (hi - kb_ref) / 128;        // thirds that hold samples of the block (kb_ref <= 0 <= lo)
+  const int ng = 3 * n_tiles;
+  if (g1 >= ng) g1 = ng - 1;
+  float sd = 0.f, sq = 0.f, se = 0.f;
+  for (int g = g0; g <= g1; g++) {
+    const FusedPart pt = part[(long long)s * ng + g];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (pt.blk[h] == b) { sd += pt.sum[h][0]; sq += pt.sum[h][1]; se += pt.sum[h][2]; }
+  }
+  const float fn = (float)(unsigned)n;
+  bb_mean_blk[(long long)s * nb + b] = sd / fn;
+  bb_rms_blk[(long long)s * nb + b] = sqrtf(sq / fn);
+  if_rms_blk[(long long)s * nb + b] = sqrtf(se / fn);
+}
+
+// ABL: ablation mask for tools/bench_fused.hip (0 = product; 1 no stage-A arithmetic, 2 no stage-B MFMAs, 4 no input DMA)
+template <int D, int NA, int PAR, int ABL = 0>
+__global__ __launch_bounds__(512) void k_ifr_fused(FusedArgs a, FusedTaps taps) {
+  using SH = FusedShape<D, NA>;
+  constexpr bool DBG = (ABL & 32) != 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_f[];
+  float2 *midr = reinterpret_cast<float2 *>(lds_f + SH::NSLOT * SH::RS * 8);
+  float2 *stage = midr + (SH::MIDR + SH::MIDM + 1);
+  const int s = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int i0 = blockIdx.x * a.tiles_per_wg;
+  const int i1 = min(i0 + a.tiles_per_wg, a.n_tiles);
+  if (i0 >= i1) return;
+  const int nt = i1 - i0, NE = SH::EPT * nt + 6, EA = SH::EPT * nt;       // EA = last stage-A epoch
+  const int jE0 = a.j_ref + 1000 * i0;                         // first mid sample of epoch 0
+  const int pos00 = (a.pos_ref + 1000 * (i0 % 3)) % SH::MIDR;
+  const int t3 = (a.t3_ref + i0) % 3;
+  const float2 *xs = a.iq + (long long)s * a.iq_stride;
+  const float2 *hs = a.in_halo + (long long)s * a.H_in;
+
+  if (wave == 0) {
+    // ------------------------------------------------------------------ loader
+    // cnt[k]: DMA instructions of the batch k epochs ahead of the one stage A works on
+    int c1 = 0, c2 = 0, c3 = 0;
+    if (!(ABL & 4)) {
+      (void)fused_fill<D, NA>(a, xs, hs, jE0, lds_f, lane);
+      if (1 <= EA) c1 = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME, lds_f + (size_t)1 * SH::RS * 8, lane);
+      if (2 <= EA) c2 = fused_fill<D, NA>(a, xs, hs, jE0 + 2 * SH::ME, lds_f + (size_t)2 * SH::RS * 8, lane);
+      if (3 <= EA) c3 = fused_fill<D, NA>(a, xs, hs, jE0 + 3 * SH::ME, lds_f + (size_t)3 * SH::RS * 8, lane);
+    }
+    fused_wait_dma(c1 + c2 + c3, SH::NDMA);           // the slot of epoch 0 has landed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int slot = SH::AHEAD;
+    unsigned long long busy = 0, t_begin = FUSED_CLK();
+    for (int e = 0; e < NE; e++) {
+      const unsigned long long tb = FUSED_CLK();
+      int c4 = 0;
+      if (!(ABL & 4) && e + SH::AHEAD <= EA)
+        c4 = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME * (e + SH::AHEAD), lds_f + (size_t)slot * SH::RS * 8, lane);
+      slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
+      // the slot of epoch e+1 must have landed: everything but the three younger batches
+      fused_wait_dma(c2 + c3 + c4, SH::NDMA);
+      c1 = c2; c2 = c3; c3 = c4;
+      busy += FUSED_CLK() - tb;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[0] = busy; a.dbg[1] = FUSED_CLK() - t_begin; }
+  } else if (wave == 1) {
+    // ------------------------------------------------------------------ stage B (one row tile per wave) + a third of the epilogue
+    fused_role_b<0, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+  } else if (wave == 2) {
+    fused_role_b<1, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+  } else if (wave == 3) {
+    fused_role_b<2, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+  } else {
+    // ------------------------------------------------------------------ stage A
+    const int aw = wave - 4;
+    FusedTapRegs<SH::NT> tv;
+    tv.load(taps.h + FUSED_TAP_PAD);
+    fused_barrier();
+    int slot = 0, pos0 = pos00, jE = jE0;
+    unsigned long long busy = 0, t_begin = FUSED_CLK();
+    for (int e = 0; e < NE; e++) {
+      const unsigned long long tb = FUSED_CLK();
+      if (e <= EA) {
+        fused_stage_a<D, NA, PAR>(a, tv, s, jE, pos0, lds_f + (size_t)slot * SH::RS * 8, midr, aw, lane, (ABL & 1) != 0, ABL & 24);
+        slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
+        pos0 += SH::ME; if (pos0 >= SH::MIDR) pos0 -= SH::MIDR;
+        jE += SH::ME;
+      }
+      if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      busy += FUSED_CLK() - tb;
+      fused_barrier();
+    }
+    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[2 * wave] = busy; a.dbg[2 * wave + 1] = FUSED_CLK() - t_begin; }
+  }
+}
+
+}  // namespace fmr
