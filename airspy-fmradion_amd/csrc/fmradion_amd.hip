@@ -26,6 +26,7 @@
 #include "design.hpp"
 #include "kernels.hpp"
 #include "kernels_par.hpp"
+#include "kernels_fused.hpp"
 
 namespace {
 #include "filter_tables.inc"
@@ -136,6 +137,12 @@ struct fmr_chain {
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
   DevBuf<float> d_afrag;               // v4: constant A fragments
+  // fused front end (kernels_fused.hpp): stage A + stage B + discriminator in one persistent kernel
+  bool fused_ok = false;               // the chain's shape fits (10 MS/s class, cf32, no Fs/4, no IF FIR, no equaliser)
+  FusedTaps fused_taps{};
+  DevBuf<float> d_hB_last;             // stage-B tap row of position 47
+  DevBuf<FusedPart> d_fused_part;
+  int n_cu = 256;
   DevBuf<float> d_hBp;                 // zero-padded tap rows for v3
   DevBuf<float> d_hpA;                 // stage-A taps in polyphase order [D][Q] (k_ifr_decim2)
   int qa = 0;                          // taps per phase (even), 0 = v2 kernel not applicable
@@ -190,7 +197,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_afrag.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_part.release(); d_afrag.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -216,7 +223,8 @@ struct fmr_chain {
   void timed_on(hipStream_t st, const char *name, F &&launch) {
     // mode 2: only the kernels of the FIR+discriminator stage carry events (two per kernel per call)
     const bool stage_kernel = std::strcmp(name, "ifr_decim") == 0 || std::strcmp(name, "ifr_poly") == 0 ||
-                              std::strcmp(name, "disc") == 0 || std::strcmp(name, "ifr_fused") == 0;
+                              std::strcmp(name, "disc") == 0 || std::strcmp(name, "ifr_fused") == 0 ||
+                              std::strcmp(name, "blk_reduce") == 0;
     if (timing == 2 && stage_kernel) {
       KernelTime kt{name, nullptr, nullptr};
       (void)hipEventCreate(&kt.a);
@@ -375,6 +383,23 @@ int fmr_chain::init(const fmr_config *c) {
           poly4 = true;
           HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 125, 210>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+          // fused front end: the 10 MS/s shape (D = 10, NA = 151) with a symmetric stage-A filter; FM without IF FIR /
+          // equaliser (the discriminator then reads the IF directly), cf32 input, no Fs/4 shift
+          const char *ef = getenv("FMR_NO_FUSED");
+          bool sym = rs.D == 10 && rs.NA == 151;
+          for (int k = 0; sym && k < rs.NA / 2; k++) sym = (fa[k] == fa[rs.NA - 1 - k]);
+          if (sym && mode == FMR_MODE_FM && !c->fmfilter_enable && c->multipath_stages == 0 && in_fmt == 0 &&
+              !c->enable_fourth_down && !(ef && ef[0] == '1')) {
+            for (int k = 0; k < FUSED_TAP_LEN; k++) fused_taps.h[k] = 0.f;
+            for (int k = 0; k <= (rs.NA - 1) / 2; k++) fused_taps.h[FUSED_TAP_PAD + k] = fa[k];
+            if ((rc = upload(d_hB_last, fb.data() + (size_t)phi[47] * rs.TB, (size_t)rs.TB))) return rc;
+            constexpr int kL = FusedShape<10, 151>::LDS_BYTES;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<10, 151, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<10, 151, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+            fused_ok = true;
+          }
         }
       }
     }
@@ -452,6 +477,7 @@ int fmr_chain::init(const fmr_config *c) {
   if (fir_enable && (rc = d_fir.alloc((size_t)S * max_if))) return rc;
   if ((rc = d_gain.alloc((size_t)S * max_if))) return rc;
   if ((rc = d_dec.alloc((size_t)S * max_if))) return rc;
+  if (fused_ok && (rc = d_fused_part.alloc((size_t)S * 3 * (max_if / 384 + 4)))) return rc;
   if ((rc = d_if_rms_blk.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_bb_mean_blk.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_bb_rms_blk.alloc((size_t)S * max_blocks))) return rc;
@@ -681,6 +707,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       *t_au_len = h_tab + 3 * max_blocks, *t_mpf = h_tab + 4 * max_blocks;
   // ------------------------------------------------------------------ front end
   long long N_if = 0, count_mid_call = 0;
+  bool use_fused = false;
+  struct { long long mA_prev, kB_prev, n_prev; int count_mid; } fused_geom{};
   // Cross-call pipelining: the front end of call N+1 (its own stream, its own IF buffer) runs
   // beside the decoder of call N, whose recurrence kernels leave most of the chip idle.
   const int par = pipelined ? (if_parity = (if_parity + 1) % kPipe) : 0;
@@ -706,7 +734,16 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     const int count_mid = (int)(rsc.mA - mA_prev);
     count_mid_call = count_mid;
     if ((size_t)count_mid > max_mid || (size_t)N_if > max_if) { set_err("internal capacity exceeded"); return FMR_ERR_CAPACITY; }
-    if (count_mid > 0) {
+    // Fused front end (stage A + stage B + discriminator in one persistent kernel) when this call is long enough and
+    // its blocks are not tiny; any other call takes the three-kernel path -- both keep the same carried state.
+    if (fused_ok && has_dec && !serial_mode && !pipelined && N_if >= 4 * 384 && count_mid >= H_mid &&
+        ((uintptr_t)d_iq % 16) == 0 && (stride % 2) == 0) {
+      use_fused = true;
+      for (int b = 0; b < nb; b++) if (t_if_len[b] != 0 && t_if_len[b] < 128) use_fused = false;
+    }
+    if (use_fused) {
+      fused_geom = {mA_prev, kB_prev, n_prev, count_mid};
+    } else if (count_mid > 0) {
       const long long top0 = (long long)rs.D * mA_prev + rs.ca() - n_prev;
       auto launch_decim = [&](auto bl_tag) {
         constexpr int BL = decltype(bl_tag)::value;
@@ -759,7 +796,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         });
       }
     }
-    if (N_if > 0 && poly2_tile > 0) {
+    if (use_fused) {
+    } else if (N_if > 0 && poly2_tile > 0) {
       const long long P_first = kB_prev / rs.LB, P_last = (kB_prev + N_if - 1) / rs.LB;
       const int tiles = (int)((P_last - P_first) / 64 + 1);
       timed_on(fes, "ifr_poly", [&] {
@@ -790,7 +828,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                            ifbuf, (long long)(H_if + max_if), H_if);
       });
     }
-    if (N_in > 0) {
+    if (N_in > 0 && !use_fused) {
       timed_on(fes, "in_halo", [&] {
         switch (in_fmt) {
         case 1: hipLaunchKernelGGL((k_update_in_halo<256, 1>), dim3(1, S), dim3(256), 0, fes, d_in_halo.p, H_in, d_iq, (long long)stride, N_in); break;
@@ -890,6 +928,51 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   BlockTab bt{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
               d_tab_slot + 4 * max_blocks, nb};
   const long long if_stride = H_if + (long long)max_if;
+  if (use_fused) {
+    // ---- fused front end: needs the block table (per-block statistics), hence launched here, after the table copy
+    constexpr int D = 10, NA = 151;
+    FusedArgs a{};
+    a.iq = d_iq; a.iq_stride = (long long)stride; a.n_valid = N_in;
+    a.in_halo = d_in_halo.p; a.H_in = H_in;
+    const long long n0 = (long long)rs.D * fused_geom.mA_prev - fused_geom.n_prev;
+    const long long lo0 = n0 + rs.ca() - (NA - 1);
+    const int par = (int)(((lo0 % 2) + 2) % 2);
+    a.nbase = lo0 - par;
+    const long long P_first = fused_geom.kB_prev / 48, P_last = (fused_geom.kB_prev + N_if - 1) / 48;
+    constexpr int kME = FusedShape<10, 151>::ME, kEPT = FusedShape<10, 151>::EPT;
+  const long long T_first = P_first / 8, E_ref = kEPT * T_first - 1;
+    a.j_ref = (int)(kME * E_ref + 104 - fused_geom.mA_prev);
+    a.pos_ref = (int)((((kME * E_ref + 208) % 3000) + 3000) % 3000);
+    a.t3_ref = (int)(T_first % 3);
+    a.kb_ref = (int)(384 * T_first - fused_geom.kB_prev);
+    a.count_mid = fused_geom.count_mid;
+    a.mid = d_mid.p; a.mid_stride = (long long)(H_mid + max_mid); a.H_mid = H_mid;
+    a.afrag = d_afrag.p; a.n_if = (int)N_if;
+    a.out = ifbuf; a.out_stride = if_stride; a.out_off = H_if;
+    a.n_tiles = (int)(P_last / 8 - T_first + 1);
+    // one workgroup per CU: contiguous runs of macro tiles, the streams share the CUs
+    const int wg_per_stream = std::max(1, n_cu / S);
+    a.tiles_per_wg = (a.n_tiles + wg_per_stream - 1) / wg_per_stream;
+    const int grid = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    a.base = d_base.p; a.base_stride = H_b + (long long)max_if; a.base_off = H_b;
+    a.dec = d_dec.p; a.dec_stride = (long long)max_if;
+    a.nf = disc_nf; a.bound = disc_bound;
+    a.st = d_state.p; a.hB_last = d_hB_last.p; a.part = d_fused_part.p;
+    a.if_off = bt.if_off; a.if_len = bt.if_len; a.nb = nb;
+    if ((size_t)a.n_tiles * 3 * S > d_fused_part.n) { set_err("internal capacity exceeded (fused tiles)"); return FMR_ERR_CAPACITY; }
+    constexpr size_t kLds = FusedShape<D, NA>::LDS_BYTES;
+    timed("ifr_fused", [&] {
+      if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(512), kLds, stream, a, fused_taps);
+      else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(512), kLds, stream, a, fused_taps);
+    });
+    timed("blk_reduce", [&] {
+      hipLaunchKernelGGL(k_fused_blk_reduce, dim3((nb + 63) / 64, S), dim3(64), 0, stream, d_fused_part.p, a.n_tiles, a.kb_ref,
+                         bt.if_off, bt.if_len, nb, d_bb_mean_blk.p, d_bb_rms_blk.p, d_if_rms_blk.p);
+    });
+    timed("in_halo", [&] {
+      hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
+    });
+  }
   hp2 = std::chrono::steady_clock::now();
   // ------------------------------------------------------- decoder, IF-rate part
   // SSB / WSPR: mix the new IF samples in place before the filter (the filter history in the halo is already mixed)
@@ -976,6 +1059,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     }
     const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
     const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
+    if (!use_fused)        // (the fused front end has already written the discriminator output and the block statistics)
     timed("disc", [&] {
       hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
                          (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,

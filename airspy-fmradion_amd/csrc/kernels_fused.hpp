@@ -60,6 +60,7 @@ struct FusedArgs {
   const float *hB_last;                                       // stage-B tap row of position 47 (TB taps): the IF sample before a run
   FusedPart *part;                                            // [S][3 n_tiles] partial sums per 128-sample third of a macro tile
   const int *if_off; const int *if_len; int nb;               // block table (IF index space, this call)
+  const int *wg_blk0;                                         // [gridDim.x]: block that holds the first IF sample of each workgroup's run
   unsigned long long *dbg;                                    // tools/bench_fused.hip: per wave {busy, total} shader cycles of workgroup 0
 };
 
@@ -75,23 +76,28 @@ struct FusedArgs {
 // half is sent: h[FUSED_TAP_PAD + k] = hA[k], k = 0 .. (NA-1)/2.
 struct FusedTaps { float h[FUSED_TAP_LEN]; };
 
+#ifndef FUSED_OPL
+#define FUSED_OPL 3          // stage-A outputs per lane: 3 (epochs of 500 mid samples, 3-slot ring) or 1 (250, 5 slots)
+#endif
 template <int D, int NA>
 struct FusedShape {
-  static constexpr int ME = 250;                 // mid samples per epoch (2 periods)
+  static constexpr int OPL = FUSED_OPL;
+  static constexpr int ME = (OPL == 3) ? 500 : 250;   // mid samples per epoch
   static constexpr int EPT = 1000 / ME;          // epochs per macro tile
+  static constexpr int LPW = (ME + 4 * OPL - 1) / (4 * OPL);   // active lanes of each of the four stage-A waves
   static constexpr int RS = D * ME + 144;        // input samples per ring slot (pre-roll NA - D + parity + slack), even
   static constexpr int NPIECE = RS / 2;          // 16-byte pieces per slot
   static constexpr int NDMA = (NPIECE + 63) / 64;
-  static constexpr int NSLOT = 5, AHEAD = NSLOT - 1;   // ring slots; the loader runs AHEAD epochs in front of stage A
-  static constexpr int NWORDS = (NA + 2) / 2;    // 16-byte words a stage-A lane reads
+  static constexpr int NSLOT = (OPL == 3) ? 3 : 5, AHEAD = NSLOT - 1;   // ring slots; the loader runs AHEAD epochs in front of stage A
+  static constexpr int NWORDS = ((OPL - 1) * D + NA + 2) / 2;           // 16-byte words a stage-A lane reads
   static constexpr int MIDR = 3000, MIDM = 207;  // mid ring: three macro-tile windows + mirror of the first 207
   static constexpr int LDS_BYTES = NSLOT * RS * 8 + (MIDR + MIDM + 1) * 8 + 384 * 8 + 64;
   static constexpr int NT = (NA + 1) / 2;        // distinct taps of the symmetric filter
-  static_assert((D % 2) == 0 && ((D / 2) & 1) == 1, "lane stride must be an odd number of 16-byte words");
+  static_assert((OPL * D) % 2 == 0 && ((OPL * D / 2) & 1) == 1, "lane stride must be an odd number of 16-byte words");
   static_assert(NA - D + 1 + D * ME <= RS, "slot too small");
   static_assert((NA & 1) == 1 && NT + FUSED_TAP_PAD <= FUSED_TAP_LEN, "odd symmetric filter");
   static_assert((AHEAD - 1) * NDMA <= 63, "vmcnt is a 6-bit counter");
-  static_assert(4 * 64 >= ME, "four stage-A waves cover an epoch");
+  static_assert(LPW <= 64 && 4 * LPW * OPL >= ME, "four stage-A waves cover an epoch");
 };
 
 // The distinct taps, two per 64-bit VGPR pair.  A packed FMA broadcasts either half of the pair through op_sel, so
@@ -154,25 +160,31 @@ __device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, 
 }
 
 // wait until at most `young` DMA instructions are outstanding (young = those issued for later epochs)
-__device__ __forceinline__ void fused_wait_dma(int young, int ndma) {
-  if (young >= 3 * ndma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(63) : "memory");   // 3 * NDMA = 63 for the 10 MS/s shape
-  else if (young >= 2 * ndma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(42) : "memory");
-  else if (young >= ndma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(21) : "memory");
+template <int NDMA>
+__device__ __forceinline__ void fused_wait_dma(int young) {
+  if (3 * NDMA <= 63 && young >= 3 * NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA <= 63 ? 3 * NDMA : 0) : "memory");
+  else if (2 * NDMA <= 63 && young >= 2 * NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA <= 63 ? 2 * NDMA : 0) : "memory");
+  else if (young >= NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // One group of G steps of the stage-A loop (compile-time recursion: the tap index of every FMA is a template constant).
-// Six accumulator chains (even / odd sample of the word x word index mod 3): a dependent v_pk_fma_f32 issues only
-// every ~27 cycles, an independent one every ~6 (measured, tools/bench_pkfma.hip), so two chains would run at half rate.
+// Output o of the lane reads word I + (D/2) o at step I, so all OPL outputs use the SAME tap pair in the same step.
+// Accumulator chains: (output, even / odd sample of the word), and for OPL = 1 also word index mod 3 -- a dependent
+// v_pk_fma_f32 issues only every ~27 cycles, an independent one every ~6 (tools/bench_pkfma.hip): six chains.
 template <int D, int NA, int PAR, int I, int IEND>
 __device__ __forceinline__ void fused_a_steps(const FusedTapRegs<FusedShape<D, NA>::NT> &tv, const float __attribute__((ext_vector_type(4))) *x,
                                               float __attribute__((ext_vector_type(2))) (&acc)[6]) {
   typedef float v2f __attribute__((ext_vector_type(2)));
   if constexpr (I < IEND) {
-    constexpr int NT = FusedShape<D, NA>::NT;
+    constexpr int NT = FusedShape<D, NA>::NT, OPL = FusedShape<D, NA>::OPL, HD = D / 2;
     constexpr int k0 = PAR + NA - 1 - 2 * I, k1 = k0 - 1;        // taps of the even / odd sample of word I
-    if constexpr (k0 >= 0 && k0 < NA) tv.template fma<(k0 < NT ? k0 : NA - 1 - k0)>(acc[2 * (I % 3)], (v2f){x[I].x, x[I].y});
-    if constexpr (k1 >= 0 && k1 < NA) tv.template fma<(k1 < NT ? k1 : NA - 1 - k1)>(acc[2 * (I % 3) + 1], (v2f){x[I].z, x[I].w});
+#pragma unroll
+    for (int o = 0; o < OPL; o++) {
+      const int c = (OPL == 1) ? 2 * (I % 3) : 2 * o;
+      if constexpr (k0 >= 0 && k0 < NA) tv.template fma<(k0 < NT ? k0 : NA - 1 - k0)>(acc[c], (v2f){x[I + HD * o].x, x[I + HD * o].y});
+      if constexpr (k1 >= 0 && k1 < NA) tv.template fma<(k1 < NT ? k1 : NA - 1 - k1)>(acc[c + 1], (v2f){x[I + HD * o].z, x[I + HD * o].w});
+    }
     fused_a_steps<D, NA, PAR, I + 1, IEND>(tv, x, acc);
   }
 }
@@ -180,12 +192,12 @@ template <int D, int NA, int PAR, int G, int PF, int GI>
 __device__ __forceinline__ void fused_a_groups(const FusedTapRegs<FusedShape<D, NA>::NT> &tv, const float __attribute__((ext_vector_type(4))) *w,
                                                float __attribute__((ext_vector_type(4))) *x,
                                                float __attribute__((ext_vector_type(2))) (&acc)[6]) {
-  constexpr int NSTEP = (PAR + NA - 1) / 2 + 1, NGRP = (NSTEP + G - 1) / G;
+  constexpr int NSTEP = (PAR + NA - 1) / 2 + 1, NGRP = (NSTEP + G - 1) / G, NW = FusedShape<D, NA>::NWORDS;
   if constexpr (GI < NGRP) {
 #pragma unroll
     for (int t = 0; t < G; t++) {              // words first used PF / G groups from now
       const int i = PF + G * GI + t;
-      if (i < NSTEP) x[i] = w[i];
+      if (i < NW) x[i] = w[i];
     }
     fused_a_steps<D, NA, PAR, G * GI, (G * GI + G < NSTEP ? G * GI + G : NSTEP)>(tv, x, acc);
     __builtin_amdgcn_sched_barrier(0);
@@ -194,9 +206,10 @@ __device__ __forceinline__ void fused_a_groups(const FusedTapRegs<FusedShape<D, 
 }
 
 // ---- role: stage A --------------------------------------------------------------------------------------
-// Lane L owns output L of the epoch (four waves x 64 lanes >= ME).  Sample q = D L + 2 i + e of the slot meets
-// tap k = PAR + NA - 1 - 2 i - e (PAR: parity of the region start); lane stride D / 2 words.  Loads run PF words
-// ahead of the FMAs; the loop has no scalar loads, so LDS data return in order and the waits are partial.
+// Lane L (LPW per wave) owns outputs OPL L .. OPL L + OPL - 1 of the epoch.  Sample q = OPL D L + 2 i + e of the slot
+// meets tap k = PAR + NA - 1 - 2 i - e of output 0 (PAR: parity of the region start); lane stride OPL D / 2 words,
+// odd => conflict-free ds_read_b128.  Loads run PF words ahead of the FMAs; the loop has no scalar loads, so LDS
+// data return in order and the waits are partial.
 template <int D, int NA, int PAR>
 __device__ __forceinline__ void fused_stage_a(const FusedArgs &a, const FusedTapRegs<FusedShape<D, NA>::NT> &tv, int s, int jE,
                                               int pos0, const unsigned char *slot, float2 *midr, int aw, int lane,
@@ -204,44 +217,53 @@ __device__ __forceinline__ void fused_stage_a(const FusedArgs &a, const FusedTap
   using SH = FusedShape<D, NA>;
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef float v4f __attribute__((ext_vector_type(4)));
-  const int L = 64 * aw + lane;
-  if (L >= SH::ME) return;
-  const v4f *w = reinterpret_cast<const v4f *>(__builtin_assume_aligned(slot, 16)) + (D / 2) * L;
-  constexpr int NSTEP = (PAR + NA - 1) / 2 + 1, G = 8, PF = 16;
-  static_assert(NSTEP <= SH::NWORDS, "word window");
+  if (lane >= SH::LPW) return;
+  const int L = SH::LPW * aw + lane;
+  if (SH::OPL * L >= SH::ME) return;
+  const v4f *w = reinterpret_cast<const v4f *>(__builtin_assume_aligned(slot, 16)) + (SH::OPL * D / 2) * L;
+  constexpr int NSTEP = (PAR + NA - 1) / 2 + 1, G = (SH::OPL == 3) ? 4 : 8, PF = (SH::OPL == 3) ? (D + 12) : 16;
+  static_assert(NSTEP + (SH::OPL - 1) * (D / 2) <= SH::NWORDS, "word window");
   v2f acc[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) acc[c] = (v2f){0.f, 0.f};
   if (!no_math) {
     v4f x[SH::NWORDS + G + PF];
-    if (abl & 8) {               // ablation: FMAs on whatever the registers hold, no LDS reads
-#pragma unroll
-      for (int i = 0; i < NSTEP; i++) { x[i] = (v4f){1.f, 2.f, 3.f, (float)lane}; asm volatile("" : "+v"(x[i])); }
-      fused_a_groups<D, NA, PAR, G, 1000, 0>(tv, w, x, acc);
-    } else if (abl & 16) {       // ablation: the LDS reads alone
+    if (abl & 16) {       // ablation: the LDS reads alone
       v4f sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < NSTEP; i++) { const v4f t = w[i]; sum += t; }
+      for (int i = 0; i < SH::NWORDS; i++) { const v4f t = w[i]; sum += t; }
       acc[0] = (v2f){sum.x + sum.z, sum.y + sum.w};
     } else {
 #pragma unroll
-    for (int i = 0; i < PF && i < NSTEP; i++) x[i] = w[i];
-    fused_a_groups<D, NA, PAR, G, PF, 0>(tv, w, x, acc);
+      for (int i = 0; i < PF && i < SH::NWORDS; i++) x[i] = w[i];
+      fused_a_groups<D, NA, PAR, G, PF, 0>(tv, w, x, acc);
     }
   }
-  const v2f ys = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + (acc[4] + acc[5]);
-  float2 y = make_float2(ys.x, ys.y);
-  const int j = jE + L;
-  if (j < 0) {                     // produced by an earlier call: its tail is the prefix halo of d_mid, older samples are never used
-    const int h = j + a.H_mid;
-    y = (h >= 0) ? a.mid[(long long)s * a.mid_stride + h] : make_float2(0.f, 0.f);
+  float2 y[3];
+  if (SH::OPL == 1) {
+    const v2f ys = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + (acc[4] + acc[5]);
+    y[0] = make_float2(ys.x, ys.y);
+  } else {
+#pragma unroll
+    for (int o = 0; o < 3; o++) { const v2f ys = acc[2 * o] + acc[2 * o + 1]; y[o] = make_float2(ys.x, ys.y); }
   }
-  int pos = pos0 + L;
-  if (pos >= SH::MIDR) pos -= SH::MIDR;
-  midr[pos] = y;
-  if (pos < SH::MIDM) midr[pos + SH::MIDR] = y;
-  // the next call's stage-B history: the last H_mid mid samples of this call, at their d_mid positions (k_shift_halo re-seats them)
-  if (j >= a.count_mid - a.H_mid && j < a.count_mid && j >= 0) a.mid[(long long)s * a.mid_stride + a.H_mid + j] = y;
+#pragma unroll
+  for (int o = 0; o < SH::OPL; o++) {
+    const int jl = SH::OPL * L + o;
+    if (jl >= SH::ME) continue;
+    float2 yo = y[o];
+    const int j = jE + jl;
+    if (j < 0) {                     // produced by an earlier call: its tail is the prefix halo of d_mid, older samples are never used
+      const int h = j + a.H_mid;
+      yo = (h >= 0) ? a.mid[(long long)s * a.mid_stride + h] : make_float2(0.f, 0.f);
+    }
+    int pos = pos0 + jl;
+    if (pos >= SH::MIDR) pos -= SH::MIDR;
+    midr[pos] = yo;
+    if (pos < SH::MIDM) midr[pos + SH::MIDR] = yo;
+    // the next call's stage-B history: the last H_mid mid samples of this call, at their d_mid positions (k_shift_halo re-seats them)
+    if (j >= a.count_mid - a.H_mid && j < a.count_mid && j >= 0) a.mid[(long long)s * a.mid_stride + a.H_mid + j] = yo;
+  }
 }
 
 // ---- role: stage B (a quarter of the k-steps of a macro tile per epoch) -----------------------------------
@@ -268,22 +290,25 @@ struct FusedB {
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[t][ks - SHB::ks_lo(MT0 + t)], b, acc[t], 0, 0, 0);
     }
   }
-  // quarter q = 0 .. 3 of the macro tile whose window starts at ring position p: 16 + 16 + 16 + 15 of the row
-  // tile's 63 live k-steps.  One accumulator, k ascending: bit-identical to k_ifr_poly4.
+  // phase q = 0 .. NPH-1 of the macro tile whose window starts at ring position p (NPH = epochs per tile).  The first
+  // phase shares its epoch with the epilogue of the previous tile, so it gets the fewest of the row tile's 63 live
+  // k-steps.  One accumulator, k ascending: bit-identical to k_ifr_poly4.
+  template <int NPH>
   __device__ __forceinline__ void epoch(int q, int p, const float2 *midr, float2 *stage, int lane) {
-    static_assert(NMT == 1, "one row tile per wave");
+    static_assert(NMT == 1 && (NPH == 2 || NPH == 4), "one row tile per wave");
     constexpr int LO = SHB::ks_lo(MT0), HI = SHB::ks_hi(MT0) + 1;
+    constexpr int C1 = LO + (NPH == 4 ? 6 : 16), C2 = LO + 25, C3 = LO + 44;
     const int n = lane & 15, kq = lane >> 4;
     const float *xb = reinterpret_cast<const float *>(midr) + 2 * (p + (n >> 1) * 125 + kq) + (n & 1);
     if (q == 0) {
       acc[0] = (v4f){0.f, 0.f, 0.f, 0.f};
-      run<LO, LO + 16>(xb);
-    } else if (q == 1) {
-      run<LO + 16, LO + 32>(xb);
-    } else if (q == 2) {
-      run<LO + 32, LO + 48>(xb);
+      run<LO, C1>(xb);
+    } else if (NPH == 4 && q == 1) {
+      run<C1, C2>(xb);
+    } else if (NPH == 4 && q == 2) {
+      run<C2, C3>(xb);
     } else {
-      run<LO + 48, HI>(xb);
+      run<(NPH == 4 ? C3 : C1), HI>(xb);
       float *sf = reinterpret_cast<float *>(stage);
 #pragma unroll
       for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * 48 + 16 * MT0 + 4 * kq + v) + (n & 1)] = acc[0][v];
@@ -291,13 +316,26 @@ struct FusedB {
   }
 };
 
-// Epochs e = 0 .. NE-1 of a workgroup, relative to its warm-up epoch (absolute 4 T0 - 1):
-//   stage A: e = 0 .. 4 nt        stage B of its tile i: e = 4 i + 5 .. 4 i + 8        epilogue of tile i: e = 4 i + 9
+// A 64-entry window of the block table in registers (lane l: block base + l), so that the epilogue's walk along the
+// blocks costs v_readlane, not a global load: under the input stream a load takes microseconds.
+struct FusedBlkWin {
+  int base, end_l, len_l;        // per lane: end = if_off + if_len of block base + lane (INT_MAX past the table)
+  __device__ __forceinline__ void load(const FusedArgs &a, int b0, int lane) {
+    base = b0;
+    const int b = b0 + lane;
+    len_l = (b < a.nb) ? a.if_len[b] : 0;
+    end_l = (b < a.nb) ? a.if_off[b] + len_l : 0x7fffffff;
+  }
+  __device__ __forceinline__ int end(int blk) const { return __builtin_amdgcn_readlane(end_l, __builtin_amdgcn_readfirstlane(blk - base)); }
+  __device__ __forceinline__ int len(int blk) const { return __builtin_amdgcn_readlane(len_l, __builtin_amdgcn_readfirstlane(blk - base)); }
+};
+
 // The discriminator of one staged third (PhaseDiscriminator.cpp:33-46, FmDecode.cpp:141-150): lane l owns samples
-// idx0 + l and idx0 + 64 + l.  prev0 = normalised phase of the sample before idx0 (wave-uniform).
+// idx0 + l and idx0 + 64 + l.  prev0 = normalised phase of the sample before idx0 (wave-uniform); save0 = the previous
+// call's last phase (m_save_value), which precedes the call's sample 0.
 template <int MT0>
 __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const float2 *stage, int kb, int tile_g, int &blk,
-                                               float prev0, float2 *os, int lane) {
+                                               FusedBlkWin &win, float prev0, float save0, float2 *os, int lane) {
   const int idx0 = 128 * MT0, k0 = kb + idx0;
   if (k0 >= a.n_if || k0 + 128 <= 0) return;
   const float2 x0 = stage[idx0 + lane], x1 = stage[idx0 + 64 + lane];
@@ -306,8 +344,8 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
   const float ph0_last = __shfl(ph0, 63, 64);
   if (lane == 0) { pv0 = prev0; pv1 = ph0_last; }
   const int ka = k0 + lane, kc = k0 + 64 + lane;
-  if (ka == 0) pv0 = a.st[s].disc_save;            // the call's first sample follows the previous call's last one (m_save_value)
-  if (kc == 0) pv1 = a.st[s].disc_save;
+  if (ka == 0) pv0 = save0;
+  if (kc == 0) pv1 = save0;
   auto diff = [&](float ph, float pv) {
     float d = ph - pv;                                                              // V5
     if (d > a.bound) d -= 2 * a.bound;
@@ -322,13 +360,25 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
   if (vc) { os[kc] = x1; bs[kc] = (double)d1; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
   if (ka == a.n_if - 1) { a.st[s].disc_save_next = ph0; a.st[s].disc_save_valid = 1; }
   if (kc == a.n_if - 1) { a.st[s].disc_save_next = ph1; a.st[s].disc_save_valid = 1; }
-  // ---- per-block partial sums: walk the block table to the block of the first valid sample, cut at its end
+  // ---- per-block partial sums: walk to the block of the first valid sample, cut at its end
   const int kf = k0 < 0 ? 0 : k0;
-  while (blk < a.nb && a.if_off[blk] + a.if_len[blk] <= kf) blk++;
+  for (;;) {
+    if (blk - win.base >= 64) win.load(a, blk, lane);       // rare: the window is exhausted
+    if (blk >= a.nb || win.end(blk) > kf) break;
+    blk++;
+  }
   int cut = 0x7fffffff, blk1 = -1;
   if (blk < a.nb) {
-    cut = a.if_off[blk] + a.if_len[blk];
-    if (cut < k0 + 128 && cut < a.n_if) { blk1 = blk + 1; while (blk1 < a.nb && a.if_len[blk1] == 0) blk1++; if (blk1 >= a.nb) blk1 = -1; }
+    cut = win.end(blk);
+    if (cut < k0 + 128 && cut < a.n_if) {
+      blk1 = blk + 1;
+      for (;;) {
+        if (blk1 >= a.nb) { blk1 = -1; break; }
+        if (blk1 - win.base >= 64) { win.load(a, blk, lane); if (blk1 - win.base >= 64) { while (blk1 < a.nb && a.if_len[blk1] == 0) blk1++; if (blk1 >= a.nb) blk1 = -1; break; } }
+        if (win.len(blk1) != 0) break;
+        blk1++;
+      }
+    }
   }
   float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
   auto add = [&](bool valid, int k, float d, float2 x) {
@@ -339,7 +389,7 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
   add(va, ka, d0, x0);
   add(vc, kc, d1, x1);
 #pragma unroll
-  for (int c = 0; c < 3; c++) { sa[c] = wave_sum(sa[c]); sb[c] = wave_sum(sb[c]); }
+  for (int c = 0; c < 3; c++) { sa[c] = wave_sum_dpp(sa[c]); sb[c] = (blk1 >= 0) ? wave_sum_dpp(sb[c]) : 0.f; }
   if (lane == 0) {
     FusedPart pt;
     pt.blk[0] = blk < a.nb ? blk : -1; pt.blk[1] = blk1;
@@ -363,7 +413,7 @@ __device__ __forceinline__ float fused_prev_phase(const FusedArgs &a, const floa
   return atan2f(im, re) / a.nf;
 }
 
-template <int MT0, bool OFF, bool DBG>
+template <int EPT, int MT0, bool OFF, bool DBG>
 __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, int t3, int nt, int NE, const float2 *midr, float2 *stage, int lane, int wave) {
   FusedB<MT0, 1> b;
   b.load(a.afrag, lane);
@@ -373,22 +423,25 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
   int kb = a.kb_ref + 384 * i0;                      // call-relative IF index of the first staged sample
   int tile_g = i0, blk = 0;
   float prev_tile = 0.f;                              // phase of the last sample of the previous tile (wave 1's first sample needs it)
+  float save0 = 0.f;
+  FusedBlkWin win{};
+  if (a.base) { save0 = a.st[s].disc_save; blk = a.wg_blk0[blockIdx.x]; win.load(a, blk, lane); }
   unsigned long long busy = 0, t_begin = FUSED_CLK();
   for (int e = 0; e < NE; e++) {
     const unsigned long long tb = FUSED_CLK();
-    if (e == 5 && a.base && MT0 == 0) {
+    if (e == EPT + 1 && a.base && MT0 == 0) {
       // the sample before this workgroup's first one: previous call (disc_save), or recomputed from the warm-up mid samples
-      if (kb <= 0) prev_tile = a.st[s].disc_save;
+      if (kb <= 0) prev_tile = save0;
       else { float v = 0.f; if (lane == 0) v = fused_prev_phase(a, midr, p); prev_tile = __shfl(v, 0, 64); }
     }
-    if (e >= 9 && ((e - 9) & 3) == 0) {              // epilogue of the tile staged at the end of the previous epoch
+    if (e >= 2 * EPT + 1 && ((e - 1) % EPT) == 0) {  // epilogue of the tile staged at the end of the previous epoch
       if (a.base) {
         // phase of the sample before this wave's third: the previous tile's last sample (wave 0) or staged sample 128 MT0 - 1
         float prev0;
-        if (MT0 == 0) prev0 = (kb == 0) ? a.st[s].disc_save : prev_tile;
-        else { const float2 xp = stage[128 * MT0 - 1]; prev0 = (kb + 128 * MT0 == 0) ? a.st[s].disc_save : atan2f(xp.y, xp.x) / a.nf; }
+        if (MT0 == 0) prev0 = prev_tile;
+        else { const float2 xp = stage[128 * MT0 - 1]; prev0 = atan2f(xp.y, xp.x) / a.nf; }
         if (MT0 == 0) { const float2 xl = stage[383]; prev_tile = atan2f(xl.y, xl.x) / a.nf; }
-        fused_epilogue<MT0>(a, s, stage, kb, tile_g, blk, prev0, os, lane);
+        fused_epilogue<MT0>(a, s, stage, kb, tile_g, blk, win, prev0, save0, os, lane);
       } else {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -399,9 +452,9 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
       }
       kb += 384; tile_g++;
     }
-    if (!OFF && e >= 5 && e <= 4 * nt + 4) {
-      b.epoch(q, p, midr, stage, lane);
-      if (++q == 4) { q = 0; p = (p == 2000) ? 0 : p + 1000; }
+    if (!OFF && e >= EPT + 1 && e <= EPT * nt + EPT) {
+      b.template epoch<EPT>(q, p, midr, stage, lane);
+      if (++q == EPT) { q = 0; p = (p == 2000) ? 0 : p + 1000; }
     }
     if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     busy += FUSED_CLK() - tb;
@@ -449,8 +502,8 @@ __global__ __launch_bounds__(512) void k_ifr_fused(FusedArgs a, FusedTaps taps) 
   const int i0 = blockIdx.x * a.tiles_per_wg;
   const int i1 = min(i0 + a.tiles_per_wg, a.n_tiles);
   if (i0 >= i1) return;
-  const int nt = i1 - i0, NE = SH::EPT * nt + 6, EA = SH::EPT * nt;       // EA = last stage-A epoch
-  const int jE0 = a.j_ref + 1000 * i0;                         // first mid sample of epoch 0
+  const int nt = i1 - i0, NE = SH::EPT * nt + SH::EPT + 2, EA = SH::EPT * nt;       // EA = last stage-A epoch
+  const int jE0 = a.j_ref + 1000 * i0;                         // first mid sample of epoch 0 (a macro tile = 1000 mid samples)
   const int pos00 = (a.pos_ref + 1000 * (i0 % 3)) % SH::MIDR;
   const int t3 = (a.t3_ref + i0) % 3;
   const float2 *xs = a.iq + (long long)s * a.iq_stride;
@@ -458,38 +511,47 @@ __global__ __launch_bounds__(512) void k_ifr_fused(FusedArgs a, FusedTaps taps) 
 
   if (wave == 0) {
     // ------------------------------------------------------------------ loader
-    // cnt[k]: DMA instructions of the batch k epochs ahead of the one stage A works on
-    int c1 = 0, c2 = 0, c3 = 0;
+    // cy[k]: DMA instructions of the batch issued k+1 epochs ago ... the batches younger than the one needed next
+    int cy[SH::AHEAD];
+#pragma unroll
+    for (int k = 0; k < SH::AHEAD; k++) cy[k] = 0;
     if (!(ABL & 4)) {
-      (void)fused_fill<D, NA>(a, xs, hs, jE0, lds_f, lane);
-      if (1 <= EA) c1 = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME, lds_f + (size_t)1 * SH::RS * 8, lane);
-      if (2 <= EA) c2 = fused_fill<D, NA>(a, xs, hs, jE0 + 2 * SH::ME, lds_f + (size_t)2 * SH::RS * 8, lane);
-      if (3 <= EA) c3 = fused_fill<D, NA>(a, xs, hs, jE0 + 3 * SH::ME, lds_f + (size_t)3 * SH::RS * 8, lane);
+#pragma unroll
+      for (int k = 0; k < SH::AHEAD; k++)
+        if (k <= EA) { const int c = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME * k, lds_f + (size_t)k * SH::RS * 8, lane); if (k >= 1) cy[k - 1] = c; }
     }
-    fused_wait_dma(c1 + c2 + c3, SH::NDMA);           // the slot of epoch 0 has landed
+    { int young = 0;
+#pragma unroll
+      for (int k = 0; k < SH::AHEAD - 1; k++) young += cy[k];
+      fused_wait_dma<SH::NDMA>(young); }               // the slot of epoch 0 has landed
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int slot = SH::AHEAD;
     unsigned long long busy = 0, t_begin = FUSED_CLK();
     for (int e = 0; e < NE; e++) {
       const unsigned long long tb = FUSED_CLK();
-      int c4 = 0;
+      int cn = 0;
       if (!(ABL & 4) && e + SH::AHEAD <= EA)
-        c4 = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME * (e + SH::AHEAD), lds_f + (size_t)slot * SH::RS * 8, lane);
+        cn = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME * (e + SH::AHEAD), lds_f + (size_t)slot * SH::RS * 8, lane);
       slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
-      // the slot of epoch e+1 must have landed: everything but the three younger batches
-      fused_wait_dma(c2 + c3 + c4, SH::NDMA);
-      c1 = c2; c2 = c3; c3 = c4;
+      // the slot of epoch e+1 must have landed: everything but the AHEAD-1 younger batches (cy[0] is epoch e+1 itself)
+      int young = cn;
+#pragma unroll
+      for (int k = 1; k < SH::AHEAD - 1; k++) young += cy[k];
+      fused_wait_dma<SH::NDMA>(young);
+#pragma unroll
+      for (int k = 0; k + 1 < SH::AHEAD - 1; k++) cy[k] = cy[k + 1];
+      if (SH::AHEAD >= 2) cy[SH::AHEAD - 2] = cn;
       busy += FUSED_CLK() - tb;
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[0] = busy; a.dbg[1] = FUSED_CLK() - t_begin; }
   } else if (wave == 1) {
     // ------------------------------------------------------------------ stage B (one row tile per wave) + a third of the epilogue
-    fused_role_b<0, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, 0, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
   } else if (wave == 2) {
-    fused_role_b<1, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, 1, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
   } else if (wave == 3) {
-    fused_role_b<2, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, 2, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
   } else {
     // ------------------------------------------------------------------ stage A
     const int aw = wave - 4;

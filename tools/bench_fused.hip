@@ -32,7 +32,7 @@ struct Ctx {
   FusedTaps taps;
   unsigned long long *d_dbg = nullptr;
   double *d_base = nullptr; float *d_dec = nullptr, *d_hBlast = nullptr, *d_stats = nullptr; StreamState *d_st = nullptr; FusedPart *d_part = nullptr; int *d_tab = nullptr;
-  bool epi = false; int nb = 0; std::vector<int> h_off, h_len;
+  bool epi = false; int nb = 0; std::vector<int> h_off, h_len; int *d_wgblk = nullptr;
   int poly2_tile;
 };
 
@@ -73,6 +73,7 @@ static void setup(Ctx &c, size_t max_in) {
   SETATTR(0, 4); SETATTR(1, 4); SETATTR(0, 7); SETATTR(1, 7); SETATTR(0, 5); SETATTR(1, 5); SETATTR(0, 6); SETATTR(1, 6);
   SETATTR(0, 14); SETATTR(1, 14); SETATTR(0, 22); SETATTR(1, 22); SETATTR(0, 32); SETATTR(1, 32); SETATTR(0, 36); SETATTR(1, 36); SETATTR(0, 38); SETATTR(1, 38); SETATTR(0, 37); SETATTR(1, 37); SETATTR(0, 35); SETATTR(1, 35);
   CK(hipMalloc(&c.d_dbg, 16 * 8)); CK(hipMemset(c.d_dbg, 0, 16 * 8));
+  CK(hipMalloc(&c.d_wgblk, 1024 * 4));
   CK(hipMalloc(&c.d_base, c.max_if * 8)); CK(hipMalloc(&c.d_dec, c.max_if * 4)); CK(hipMalloc(&c.d_st, sizeof(StreamState)));
   CK(hipMemset(c.d_st, 0, sizeof(StreamState)));
   CK(hipMalloc(&c.d_part, (c.max_if / 128 + 16) * sizeof(FusedPart))); CK(hipMalloc(&c.d_tab, 2 * 4096 * 4)); CK(hipMalloc(&c.d_stats, 3 * 4096 * 4));
@@ -123,9 +124,10 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
   const int par = (int)(((lo0 % 2) + 2) % 2);
   a.nbase = lo0 - par;
   const long long P_first = g.kB_prev / 48, P_last = (g.kB_prev + g.N_if - 1) / 48;
-  const long long T_first = P_first / 8, E_ref = 4 * T_first - 1;
-  a.j_ref = (int)(250 * E_ref + 104 - g.mA_prev);
-  a.pos_ref = (int)((((250 * E_ref + 208) % 3000) + 3000) % 3000);
+  constexpr int kME = FusedShape<10, 151>::ME, kEPT = FusedShape<10, 151>::EPT;
+  const long long T_first = P_first / 8, E_ref = kEPT * T_first - 1;
+  a.j_ref = (int)(kME * E_ref + 104 - g.mA_prev);
+  a.pos_ref = (int)((((kME * E_ref + 208) % 3000) + 3000) % 3000);
   a.t3_ref = (int)(T_first % 3);
   a.kb_ref = (int)(384 * T_first - g.kB_prev);
   a.count_mid = g.count_mid;
@@ -142,6 +144,19 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
   a.tiles_per_wg = (a.n_tiles + n_wg - 1) / n_wg;
   const int grid = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
   constexpr size_t kLds = FusedShape<D, NA>::LDS_BYTES;
+  if (c.epi) {
+    // block of the first IF sample of every workgroup (host side of the block walk)
+    std::vector<int> tab(2 * 4096), wb(grid);
+    CK(hipMemcpy(tab.data(), c.d_tab, tab.size() * 4, hipMemcpyDeviceToHost));
+    int b = 0;
+    for (int w = 0; w < grid; w++) {
+      const long long kf = std::max<long long>(0, (long long)a.kb_ref + 384ll * w * a.tiles_per_wg);
+      while (b < c.nb && tab[b] + tab[4096 + b] <= kf) b++;
+      wb[w] = b;
+    }
+    CK(hipMemcpy(c.d_wgblk, wb.data(), grid * 4, hipMemcpyHostToDevice));
+    a.wg_blk0 = c.d_wgblk;
+  }
   if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, ABL>), dim3(grid, 1), dim3(512), kLds, 0, a, c.taps);
   else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, ABL>), dim3(grid, 1), dim3(512), kLds, 0, a, c.taps);
 }
@@ -308,6 +323,19 @@ int main(int argc, char **argv) {
   time_it("old: ifr_decim2 (stage A)", bytes, [&] { launch_old(c, g, d_iq, c.d_if_old, true, false); });
   time_it("old: ifr_poly4 (stage B)", bytes, [&] { launch_old(c, g, d_iq, c.d_if_old, false, true); });
   time_it("old: stage A + stage B", bytes, [&] { launch_old(c, g, d_iq, c.d_if_old); });
+  {
+    // block table of the timing geometry (65536-sample blocks) for the runs with the discriminator epilogue
+    ResamplerCounter rc2; rc2.advance(c.rs, 12345678);
+    std::vector<int> tab(2 * 4096, 0);
+    long long acc_if = 0, left = (long long)N; int nb = 0;
+    while (left > 0 && nb < 4096) { const long long bl = std::min<long long>(65536, left); const long long k = rc2.advance(c.rs, bl); tab[nb] = (int)acc_if; tab[4096 + nb] = (int)k; acc_if += k; left -= bl; nb++; }
+    c.nb = nb;
+    CK(hipMemcpy(c.d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  }
+  c.epi = true;
+  time_it("fused A+B+discriminator, 256 workgroups", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
+  time_it("fused A+B+discriminator, 248 workgroups", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 248); });
+  c.epi = false;
   for (int nwg : {256, 512, 248})
     { char nm[64]; snprintf(nm, sizeof nm, "fused A+B, %d workgroups", nwg); time_it(nm, bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, nwg); }); }
   time_it("ablation: no stage-A math", bytes, [&] { launch_new<1>(c, g, d_iq, c.d_if_new, 256); });
