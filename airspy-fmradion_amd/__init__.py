@@ -28,7 +28,7 @@ EXPORTS = [
     "fmr_create", "fmr_destroy", "fmr_last_error", "fmr_version", "fmr_resampler_info", "fmr_process",
     "fmr_process_blocks", "fmr_process_blocks_device", "fmr_synchronize", "fmr_resample", "fmr_get_status",
     "fmr_get_pps_events", "fmr_get_multipath_coefficients", "fmr_debug_read", "fmr_get_kernel_times",
-    "fmr_enable_kernel_timing", "fmr_filter_table",
+    "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert",
 ]
 
 
@@ -43,7 +43,7 @@ class Config(C.Structure):
         ("filter_coeff", C.POINTER(C.c_float)), ("n_filter_coeff", C.c_int), ("stereo", C.c_int),
         ("deemphasis_us", C.c_double), ("pilot_shift", C.c_int), ("multipath_stages", C.c_uint),
         ("max_block_len", C.c_size_t), ("max_blocks", C.c_int), ("nbfm_freq_dev", C.c_double),
-        ("input_format", C.c_int),
+        ("input_format", C.c_int), ("output_rate", C.c_double),
     ]
 
 
@@ -121,6 +121,8 @@ def lib():
     L.fmr_get_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), fp, C.c_int]
     L.fmr_enable_kernel_timing.restype = None
     L.fmr_enable_kernel_timing.argtypes = [vp, C.c_int]
+    L.fmr_fourth_convert.restype = C.c_int
+    L.fmr_fourth_convert.argtypes = [vp, fp, C.c_size_t, fp, C.c_int, C.POINTER(C.c_uint)]
     L.fmr_filter_table.restype = C.c_int
     L.fmr_filter_table.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int)]
     _lib = L
@@ -145,7 +147,8 @@ class Chain:
 
     def __init__(self, mode=MODE_FM, input_rate=384000.0, enable_resampler=False, fourth_down=False,
                  fmfilter_enable=False, filter_coeff=None, stereo=True, deemphasis_us=50.0, pilot_shift=False,
-                 multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0, nbfm_freq_dev=0.0, input_format=0):
+                 multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0, nbfm_freq_dev=0.0, input_format=0,
+                 output_rate=0.0):
         coeff = np.ascontiguousarray(DELAY_3TAPS if filter_coeff is None else filter_coeff, dtype=np.float32)
         self._coeff = coeff
         cfg = Config()
@@ -159,6 +162,7 @@ class Chain:
         cfg.max_block_len, cfg.max_blocks = int(max_block_len), int(max_blocks)
         cfg.nbfm_freq_dev = float(nbfm_freq_dev)
         cfg.input_format = int(input_format)
+        cfg.output_rate = float(output_rate)
         self.input_format = int(input_format)
         self.n_streams, self.mode, self.stereo = n_streams, mode, bool(stereo) and mode == MODE_FM
         self.h = C.c_void_p()
@@ -212,6 +216,15 @@ class Chain:
                                            audio.ctypes.data_as(C.POINTER(C.c_double)), acap,
                                            alen.ctypes.data_as(u32p)))
         return audio[:, :int(alen.sum())].copy(), alen
+
+    def fourth_convert(self, iq, index=0, up=False):
+        """FourthConverterIQ::process on one block; returns (shifted block, new table index)."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        out = np.empty_like(iq)
+        idx = C.c_uint(index)
+        self._chk(lib().fmr_fourth_convert(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), len(iq),
+                                           out.ctypes.data_as(C.POINTER(C.c_float)), int(up), C.byref(idx)))
+        return out, idx.value
 
     def resample(self, iq):
         iq = np.ascontiguousarray(iq, dtype=np.complex64)

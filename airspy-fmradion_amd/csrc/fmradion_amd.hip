@@ -141,6 +141,7 @@ struct fmr_chain {
   bool fused_ok = false;               // the chain's shape fits (10 MS/s class, cf32, no Fs/4, no IF FIR, no equaliser)
   FusedTaps fused_taps{};
   DevBuf<float> d_hB_last;             // stage-B tap row of position 47
+  DevBuf<float> d_fused_taps;          // device copy of fused_taps
   DevBuf<FusedPart> d_fused_part;
   int n_cu = 256;
   DevBuf<float> d_hBp;                 // zero-padded tap rows for v3
@@ -167,6 +168,7 @@ struct fmr_chain {
   // block tables: ring of pinned host slots + device slots so that queued
   // asynchronous calls never overwrite a table that is still being copied
   static constexpr int kTabSlots = 8;
+  static constexpr int kMaxFusedWg = 1024;
   int *h_tab_all = nullptr;  // pinned, kTabSlots * tab_ints
   size_t tab_ints = 0;       // 5*max_blocks block table + 3*max_ck chunk table + (max_blocks+1) first-chunk table
   unsigned long long call_seq = 0;      // calls issued
@@ -197,7 +199,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_part.release(); d_afrag.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_taps.release(); d_fused_part.release(); d_afrag.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -259,6 +261,7 @@ struct fmr_chain {
   }
   int init(const fmr_config *c);
   bool cold = true;                     // no call yet: AGC at its initial gain, PLL unlocked
+  int pps_block_base = 0;               // blocks of the call that ran before the part whose PPS events the state holds
   int run_cold_aware(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
                      size_t astride, uint32_t *audio_len);
   int run(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
@@ -294,7 +297,8 @@ int fmr_chain::init(const fmr_config *c) {
   HIPCHK(hipEventCreateWithFlags(&ev_tab, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ev_mono, hipEventDisableTiming));
   for (hipEvent_t *e : {&ev_disc, &ev_pll, &ev_stats, &ev_fin, &ev_if}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-  const double dec_rate = (mode == FMR_MODE_FM || mode == FMR_MODE_NONE) ? kFmRate : kAmRate;
+  double dec_rate = (mode == FMR_MODE_FM || mode == FMR_MODE_NONE) ? kFmRate : kAmRate;
+  if (mode == FMR_MODE_NONE && c->output_rate > 0) dec_rate = c->output_rate;     // IfResampler(in, out), IfResampler.h:35
   has_rs = c->enable_resampler != 0;
   max_blocks = c->max_blocks;
   max_in = c->max_block_len * (size_t)c->max_blocks;
@@ -339,6 +343,18 @@ int fmr_chain::init(const fmr_config *c) {
     {
       const char *e = getenv("FMR_DECIM_V1");
       if (e && e[0] == '1') qa = 0;
+    }
+    if (in_fmt != 0) {
+      // the fused sample conversion lives in the v2 front-end kernel only: refuse the chain now, not on every call
+      constexpr int BL2 = 128, T2 = 2 * BL2;
+      int s_pad = T2 + 16;
+      while ((s_pad & 15) != 2) s_pad++;
+      const size_t lds2 = sizeof(float2) * ((size_t)rs.D * s_pad + 2);
+      if (!(qa == 16 && lds2 <= 64000 && (size_t)rs.D * (T2 + 16) <= (size_t)2 * 16 * BL2)) {
+        set_err("input_format != cf32 needs a source rate with integer pre-decimation >= 2 (%.0f -> %.0f Hz gives D = %d): "
+                "convert on the host or use cf32 input", c->input_rate, dec_rate, rs.D);
+        return FMR_ERR_UNSUPPORTED;
+      }
     }
     {
       // stage-B v2: 64 periods per tile must fit in LDS, odd MB keeps the lane stride conflict-free
@@ -391,8 +407,9 @@ int fmr_chain::init(const fmr_config *c) {
           if (sym && mode == FMR_MODE_FM && !c->fmfilter_enable && c->multipath_stages == 0 && in_fmt == 0 &&
               !c->enable_fourth_down && !(ef && ef[0] == '1')) {
             for (int k = 0; k < FUSED_TAP_LEN; k++) fused_taps.h[k] = 0.f;
-            for (int k = 0; k <= (rs.NA - 1) / 2; k++) fused_taps.h[FUSED_TAP_PAD + k] = fa[k];
+            for (int k = 0; k < rs.NA; k++) fused_taps.h[FUSED_TAP_PAD + k] = fa[k];
             if ((rc = upload(d_hB_last, fb.data() + (size_t)phi[47] * rs.TB, (size_t)rs.TB))) return rc;
+            if ((rc = upload(d_fused_taps, fused_taps.h, (size_t)FUSED_TAP_LEN))) return rc;
             constexpr int kL = FusedShape<10, 151>::LDS_BYTES;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<10, 151, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<10, 151, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
@@ -452,7 +469,7 @@ int fmr_chain::init(const fmr_config *c) {
   }
   if ((rc = upload(d_state, h_state.data(), h_state.size()))) return rc;
   max_ck = max_if / C_PLL_MIN + (size_t)max_blocks + 2;
-  tab_ints = 5 * (size_t)max_blocks + 3 * max_ck + (size_t)max_blocks + 1;
+  tab_ints = 5 * (size_t)max_blocks + 3 * max_ck + (size_t)max_blocks + 1 + kMaxFusedWg;   // tail: first block of each fused workgroup
   HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * tab_ints));
   HIPCHK(hipHostMalloc((void **)&h_marks, 2 * sizeof(unsigned long long)));
   h_marks[0] = h_marks[1] = 0;
@@ -644,19 +661,24 @@ int fmr_chain::init(const fmr_config *c) {
 int fmr_chain::run_cold_aware(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
                               size_t astride, uint32_t *audio_len) {
   const bool was_cold = cold;
-  cold = false;
-  if (!was_cold || mode != FMR_MODE_FM || !has_rs || nb < 2) return run(d_iq, stride, block_len, nb, d_aud, astride, audio_len);
+  pps_block_base = 0;
+  auto plain = [&]() { const int rc0 = run(d_iq, stride, block_len, nb, d_aud, astride, audio_len); if (rc0 == FMR_OK) cold = false; return rc0; };
+  if (!was_cold || mode != FMR_MODE_FM || !has_rs || nb < 2) return plain();
   const double target = 0.8 * cfg.input_rate;
   double total = 0;
   for (int b = 0; b < nb; b++) total += block_len[b];
-  if (total < 2.0 * target) return run(d_iq, stride, block_len, nb, d_aud, astride, audio_len);
+  if (total < 2.0 * target) return plain();
   size_t in_off = 0;
   int k = 0;
   while (k < nb - 1 && (double)in_off < target) in_off += block_len[k++];
-  if (in_fmt != 0 && (in_off * (size_t)in_bps) % 16 != 0) return run(d_iq, stride, block_len, nb, d_aud, astride, audio_len);
+  if (in_fmt != 0 && (in_off * (size_t)in_bps) % 16 != 0) return plain();
   std::vector<uint32_t> al((size_t)nb, 0);
   int rc = run(d_iq, stride, block_len, k, d_aud, astride, al.data());
   if (rc) return rc;
+  cold = false;
+  // The head (< 0.8 s of signal from a cold PLL) cannot hold a PPS event: the first one needs the lock (0.5 s) plus
+  // 19000 pilot periods (1 s).  The state keeps the tail's events; their block index is reported relative to the call.
+  pps_block_base = k;
   size_t au_off = 0;
   for (int b = 0; b < k; b++) au_off += al[b];
   const float2 *iq2 = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(d_iq) + in_off * (size_t)in_bps);
@@ -910,6 +932,28 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   // Table kernels and the PLL's initial node guess run on the side stream, beside the front end.
   hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((head_ints + 255) / 256)), dim3(256), 0, side,
                      (const int *)h_tab, d_tab_slot, (int)head_ints);
+  int fused_grid = 0, fused_tiles_per_wg = 0, fused_n_tiles = 0, fused_kb_ref = 0;
+  long long fused_T_first = 0;
+  if (use_fused) {
+    // one workgroup per CU: contiguous runs of macro tiles, the streams share the CUs.  The table's tail carries the
+    // block that holds the first IF sample of every workgroup's run (the epilogue walks the block table from there).
+    const long long P_first = fused_geom.kB_prev / 48, P_last = (fused_geom.kB_prev + N_if - 1) / 48;
+    fused_T_first = P_first / 8;
+    fused_n_tiles = (int)(P_last / 8 - fused_T_first + 1);
+    const int wg_per_stream = std::max(1, std::min(kMaxFusedWg, n_cu / S));
+    fused_tiles_per_wg = (fused_n_tiles + wg_per_stream - 1) / wg_per_stream;
+    fused_grid = (fused_n_tiles + fused_tiles_per_wg - 1) / fused_tiles_per_wg;
+    int *t_wg = h_tab + (tab_ints - kMaxFusedWg);
+    const long long kb_ref = 384 * fused_T_first - fused_geom.kB_prev;
+    int b = 0;
+    for (int w = 0; w < fused_grid; w++) {
+      const long long kf = std::max<long long>(0, kb_ref + 384ll * w * fused_tiles_per_wg);
+      while (b < nb && (long long)t_if_off[b] + t_if_len[b] <= kf) b++;
+      t_wg[w] = b;
+    }
+    hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((fused_grid + 255) / 256)), dim3(256), 0, side,
+                       (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), fused_grid);
+  }
   int *d_first = d_tab_slot + 5 * (size_t)max_blocks;
   int *d_ck = d_tab_slot + head_ints;
   ChunkTab ct{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_first, nck};
@@ -933,14 +977,13 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     constexpr int D = 10, NA = 151;
     FusedArgs a{};
     a.iq = d_iq; a.iq_stride = (long long)stride; a.n_valid = N_in;
-    a.in_halo = d_in_halo.p; a.H_in = H_in;
+    a.in_halo = d_in_halo.p; a.H_in = H_in; a.taps = d_fused_taps.p;
     const long long n0 = (long long)rs.D * fused_geom.mA_prev - fused_geom.n_prev;
     const long long lo0 = n0 + rs.ca() - (NA - 1);
     const int par = (int)(((lo0 % 2) + 2) % 2);
     a.nbase = lo0 - par;
-    const long long P_first = fused_geom.kB_prev / 48, P_last = (fused_geom.kB_prev + N_if - 1) / 48;
     constexpr int kME = FusedShape<10, 151>::ME, kEPT = FusedShape<10, 151>::EPT;
-  const long long T_first = P_first / 8, E_ref = kEPT * T_first - 1;
+    const long long T_first = fused_T_first, E_ref = kEPT * T_first - 1;
     a.j_ref = (int)(kME * E_ref + 104 - fused_geom.mA_prev);
     a.pos_ref = (int)((((kME * E_ref + 208) % 3000) + 3000) % 3000);
     a.t3_ref = (int)(T_first % 3);
@@ -949,11 +992,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     a.mid = d_mid.p; a.mid_stride = (long long)(H_mid + max_mid); a.H_mid = H_mid;
     a.afrag = d_afrag.p; a.n_if = (int)N_if;
     a.out = ifbuf; a.out_stride = if_stride; a.out_off = H_if;
-    a.n_tiles = (int)(P_last / 8 - T_first + 1);
-    // one workgroup per CU: contiguous runs of macro tiles, the streams share the CUs
-    const int wg_per_stream = std::max(1, n_cu / S);
-    a.tiles_per_wg = (a.n_tiles + wg_per_stream - 1) / wg_per_stream;
-    const int grid = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    a.n_tiles = fused_n_tiles;
+    a.tiles_per_wg = fused_tiles_per_wg;
+    const int grid = fused_grid;
+    a.wg_blk0 = d_tab_slot + (tab_ints - kMaxFusedWg);
     a.base = d_base.p; a.base_stride = H_b + (long long)max_if; a.base_off = H_b;
     a.dec = d_dec.p; a.dec_stride = (long long)max_if;
     a.nf = disc_nf; a.bound = disc_bound;
@@ -962,13 +1004,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if ((size_t)a.n_tiles * 3 * S > d_fused_part.n) { set_err("internal capacity exceeded (fused tiles)"); return FMR_ERR_CAPACITY; }
     constexpr size_t kLds = FusedShape<D, NA>::LDS_BYTES;
     timed("ifr_fused", [&] {
-      if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(512), kLds, stream, a, fused_taps);
-      else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(512), kLds, stream, a, fused_taps);
+      if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, stream, a, fused_taps);
+      else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, stream, a, fused_taps);
     });
-    timed("blk_reduce", [&] {
-      hipLaunchKernelGGL(k_fused_blk_reduce, dim3((nb + 63) / 64, S), dim3(64), 0, stream, d_fused_part.p, a.n_tiles, a.kb_ref,
-                         bt.if_off, bt.if_len, nb, d_bb_mean_blk.p, d_bb_rms_blk.p, d_if_rms_blk.p);
-    });
+    fused_kb_ref = a.kb_ref;
     timed("in_halo", [&] {
       hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
     });
@@ -1068,9 +1107,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     });
     HIPCHK(hipEventRecord(ev_disc, stream));
     HIPCHK(hipStreamWaitEvent(side, ev_disc, 0));
-    timed_on(side, "stats", [&] {
+    timed_on(side, "stats", [&] {     // (fused front end: the block values are summed from its partial sums on the fly)
       hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
-                         d_bb_rms_blk.p, d_state.p, S, 1);
+                         d_bb_rms_blk.p, d_state.p, S, 1, use_fused ? d_fused_part.p : (const FusedPart *)nullptr,
+                         fused_n_tiles, fused_kb_ref);
     });
     HIPCHK(hipEventRecord(ev_stats, side));
     bool fin_on_side = false;
@@ -1355,21 +1395,49 @@ int fmr_synchronize(fmr_chain *c) {
   return FMR_OK;
 }
 
+// how many doubles per stream the blocks would produce, from copies of the count-law counters (nothing is advanced)
+static size_t predict_audio(const fmr_chain *c, const uint32_t *block_len, int nb) {
+  ResamplerCounter r = c->rsc, ar = c->arsc;
+  size_t total = 0;
+  for (int b = 0; b < nb; b++) {
+    const long long n_if = c->has_rs ? r.advance(c->rs, block_len[b]) : (long long)block_len[b];
+    if (!c->has_dec || n_if == 0) continue;
+    if (c->mode == FMR_MODE_FM) total += (size_t)ar.advance(c->ars, n_if) * (c->stereo ? 2 : 1);
+    else total += (size_t)n_if;
+  }
+  return total;
+}
+
 int fmr_process_blocks_device(fmr_chain *c, const float *d_iq, size_t stream_stride, const uint32_t *block_len,
                               int n_blocks, double *d_audio, size_t audio_stride, uint32_t *audio_len, int sync) {
-  if (!c || !d_iq || !block_len) return FMR_ERR_BAD_ARG;
-  const int rc = c->run_cold_aware((const float2 *)d_iq, stream_stride, block_len, n_blocks, d_audio, audio_stride, audio_len);
-  if (rc) return rc;
-  if (sync) HIPCHK(hipStreamSynchronize(c->stream));
-  return FMR_OK;
+  if (!c || !d_iq || !block_len || n_blocks < 1) return FMR_ERR_BAD_ARG;
+  try {
+    if (c->has_dec) {
+      if (!d_audio) { set_err("d_audio is null"); return FMR_ERR_BAD_ARG; }
+      if (n_blocks <= c->max_blocks && predict_audio(c, block_len, n_blocks) > audio_stride) {
+        set_err("audio_stride too small for the audio these blocks produce (nothing was processed)");
+        return FMR_ERR_CAPACITY;
+      }
+    }
+    const int rc = c->run_cold_aware((const float2 *)d_iq, stream_stride, block_len, n_blocks, d_audio, audio_stride, audio_len);
+    if (rc) return rc;
+    if (sync) HIPCHK(hipStreamSynchronize(c->stream));
+    return FMR_OK;
+  } catch (const std::exception &e) { set_err("exception: %s", e.what()); return FMR_ERR_HIP; }
 }
 
 int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, const uint32_t *block_len, int n_blocks,
                        double *audio, size_t audio_stride, uint32_t *audio_len) {
-  if (!c || !iq || !block_len) return FMR_ERR_BAD_ARG;
+  if (!c || !iq || !block_len || n_blocks < 1) return FMR_ERR_BAD_ARG;
+  try {
   size_t N_in = 0;
   for (int b = 0; b < n_blocks; b++) N_in += block_len[b];
   if (N_in > c->max_in) { set_err("input longer than max_block_len*max_blocks"); return FMR_ERR_CAPACITY; }
+  if (n_blocks <= c->max_blocks && c->has_dec && audio) {
+    // capacity is checked BEFORE any decoder state advances: a refused call can be retried with a larger buffer
+    const size_t need = predict_audio(c, block_len, n_blocks);
+    if (need > audio_stride) { set_err("audio capacity %zu too small: these blocks produce %zu doubles (nothing was processed)", audio_stride, need); return FMR_ERR_CAPACITY; }
+  }
   HIPCHK(hipSetDevice(c->cfg.device));
   if (N_in)
     HIPCHK(hipMemcpy2DAsync(c->d_in.p, (size_t)c->in_bps * c->max_in, iq, (size_t)c->in_bps * stream_stride,
@@ -1387,6 +1455,21 @@ int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, cons
                             sizeof(double) * total, c->S, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(hipStreamSynchronize(c->stream));
+  return FMR_OK;
+  } catch (const std::exception &e) { set_err("exception: %s", e.what()); return FMR_ERR_HIP; }
+}
+
+int fmr_fourth_convert(fmr_chain *c, const float *iq, size_t n, float *out_iq, int up, unsigned *index) {
+  if (!c || !index || (n && (!iq || !out_iq))) return FMR_ERR_BAD_ARG;
+  if (n == 0) return FMR_OK;
+  if (n > c->max_in || c->in_fmt != 0) { set_err("fmr_fourth_convert: block longer than the chain's capacity, or raw-format chain"); return FMR_ERR_CAPACITY; }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipMemcpyAsync(c->d_in.p, iq, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_fourth_shift, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, c->stream, c->d_in.p,
+                     c->d_in.p, (long long)n, *index & 3u, up);
+  HIPCHK(hipMemcpyAsync(out_iq, c->d_in.p, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *index = up ? (unsigned)((*index + 4u - (unsigned)(n & 3)) & 3u) : (unsigned)((*index + (unsigned)(n & 3)) & 3u);
   return FMR_OK;
 }
 
@@ -1457,7 +1540,7 @@ int fmr_get_status(fmr_chain *c, int stream, fmr_status *st) {
 }
 
 int fmr_get_pps_events(fmr_chain *c, int stream, fmr_pps_event *ev, int cap) {
-  if (!c || stream < 0 || stream >= c->S) return FMR_ERR_BAD_ARG;
+  if (!c || stream < 0 || stream >= c->S || cap < 0 || (cap > 0 && !ev)) return FMR_ERR_BAD_ARG;
   const int rc = fetch_state(c);
   if (rc) return rc;
   const StreamState &s = c->h_state[stream];
@@ -1465,7 +1548,7 @@ int fmr_get_pps_events(fmr_chain *c, int stream, fmr_pps_event *ev, int cap) {
     ev[i].pps_index = s.pps[i].pps_index;
     ev[i].sample_index = s.pps[i].sample_index;
     ev[i].block_position = s.pps[i].block_position;
-    ev[i].block = s.pps[i].block;
+    ev[i].block = s.pps[i].block + (uint32_t)c->pps_block_base;
     ev[i].stream = (uint32_t)stream;
   }
   return s.n_pps;

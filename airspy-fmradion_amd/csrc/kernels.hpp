@@ -130,6 +130,17 @@ __device__ __forceinline__ float2 fourth_rot(float2 v, unsigned idx) {
   }
 }
 
+// FourthConverterIQ::process as a stand-alone kernel (FourthConverterIQ.h:45-79): the table index advances by one
+// per sample (down: 0,1,2,3 -> x1, x(-j)..., up: 0,3,2,1); idx0 = the object's m_index at the call.
+__global__ void k_fourth_shift(const float2 *__restrict__ in, float2 *__restrict__ out, long long n, unsigned idx0, int up) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned step = (unsigned)(i & 3);
+    const unsigned idx = up ? (idx0 + 4u - step) & 3u : (idx0 + step) & 3u;
+    out[i] = fourth_rot(in[i], idx);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K_A  ifr_decim : front-end stage A, integer decimation by D with an NA-tap
 // linear-phase FIR.  The only kernel that touches every input IQ sample:
@@ -1132,21 +1143,60 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// one wave per stream: 64 block results per load, the EMA chain runs on SGPR broadcasts
+// Per-block statistics of the fused front end (kernels_fused.hpp) travel as partial sums over the 128 IF samples a
+// stage-B wave finishes at a time, cut at the (at most one) block boundary inside them.
+struct FusedPart {
+  int blk[2];            // block of the samples before / after the cut (-1: none)
+  float sum[2][3];       // sum d, sum d^2 (discriminator output), sum |x|^2 (IF) of each piece
+};
+
+// one wave per stream: 64 block results per load, the EMA chain runs on SGPR broadcasts.  part != nullptr: the block
+// values are summed here from the fused front end's pieces (index order: deterministic) instead of read from the
+// per-block arrays k_disc writes -- mean / rms of the discriminator output (Utility.h:135-152) and the IF RMS
+// (Utility.h:118-132, FmDecode.cpp:95).
 __global__ __launch_bounds__(64) void k_stats(BlockTab bt, const float *__restrict__ if_rms_blk,
                                               const float *__restrict__ bb_mean_blk,
                                               const float *__restrict__ bb_rms_blk, StreamState *st, int n_streams,
-                                              int has_disc) {
+                                              int has_disc, const FusedPart *__restrict__ part = nullptr, int n_tiles = 0,
+                                              int kb_ref = 0) {
   const int s = blockIdx.x;
   const int lane = threadIdx.x;
   if (s >= n_streams) return;
   float m = st[s].baseband_mean, l = st[s].baseband_level, r = st[s].if_rms;
-  for (int b0 = 0; b0 < bt.nb; b0 += 64) {
+  // The EMAs forget: 0.95^400 = 1.2e-9 is below half a float ulp of the result, so only the last ~400 non-empty blocks
+  // of a long call can be seen in the float state -- the walk starts there (it was 0.2 ms of one wave for 2048 blocks).
+  int b_first = 0;
+  {
+    int seen = 0;
+    for (int b0 = ((bt.nb - 1) / 64) * 64; b0 > 0; b0 -= 64) {
+      const int b = b0 + lane;
+      seen += __popcll(__ballot(b < bt.nb && bt.if_len[b] != 0));
+      if (seen >= 400) { b_first = b0; break; }
+    }
+  }
+  for (int b0 = b_first; b0 < bt.nb; b0 += 64) {
     const int b = min(b0 + lane, bt.nb - 1);
     const int my_n = bt.if_len[b];
-    const float my_r = if_rms_blk[(long long)s * bt.nb + b];
-    const float my_m = bb_mean_blk[(long long)s * bt.nb + b];
-    const float my_l = bb_rms_blk[(long long)s * bt.nb + b];
+    float my_r, my_m, my_l;
+    if (part) {
+      float sd = 0.f, sq = 0.f, se = 0.f;
+      if (my_n) {
+        const int lo = bt.if_off[b], hi = lo + my_n - 1, ng = 3 * n_tiles;
+        const int g0 = (lo - kb_ref) / 128, g1 = min((hi - kb_ref) / 128, ng - 1);   // thirds that hold samples of the block
+        for (int g = g0; g <= g1; g++) {
+          const FusedPart pt = part[(long long)s * ng + g];
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+            if (pt.blk[h] == b) { sd += pt.sum[h][0]; sq += pt.sum[h][1]; se += pt.sum[h][2]; }
+        }
+      }
+      const float fn = (float)(unsigned)(my_n ? my_n : 1);
+      my_m = sd / fn; my_l = sqrtf(sq / fn); my_r = sqrtf(se / fn);
+    } else {
+      my_r = if_rms_blk[(long long)s * bt.nb + b];
+      my_m = bb_mean_blk[(long long)s * bt.nb + b];
+      my_l = bb_rms_blk[(long long)s * bt.nb + b];
+    }
     const int cnt = min(64, bt.nb - b0);
     for (int j = 0; j < cnt; j++) {
       if (__builtin_amdgcn_readlane(my_n, j) == 0) continue;

@@ -28,18 +28,12 @@
 
 namespace fmr {
 
-// Per-block statistics travel as partial sums over the 128 IF samples a stage-B wave finishes at a time, cut at the
-// (at most one) block boundary inside them; k_fused_blk_reduce adds the pieces of a block in index order.
-struct FusedPart {
-  int blk[2];            // block of the samples before / after the cut (-1: none)
-  float sum[2][3];       // sum d, sum d^2 (discriminator output), sum |x|^2 (IF) of each piece
-};
-
 // Everything is call-relative and 32-bit on the device: the host folds the absolute stream positions into a few
 // reference values of the call's first epoch (E_ref = 4 T_first - 1).
 struct FusedArgs {
   const float2 *iq; long long iq_stride; long long n_valid;   // this call's input (per stream: iq + s * iq_stride)
   const float2 *in_halo; int H_in;                            // last H_in input samples of the previous call
+  const float *taps;                                          // device copy of FusedTaps::h (read through scalar loads)
   long long nbase;            // region start (local input index, even) of an epoch whose first output is j = 0:
                               //   nb(E) = nbase + D * jE(E),  nbase = n0 + ca - (NA - 1) - par
   int j_ref;                  // jE(E_ref): call-relative index (m - mA_prev) of the first mid sample of epoch E_ref
@@ -70,10 +64,10 @@ struct FusedArgs {
 #endif
 // cycle counters only in the instrumented ablation builds (s_memtime costs ~100 cycles of latency per read)
 #define FUSED_CLK() (DBG ? __builtin_readcyclecounter() : 0ull)
-#define FUSED_TAP_PAD 8
-#define FUSED_TAP_LEN 96
-// Stage-A taps travel in the kernel-argument segment; the filter is symmetric (linear phase), so only the first
-// half is sent: h[FUSED_TAP_PAD + k] = hA[k], k = 0 .. (NA-1)/2.
+#define FUSED_TAP_PAD 32
+#define FUSED_TAP_LEN 232
+// Stage-A taps travel in the kernel-argument segment (constant address space): every tap load is a scalar load.
+// h[FUSED_TAP_PAD + k] = hA[k], zeros elsewhere.
 struct FusedTaps { float h[FUSED_TAP_LEN]; };
 
 #ifndef FUSED_OPL
@@ -91,11 +85,12 @@ struct FusedShape {
   static constexpr int NSLOT = (OPL == 3) ? 3 : 5, AHEAD = NSLOT - 1;   // ring slots; the loader runs AHEAD epochs in front of stage A
   static constexpr int NWORDS = ((OPL - 1) * D + NA + 2) / 2;           // 16-byte words a stage-A lane reads
   static constexpr int MIDR = 3000, MIDM = 207;  // mid ring: three macro-tile windows + mirror of the first 207
-  static constexpr int LDS_BYTES = NSLOT * RS * 8 + (MIDR + MIDM + 1) * 8 + 384 * 8 + 64;
+  static constexpr int SIDE = 2 * ME;            // k-split form: partial sums of the second half-wave, double buffered (float2)
+  static constexpr int LDS_BYTES = NSLOT * RS * 8 + (MIDR + MIDM + 1) * 8 + 384 * 8 + SIDE * 8 + 64;
   static constexpr int NT = (NA + 1) / 2;        // distinct taps of the symmetric filter
   static_assert((OPL * D) % 2 == 0 && ((OPL * D / 2) & 1) == 1, "lane stride must be an odd number of 16-byte words");
   static_assert(NA - D + 1 + D * ME <= RS, "slot too small");
-  static_assert((NA & 1) == 1 && NT + FUSED_TAP_PAD <= FUSED_TAP_LEN, "odd symmetric filter");
+  static_assert((NA & 1) == 1 && NA + 2 * FUSED_TAP_PAD <= FUSED_TAP_LEN, "tap table");
   static_assert((AHEAD - 1) * NDMA <= 63, "vmcnt is a 6-bit counter");
   static_assert(LPW <= 64 && 4 * LPW * OPL >= ME, "four stage-A waves cover an epoch");
 };
@@ -107,7 +102,7 @@ template <int NT>
 struct FusedTapRegs {
   typedef float v2f __attribute__((ext_vector_type(2)));
   v2f p[(NT + 1) / 2];
-  __device__ __forceinline__ void load(const float *h) {
+  __device__ __forceinline__ void load_sym(const float *h) {      // h[k] = hA[k]: the first NT taps of the symmetric filter
 #pragma unroll
     for (int j = 0; j < (NT + 1) / 2; j++) {
       p[j] = (v2f){h[2 * j], (2 * j + 1 < NT) ? h[2 * j + 1] : 0.f};
@@ -266,6 +261,105 @@ __device__ __forceinline__ void fused_stage_a(const FusedArgs &a, const FusedTap
   }
 }
 
+// ---- role: stage A, k-split form (12-wave workgroup) --------------------------------------------------------
+// Two waves on the same SIMD share each group of 42 x 3 outputs: wave HALF = 0 runs the first half of the window
+// (steps 0 .. NH-1) and stores into the mid ring, HALF = 1 the second and stores into a side buffer; the first wave
+// adds the two one epoch later (fused_a_fixup; LDS float atomics cost microseconds).  One wave alone issues a packed
+// FMA only every ~6 cycles; two co-resident waves fill the SIMD.  Taps are wave-uniform scalar loads (one group ahead).
+template <int D, int NA, int PAR, int HALF>
+__device__ __forceinline__ void fused_stage_a_half(const FusedArgs &a, const FusedTaps &taps, int s, int jE, int pos0,
+                                                   const unsigned char *slot, float2 *midr, float2 *side, int aw, int lane, bool no_math) {
+  using SH = FusedShape<D, NA>;
+  static_assert(SH::OPL == 3, "k-split form: three outputs per lane");
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  if (lane >= SH::LPW) return;
+  const int L = SH::LPW * aw + lane;
+  constexpr int HD = D / 2, NSTEP = (PAR + NA - 1) / 2 + 1, NH = (NSTEP + 1) / 2;
+  constexpr int I0 = HALF ? NH : 0, I1 = HALF ? NSTEP : NH, G = 4, PF = 8, NGRP = (I1 - I0 + G - 1) / G;
+  // tap pair of step i: hq[-2 i], hq[-2 i - 1]; the table sits in the kernarg segment (constant address space => s_load)
+  typedef const __attribute__((address_space(4))) float *cptr;
+  cptr hq = (cptr)(uintptr_t)(a.taps + FUSED_TAP_PAD + PAR + (NA - 1));
+  asm volatile("" : "+s"(hq));
+  const v4f *w = reinterpret_cast<const v4f *>(__builtin_assume_aligned(slot, 16)) + (3 * HD) * L;
+  v2f acc[3][2];
+#pragma unroll
+  for (int o = 0; o < 3; o++) acc[o][0] = acc[o][1] = (v2f){0.f, 0.f};
+  if (!no_math) {
+    v4f x[SH::NWORDS + G + PF];
+#pragma unroll
+    for (int i = I0; i < I0 + 2 * HD + PF && i < SH::NWORDS; i++) x[i] = w[i];
+    float hk[2][2 * G];
+#pragma unroll
+    for (int t = 0; t < 2 * G; t++) hk[0][t] = hq[-2 * I0 - t];
+#pragma unroll
+    for (int g = 0; g < NGRP; g++) {
+#pragma unroll
+      for (int t = 0; t < G; t++) {            // words first used two groups from now
+        const int i = I0 + 2 * HD + PF + G * g + t;
+        if (i < SH::NWORDS && i < I1 + 2 * HD) x[i] = w[i];
+      }
+      // taps of the next group (the table is zero padded).  The pointer is laundered per group: with a compile-time
+      // address the compiler loads all taps up front and spills them through v_writelane / v_readlane
+      asm volatile("" : "+s"(hq));
+#pragma unroll
+      for (int t = 0; t < 2 * G; t++) hk[(g + 1) & 1][t] = hq[-2 * (I0 + G * (g + 1)) - t];
+#pragma unroll
+      for (int t = 0; t < G; t++) {
+        const int i = I0 + G * g + t;
+        if (i < I1) {
+          const float h0 = hk[g & 1][2 * t], h1 = hk[g & 1][2 * t + 1];
+#pragma unroll
+          for (int o = 0; o < 3; o++) {
+            const v4f xx = x[i + HD * o];
+            acc[o][0] = __builtin_elementwise_fma((v2f){h0, h0}, (v2f){xx.x, xx.y}, acc[o][0]);
+            acc[o][1] = __builtin_elementwise_fma((v2f){h1, h1}, (v2f){xx.z, xx.w}, acc[o][1]);
+          }
+        }
+      }
+      // pin this group's FMAs here: without it instruction selection sinks every FMA below the last load
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 3; o++) {
+    const int jl = 3 * L + o;
+    if (jl >= SH::ME) continue;
+    float2 y = make_float2(acc[o][0].x + acc[o][1].x, acc[o][0].y + acc[o][1].y);
+    if (HALF) { side[jl] = y; continue; }           // added to the ring by the first-half wave one epoch later
+    int pos = pos0 + jl;
+    if (pos >= SH::MIDR) pos -= SH::MIDR;
+    midr[pos] = y;
+  }
+}
+
+// One epoch later: ring += second half's partial sum (the sum of two operands does not depend on the order), the
+// overrides for samples of earlier calls, the mirror of the ring's first positions and the next call's history.
+template <int D, int NA>
+__device__ __forceinline__ void fused_a_fixup(const FusedArgs &a, int s, int jE, int pos0, float2 *midr, const float2 *side, int aw, int lane) {
+  using SH = FusedShape<D, NA>;
+  if (lane >= SH::LPW) return;
+  const int L = SH::LPW * aw + lane;
+#pragma unroll
+  for (int o = 0; o < 3; o++) {
+    const int jl = 3 * L + o, j = jE + jl;
+    if (jl >= SH::ME) continue;
+    int pos = pos0 + jl;
+    if (pos >= SH::MIDR) pos -= SH::MIDR;
+    const float2 p0 = midr[pos], p1 = side[jl];
+    float2 y = make_float2(p0.x + p1.x, p0.y + p1.y);
+    if (j < 0) {                     // produced by an earlier call: its tail is the prefix halo of d_mid, older samples are never used
+      const int h = j + a.H_mid;
+      y = (h >= 0) ? a.mid[(long long)s * a.mid_stride + h] : make_float2(0.f, 0.f);
+    }
+    midr[pos] = y;
+    if (pos < SH::MIDM) midr[pos + SH::MIDR] = y;
+    // the next call's stage-B history: the last H_mid mid samples of this call, at their d_mid positions (k_shift_halo re-seats them)
+    if (j >= a.count_mid - a.H_mid && j < a.count_mid && j >= 0) a.mid[(long long)s * a.mid_stride + a.H_mid + j] = y;
+  }
+}
+
 // ---- role: stage B (a quarter of the k-steps of a macro tile per epoch) -----------------------------------
 template <int MT0, int NMT>
 struct FusedB {
@@ -413,7 +507,7 @@ __device__ __forceinline__ float fused_prev_phase(const FusedArgs &a, const floa
   return atan2f(im, re) / a.nf;
 }
 
-template <int EPT, int MT0, bool OFF, bool DBG>
+template <int EPT, int LAG, int MT0, bool OFF, bool DBG>
 __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, int t3, int nt, int NE, const float2 *midr, float2 *stage, int lane, int wave) {
   FusedB<MT0, 1> b;
   b.load(a.afrag, lane);
@@ -429,12 +523,12 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
   unsigned long long busy = 0, t_begin = FUSED_CLK();
   for (int e = 0; e < NE; e++) {
     const unsigned long long tb = FUSED_CLK();
-    if (e == EPT + 1 && a.base && MT0 == 0) {
+    if (e == EPT + 1 + LAG && a.base && MT0 == 0) {
       // the sample before this workgroup's first one: previous call (disc_save), or recomputed from the warm-up mid samples
       if (kb <= 0) prev_tile = save0;
       else { float v = 0.f; if (lane == 0) v = fused_prev_phase(a, midr, p); prev_tile = __shfl(v, 0, 64); }
     }
-    if (e >= 2 * EPT + 1 && ((e - 1) % EPT) == 0) {  // epilogue of the tile staged at the end of the previous epoch
+    if (e >= 2 * EPT + 1 + LAG && ((e - 1 - LAG) % EPT) == 0) {  // epilogue of the tile staged at the end of the previous epoch
       if (a.base) {
         // phase of the sample before this wave's third: the previous tile's last sample (wave 0) or staged sample 128 MT0 - 1
         float prev0;
@@ -452,7 +546,7 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
       }
       kb += 384; tile_g++;
     }
-    if (!OFF && e >= EPT + 1 && e <= EPT * nt + EPT) {
+    if (!OFF && e >= EPT + 1 + LAG && e <= EPT * nt + EPT + LAG) {
       b.template epoch<EPT>(q, p, midr, stage, lane);
       if (++q == EPT) { q = 0; p = (p == 2000) ? 0 : p + 1000; }
     }
@@ -490,8 +584,12 @@ __global__ void k_fused_blk_reduce(const FusedPart *__restrict__ part, int n_til
 }
 
 // ABL: ablation mask for tools/bench_fused.hip (0 = product; 1 no stage-A arithmetic, 2 no stage-B MFMAs, 4 no input DMA)
+#ifndef FUSED_KSPLIT
+#define FUSED_KSPLIT 1        // 12-wave workgroup, stage A split over two waves per SIMD (needs FUSED_OPL = 3)
+#endif
+#define FUSED_THREADS (FUSED_KSPLIT ? 768 : 512)
 template <int D, int NA, int PAR, int ABL = 0>
-__global__ __launch_bounds__(512) void k_ifr_fused(FusedArgs a, FusedTaps taps) {
+__global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedTaps taps) {
   using SH = FusedShape<D, NA>;
   constexpr bool DBG = (ABL & 32) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_f[];
@@ -502,7 +600,7 @@ __global__ __launch_bounds__(512) void k_ifr_fused(FusedArgs a, FusedTaps taps) 
   const int i0 = blockIdx.x * a.tiles_per_wg;
   const int i1 = min(i0 + a.tiles_per_wg, a.n_tiles);
   if (i0 >= i1) return;
-  const int nt = i1 - i0, NE = SH::EPT * nt + SH::EPT + 2, EA = SH::EPT * nt;       // EA = last stage-A epoch
+  const int nt = i1 - i0, NE = SH::EPT * nt + SH::EPT + 2 + FUSED_KSPLIT, EA = SH::EPT * nt;       // EA = last stage-A epoch
   const int jE0 = a.j_ref + 1000 * i0;                         // first mid sample of epoch 0 (a macro tile = 1000 mid samples)
   const int pos00 = (a.pos_ref + 1000 * (i0 % 3)) % SH::MIDR;
   const int t3 = (a.t3_ref + i0) % 3;
@@ -547,16 +645,41 @@ __global__ __launch_bounds__(512) void k_ifr_fused(FusedArgs a, FusedTaps taps) 
     if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[0] = busy; a.dbg[1] = FUSED_CLK() - t_begin; }
   } else if (wave == 1) {
     // ------------------------------------------------------------------ stage B (one row tile per wave) + a third of the epilogue
-    fused_role_b<SH::EPT, 0, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, FUSED_KSPLIT, 0, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
   } else if (wave == 2) {
-    fused_role_b<SH::EPT, 1, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, FUSED_KSPLIT, 1, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
   } else if (wave == 3) {
-    fused_role_b<SH::EPT, 2, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, FUSED_KSPLIT, 2, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+  } else if (FUSED_KSPLIT) {
+    // ------------------------------------------------------------------ stage A, two half-waves per output group
+    const int aw = (wave - 4) & 3, half = (wave - 4) >> 2;
+    float2 *side = stage + 384;
+    fused_barrier();
+    int slot = 0, pos0 = pos00, jE = jE0;
+    unsigned long long busy = 0, t_begin = FUSED_CLK();
+    for (int e = 0; e < NE; e++) {
+      const unsigned long long tb = FUSED_CLK();
+      if (half == 0 && e >= 1 && e <= EA + 1) {           // the epoch before this one: add the second half's partial sums
+        int pp = pos0 - SH::ME; if (pp < 0) pp += SH::MIDR;
+        fused_a_fixup<D, NA>(a, s, jE - SH::ME, pp, midr, side + ((e - 1) & 1) * SH::ME, aw, lane);
+      }
+      if (e <= EA) {
+        const unsigned char *sl = lds_f + (size_t)slot * SH::RS * 8;
+        if (half == 0) fused_stage_a_half<D, NA, PAR, 0>(a, taps, s, jE, pos0, sl, midr, side + (e & 1) * SH::ME, aw, lane, (ABL & 1) != 0);
+        else fused_stage_a_half<D, NA, PAR, 1>(a, taps, s, jE, pos0, sl, midr, side + (e & 1) * SH::ME, aw, lane, (ABL & 1) != 0);
+        slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
+      }
+      if (e <= EA + 1) { pos0 += SH::ME; if (pos0 >= SH::MIDR) pos0 -= SH::MIDR; jE += SH::ME; }
+      if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      busy += FUSED_CLK() - tb;
+      fused_barrier();
+    }
+    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wave < 8) { a.dbg[2 * wave] = busy; a.dbg[2 * wave + 1] = FUSED_CLK() - t_begin; }
   } else {
-    // ------------------------------------------------------------------ stage A
+    // ------------------------------------------------------------------ stage A (8-wave workgroup: one wave per output group)
     const int aw = wave - 4;
     FusedTapRegs<SH::NT> tv;
-    tv.load(taps.h + FUSED_TAP_PAD);
+    tv.load_sym(taps.h + FUSED_TAP_PAD);
     fused_barrier();
     int slot = 0, pos0 = pos00, jE = jE0;
     unsigned long long busy = 0, t_begin = FUSED_CLK();

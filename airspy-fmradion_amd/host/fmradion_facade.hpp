@@ -22,9 +22,14 @@
 //    through host vectors, as in main.cpp).
 //  * IfResampler / AudioResampler arithmetic is this project's resampler
 //    specification, not r8brain's (absent from the reference tree).
+//  * Errors: the reference classes cannot fail and throw nothing.  A failing HIP call here is fatal in the way
+//    main.cpp treats its own fatal errors (message on stderr, exit(1), main.cpp:764-767); define
+//    FMR_FACADE_THROW before including this header to get std::runtime_error instead (the tests do).
 #pragma once
 #include <complex>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -42,7 +47,21 @@ enum class ModType { FM, NBFM, AM, DSB, USB, LSB, CW, WSPR };   // include/SoftF
 
 namespace fmr_detail {
 inline void check(int rc, const char *what) {
-  if (rc != FMR_OK) throw std::runtime_error(std::string(what) + ": " + fmr_last_error());
+  if (rc == FMR_OK) return;
+#ifdef FMR_FACADE_THROW
+  throw std::runtime_error(std::string(what) + ": " + fmr_last_error());
+#else
+  std::fprintf(stderr, "ERROR: %s: %s\n", what, fmr_last_error());
+  std::exit(1);
+#endif
+}
+inline void fail(const char *what) {
+#ifdef FMR_FACADE_THROW
+  throw std::runtime_error(what);
+#else
+  std::fprintf(stderr, "ERROR: %s\n", what);
+  std::exit(1);
+#endif
 }
 inline fmr_chain *make(const fmr_config &cfg) {
   fmr_chain *c = nullptr;
@@ -57,7 +76,7 @@ struct FilterParameters {
     const void *p = nullptr;
     int dbl = 0;
     const int n = fmr_filter_table(name, &p, &dbl);
-    if (n < 0 || dbl) throw std::runtime_error("unknown IQ filter table");
+    if (n < 0 || dbl) { fmr_detail::fail("unknown IQ filter table"); return {}; }
     const float *f = static_cast<const float *>(p);
     return IQSampleCoeff(f, f + n);
   }
@@ -65,7 +84,7 @@ struct FilterParameters {
     const void *p = nullptr;
     int dbl = 0;
     const int n = fmr_filter_table(name, &p, &dbl);
-    if (n < 0 || !dbl) throw std::runtime_error("unknown audio filter table");
+    if (n < 0 || !dbl) { fmr_detail::fail("unknown audio filter table"); return {}; }
     const double *f = static_cast<const double *>(p);
     return SampleCoeff(f, f + n);
   }
@@ -84,21 +103,50 @@ struct FilterParameters {
   static inline const SampleCoeff jj1bdx_48khz_nbfmaudio = audio("jj1bdx_48khz_nbfmaudio");
 };
 
-// IfResampler::process(const IQSampleVector&, IQSampleVector&)  (IfResampler.h:35-38)
+// FourthConverterIQ (FourthConverterIQ.h:30-82): Fs/4 shift, exact.  Stand-alone use costs a PCIe round trip per
+// block; a decoder with attach_front_end(rate, true) applies the same shift inside its front-end kernel.
+class FourthConverterIQ {
+public:
+  explicit FourthConverterIQ(bool up, int device = 0) : m_up(up) {
+    fmr_config cfg{};
+    cfg.device = device; cfg.n_streams = 1; cfg.mode = -1; cfg.input_rate = 384000.0;
+    cfg.max_block_len = 65536; cfg.max_blocks = 1;
+    m_chain = fmr_detail::make(cfg);
+  }
+  ~FourthConverterIQ() { fmr_destroy(m_chain); }
+  FourthConverterIQ(const FourthConverterIQ &) = delete;
+  FourthConverterIQ &operator=(const FourthConverterIQ &) = delete;
+  void process(const IQSampleVector &samples_in, IQSampleVector &samples_out) {
+    samples_out.resize(samples_in.size());
+    fmr_detail::check(fmr_fourth_convert(m_chain, reinterpret_cast<const float *>(samples_in.data()), samples_in.size(),
+                                         reinterpret_cast<float *>(samples_out.data()), m_up ? 1 : 0, &m_index),
+                      "fmr_fourth_convert");
+  }
+
+private:
+  fmr_chain *m_chain = nullptr;
+  unsigned m_index = 0;          // FourthConverterIQ.h:31
+  const bool m_up;
+};
+
+// IfResampler::process(const IQSampleVector&, IQSampleVector&)  (IfResampler.h:35-38), any pair of integer rates the
+// resampler design covers (384 kHz for FM, 48 kHz for the AM / NBFM decoders, main.cpp:775-777).  Equal rates: a copy
+// (main.cpp does not call process() then, :778,925-929).
 class IfResampler {
 public:
   static constexpr int max_input_length = 65536;   // IfResampler.h:31
   IfResampler(const double input_rate, const double output_rate, int device = 0) {
-    if (output_rate != 384000.0) throw std::runtime_error("IfResampler facade: the FM IF rate is 384 kHz; AM chains fuse their front end (AmDecoder::attach_front_end)");
+    if (input_rate == output_rate) return;
     fmr_config cfg{};
-    cfg.device = device; cfg.n_streams = 1; cfg.mode = -1; cfg.input_rate = input_rate;
+    cfg.device = device; cfg.n_streams = 1; cfg.mode = -1; cfg.input_rate = input_rate; cfg.output_rate = output_rate;
     cfg.enable_resampler = 1; cfg.max_block_len = max_input_length; cfg.max_blocks = 1;
     m_chain = fmr_detail::make(cfg);
   }
-  ~IfResampler() { fmr_destroy(m_chain); }
+  ~IfResampler() { if (m_chain) fmr_destroy(m_chain); }
   IfResampler(const IfResampler &) = delete;
   IfResampler &operator=(const IfResampler &) = delete;
   void process(const IQSampleVector &samples_in, IQSampleVector &samples_out) {
+    if (!m_chain) { samples_out = samples_in; return; }
     samples_out.resize(samples_in.size() + 64);
     size_t n = 0;
     fmr_detail::check(fmr_resample(m_chain, reinterpret_cast<const float *>(samples_in.data()), samples_in.size(),
@@ -160,6 +208,8 @@ public:
                                   audio.data(), audio.size(), &n),
                       "fmr_process");
     audio.resize(n);
+    m_pps_fetched = false;       // PilotPhaseLock::process clears m_pps_events on every call (PilotPhaseLock.cpp:62)
+    m_pps.clear();
   }
   bool stereo_detected() { return status().stereo_detected != 0; }
   float get_tuning_offset() { return status().baseband_mean * freq_dev; }
@@ -167,15 +217,15 @@ public:
   double get_pilot_level() { return status().pilot_level; }
   float get_if_rms() { return status().if_rms; }
   double get_multipath_error() { return status().multipath_error; }
+  // Events of the most recent process() call; erase_first_pps_event() consumes them one by one (main.cpp:1087-1094).
   std::vector<PilotPhaseLock::PpsEvent> get_pps_events() {
-    fmr_pps_event ev[64];
-    const int n = fmr_get_pps_events(m_chain, 0, ev, 64);
-    std::vector<PilotPhaseLock::PpsEvent> out;
-    for (int i = (int)m_pps_erased; i < n && i < 64; i++)
-      out.push_back({ev[i].pps_index, ev[i].sample_index, ev[i].block_position});
-    return out;
+    fetch_pps();
+    return m_pps;
   }
-  void erase_first_pps_event() { m_pps_erased++; }
+  void erase_first_pps_event() {
+    fetch_pps();
+    if (!m_pps.empty()) m_pps.erase(m_pps.begin());
+  }
   const std::vector<std::complex<float>> &get_multipath_coefficients() {
     m_coeff.resize(1300);
     const int n = fmr_get_multipath_coefficients(m_chain, 0, reinterpret_cast<float *>(m_coeff.data()), 2600);
@@ -189,10 +239,19 @@ private:
     fmr_detail::check(fmr_get_status(m_chain, 0, &st), "fmr_get_status");
     return st;
   }
+  void fetch_pps() {
+    if (m_pps_fetched) return;
+    fmr_pps_event ev[64];
+    const int n = fmr_get_pps_events(m_chain, 0, ev, 64);
+    m_pps.clear();
+    for (int i = 0; i < n && i < 64; i++) m_pps.push_back({ev[i].pps_index, ev[i].sample_index, ev[i].block_position});
+    m_pps_fetched = true;
+  }
   fmr_config m_cfg{};
   fmr_chain *m_chain = nullptr;
   bool m_stereo;
-  unsigned m_pps_erased = 0;
+  bool m_pps_fetched = true;
+  std::vector<PilotPhaseLock::PpsEvent> m_pps;
   std::vector<std::complex<float>> m_coeff;
 };
 
@@ -202,9 +261,11 @@ public:
   static constexpr double sample_rate_pcm = 48000;
   static constexpr double internal_rate_pcm = 48000;
   AmDecoder(IQSampleCoeff &amfilter_coeff, const ModType mode, int device = 0) {
-    if (mode == ModType::FM || mode == ModType::NBFM) throw std::runtime_error("AmDecoder: FM modes have their own decoders");
+    // main.cpp:813 constructs the AmDecoder whatever the mode; with an FM mode it is never used (AmDecode.cpp:96-147
+    // has no case for it): build it as an AM decoder
     m_cfg = fmr_config{};
-    m_cfg.device = device; m_cfg.n_streams = 1; m_cfg.mode = static_cast<int>(mode);   // FMR_MODE_* follow ModType
+    m_cfg.device = device; m_cfg.n_streams = 1;
+    m_cfg.mode = (mode == ModType::FM || mode == ModType::NBFM) ? FMR_MODE_AM : static_cast<int>(mode);   // FMR_MODE_* follow ModType
     m_cfg.input_rate = internal_rate_pcm; m_cfg.filter_coeff = amfilter_coeff.data();
     m_cfg.n_filter_coeff = (int)amfilter_coeff.size(); m_cfg.max_block_len = 65536; m_cfg.max_blocks = 1;
     m_chain = fmr_detail::make(m_cfg);

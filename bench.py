@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BLK = 65536                    # Airspy block length (main.cpp:687)
 FS = 10e6
 AM_BLK, AM_FS = 2048, 384e3    # FileSource default block length (FileSource.h:34), configs[2] rate
-STAGE_KERNELS = ("ifr_fused", "blk_reduce", "ifr_decim", "ifr_poly", "disc")
+STAGE_KERNELS = ("ifr_fused", "ifr_decim", "ifr_poly", "disc")
 
 
 def synth_fm_stereo_torch(n, fs, stream_id, device):

@@ -87,6 +87,9 @@ typedef struct {
    * interleaved I,Q samples of that type; counts and strides stay in IQ samples; raw-format device buffers and
    * strides must be 16-byte aligned. */
   int input_format;           /* FMR_IQ_CF32 (default) | FMR_IQ_S16 | FMR_IQ_U8 | FMR_IQ_S8 */
+  /* Front-end-only chains (mode = -1): IfResampler(input_rate, output_rate) of include/IfResampler.h:35; 0 = the FM
+   * IF rate (384 kHz).  Decoder chains ignore it (their rate is fixed: FmDecode.h:38, AmDecode.h:36). */
+  double output_rate;
 } fmr_config;
 
 /* Per-stream status after the most recent call (getters of FmDecode.h:77-105 /
@@ -153,6 +156,11 @@ int fmr_synchronize(fmr_chain *c);
  * chain created with enable_resampler; bypasses the decoder.  Host buffers. */
 int fmr_resample(fmr_chain *c, const float *iq, size_t n, float *out_iq,
                  size_t out_cap, size_t *n_out);
+
+/* --- FourthConverterIQ::process (include/FourthConverterIQ.h:38-82) on host buffers: multiply by the Fs/4 table,
+ * `up` selects FourthConverterIQ(true); `index` (in/out, 0..3) is the object's m_index.  Exact (+-1, +-j swaps).
+ * Decoder chains fuse the shift into their front-end kernel instead (enable_fourth_down). */
+int fmr_fourth_convert(fmr_chain *c, const float *iq, size_t n, float *out_iq, int up, unsigned *index);
 
 int fmr_get_status(fmr_chain *c, int stream, fmr_status *st);
 /* PPS events of the most recent call (FmDecode.h:92); returns the count. */

@@ -2,6 +2,7 @@
 // when a GPU is present, pushes one block through FmDecoder::process.  CPU: the
 // constructors must fail loudly (no fallback).
 #include <cstdio>
+#define FMR_FACADE_THROW
 #include "../airspy-fmradion_amd/host/fmradion_facade.hpp"
 
 int main() {

@@ -1,0 +1,72 @@
+// A stand-in for the reference's stream loop (main.cpp:879-1002, variant A of INTEGRATION.md): the same objects,
+// constructed the same way (main.cpp:771-829), called in the same order on every block -- against the facade header.
+// Source and sink are files instead of SDR hardware / sound card (those sit outside the hot path):
+//   stream_loop <mode fm|nbfm|am|dsb|usb|lsb|cw|wspr> <ifrate> <fourth 0|1> <blocklen> <in.cf32> <audio.f64> <pps.txt>
+// Audio is written WITH the -6 dB of main.cpp:1000-1002; PPS lines carry pps_index, sample_index, block_position, block.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#define FMR_FACADE_THROW
+#include "../airspy-fmradion_amd/host/fmradion_facade.hpp"
+
+int main(int argc, char **argv) {
+  if (argc < 8) return 2;
+  const std::string m = argv[1];
+  const double ifrate = atof(argv[2]);
+  const bool enable_fs_fourth_downconverter = atoi(argv[3]) != 0;
+  const size_t blocklen = (size_t)atol(argv[4]);
+  ModType modtype = ModType::FM;
+  if (m == "nbfm") modtype = ModType::NBFM; else if (m == "am") modtype = ModType::AM; else if (m == "dsb") modtype = ModType::DSB;
+  else if (m == "usb") modtype = ModType::USB; else if (m == "lsb") modtype = ModType::LSB; else if (m == "cw") modtype = ModType::CW;
+  else if (m == "wspr") modtype = ModType::WSPR;
+  const double demodulator_rate = (modtype == ModType::FM) ? FmDecoder::sample_rate_if : AmDecoder::internal_rate_pcm;   // main.cpp:713-723
+  FILE *fin = fopen(argv[5], "rb"), *fau = fopen(argv[6], "wb"), *fpps = fopen(argv[7], "w");
+  if (!fin || !fau || !fpps) return 3;
+  try {
+    FourthConverterIQ fourth_downconverter(false);
+    IfResampler if_resampler(ifrate, demodulator_rate);
+    const bool enable_downsampling = (ifrate != demodulator_rate);
+    IQSampleCoeff amfilter_coeff = FilterParameters::jj1bdx_am_48khz_narrow;       // -f narrow for the AM family
+    IQSampleCoeff fmfilter_coeff = FilterParameters::delay_3taps_only_iq;         // -f default for FM
+    IQSampleCoeff nbfmfilter_coeff = FilterParameters::jj1bdx_nbfm_48khz_default;
+    AmDecoder am(amfilter_coeff, modtype);
+    FmDecoder fm(false, fmfilter_coeff, true, FmDecoder::deemphasis_time_eu, false, 0);
+    NbfmDecoder nbfm(nbfmfilter_coeff, NbfmDecoder::freq_dev_normal);
+    const float squelch_level = 0.0f;
+    for (unsigned long long block = 0;; block++) {
+      IQSampleVector iqsamples(blocklen);
+      const size_t got = fread(iqsamples.data(), sizeof(IQSample), blocklen, fin);
+      if (got == 0) break;
+      iqsamples.resize(got);
+      IQSampleVector if_shifted_samples, if_samples;
+      SampleVector audiosamples(0);
+      if (enable_fs_fourth_downconverter) fourth_downconverter.process(iqsamples, if_shifted_samples);
+      else if_shifted_samples = std::move(iqsamples);
+      if (enable_downsampling) if_resampler.process(if_shifted_samples, if_samples);
+      else if_samples = std::move(if_shifted_samples);
+      if (if_samples.empty()) continue;
+      double if_rms = 0.0;
+      switch (modtype) {
+      case ModType::FM: fm.process(if_samples, audiosamples); if_rms = fm.get_if_rms(); break;
+      case ModType::NBFM: nbfm.process(if_samples, audiosamples); if_rms = nbfm.get_if_rms(); break;
+      default: am.process(if_samples, audiosamples); if_rms = am.get_if_rms(); break;
+      }
+      if (audiosamples.empty()) continue;
+      const double g = if_rms >= squelch_level ? 0.5 : 0.0;
+      for (auto &v : audiosamples) v *= g;
+      fwrite(audiosamples.data(), sizeof(double), audiosamples.size(), fau);
+      if (modtype == ModType::FM) {
+        for (const PilotPhaseLock::PpsEvent &ev : fm.get_pps_events()) {
+          fprintf(fpps, "%llu %llu %.17g %llu\n", (unsigned long long)ev.pps_index, (unsigned long long)ev.sample_index, ev.block_position, block);
+          fm.erase_first_pps_event();
+        }
+      }
+    }
+  } catch (const std::exception &e) {
+    std::printf("no gpu: %s\n", e.what());
+    return 10;
+  }
+  fclose(fin); fclose(fau); fclose(fpps);
+  return 0;
+}

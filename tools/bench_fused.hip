@@ -30,7 +30,7 @@ struct Ctx {
   float2 *d_in_halo, *d_mid, *d_if_old, *d_if_new;
   float *d_hpA, *d_afrag;
   FusedTaps taps;
-  unsigned long long *d_dbg = nullptr;
+  unsigned long long *d_dbg = nullptr; float *d_taps = nullptr;
   double *d_base = nullptr; float *d_dec = nullptr, *d_hBlast = nullptr, *d_stats = nullptr; StreamState *d_st = nullptr; FusedPart *d_part = nullptr; int *d_tab = nullptr;
   bool epi = false; int nb = 0; std::vector<int> h_off, h_len; int *d_wgblk = nullptr;
   int poly2_tile;
@@ -47,7 +47,7 @@ static void setup(Ctx &c, size_t max_in) {
   for (int k = 0; k < rs.NA; k++) hp[(size_t)(k % rs.D) * qa + k / rs.D] = fa[k];
   CK(hipMalloc(&c.d_hpA, hp.size() * 4)); CK(hipMemcpy(c.d_hpA, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
   for (int k = 0; k < FUSED_TAP_LEN; k++) c.taps.h[k] = 0.f;
-  for (int k = 0; k <= (rs.NA - 1) / 2; k++) {
+  for (int k = 0; k < rs.NA; k++) {
     c.taps.h[FUSED_TAP_PAD + k] = fa[k];
     if (fa[k] != fa[rs.NA - 1 - k]) { printf("stage-A taps are not symmetric at %d\n", k); exit(1); }
   }
@@ -72,6 +72,7 @@ static void setup(Ctx &c, size_t max_in) {
   SETATTR(0, 0); SETATTR(1, 0); SETATTR(0, 1); SETATTR(1, 1); SETATTR(0, 2); SETATTR(1, 2); SETATTR(0, 3); SETATTR(1, 3);
   SETATTR(0, 4); SETATTR(1, 4); SETATTR(0, 7); SETATTR(1, 7); SETATTR(0, 5); SETATTR(1, 5); SETATTR(0, 6); SETATTR(1, 6);
   SETATTR(0, 14); SETATTR(1, 14); SETATTR(0, 22); SETATTR(1, 22); SETATTR(0, 32); SETATTR(1, 32); SETATTR(0, 36); SETATTR(1, 36); SETATTR(0, 38); SETATTR(1, 38); SETATTR(0, 37); SETATTR(1, 37); SETATTR(0, 35); SETATTR(1, 35);
+  CK(hipMalloc(&c.d_taps, FUSED_TAP_LEN * 4)); CK(hipMemcpy(c.d_taps, c.taps.h, FUSED_TAP_LEN * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&c.d_dbg, 16 * 8)); CK(hipMemset(c.d_dbg, 0, 16 * 8));
   CK(hipMalloc(&c.d_wgblk, 1024 * 4));
   CK(hipMalloc(&c.d_base, c.max_if * 8)); CK(hipMalloc(&c.d_dec, c.max_if * 4)); CK(hipMalloc(&c.d_st, sizeof(StreamState)));
@@ -118,7 +119,7 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
   constexpr int D = 10, NA = 151;
   FusedArgs a{};
   a.iq = d_iq; a.iq_stride = (long long)c.max_in; a.n_valid = g.N_in;
-  a.in_halo = c.d_in_halo; a.H_in = c.H_in;
+  a.in_halo = c.d_in_halo; a.H_in = c.H_in; a.taps = c.d_taps;
   const long long n0 = (long long)rs.D * g.mA_prev - g.n_prev;
   const long long lo0 = n0 + rs.ca() - (NA - 1);
   const int par = (int)(((lo0 % 2) + 2) % 2);
@@ -157,8 +158,8 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
     CK(hipMemcpy(c.d_wgblk, wb.data(), grid * 4, hipMemcpyHostToDevice));
     a.wg_blk0 = c.d_wgblk;
   }
-  if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, ABL>), dim3(grid, 1), dim3(512), kLds, 0, a, c.taps);
-  else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, ABL>), dim3(grid, 1), dim3(512), kLds, 0, a, c.taps);
+  if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, ABL>), dim3(grid, 1), dim3(FUSED_THREADS), kLds, 0, a, c.taps);
+  else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, ABL>), dim3(grid, 1), dim3(FUSED_THREADS), kLds, 0, a, c.taps);
 }
 
 static void halo_updates(Ctx &c, const CallGeom &g, const float2 *d_iq) {
