@@ -57,7 +57,7 @@ class Status(C.Structure):
         ("pll_fallback", C.c_int), ("pll_residual", C.c_double),
         ("agc_residual_history", C.c_float * 16), ("pll_residual_history", C.c_double * 16),
         ("pll_residual_components", C.c_double * 8),
-        ("pll_mismatch_history", C.c_double * 16), ("pll_mismatch_accepted", C.c_int), ("reserved0", C.c_int),
+        ("pll_mismatch_history", C.c_double * 16), ("pll_mismatch_accepted", C.c_int), ("af_agc_fallback", C.c_int),
     ]
 
 

@@ -58,7 +58,7 @@ constexpr double kIfAtten = 140.0;     // resampler spec, DESIGN.md
 constexpr double kAudioAtten = 180.0;
 constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
-constexpr int C_AGC = 256, C_DC = 64, C_DE = 256;
+constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 512, K_AF_ITERS = 6;
 constexpr int C_PLL_MIN = 64;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
 constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 4;   // PLL: 2 rounds in lock, 2 spare (each unused round costs ~18 us of launches)
 
@@ -160,6 +160,8 @@ struct fmr_chain {
       d_blk_level, d_agc_M,
       d_dc_G, d_dc_start;
   DevBuf<float> d_agc_nodes, d_agc_G;
+  DevBuf<double> d_af_nodes, d_af_G, d_af_M, d_af_out;   // AmDecoder audio tail, time-parallel form
+  DcCoef am_dk{};
   DevBuf<int> d_ck_wraps, d_blk_wraps;
   DevBuf<unsigned long long> d_ck_mask;
   int mask_words = 2;
@@ -203,6 +205,7 @@ struct fmr_chain {
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
+    d_af_nodes.release(); d_af_G.release(); d_af_M.release(); d_af_out.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     if (h_marks) (void)hipHostFree(h_marks);
     for (hipEvent_t e : {ev_disc, ev_pll, ev_stats, ev_fin, ev_if}) if (e) (void)hipEventDestroy(e);
@@ -650,6 +653,29 @@ int fmr_chain::init(const fmr_config *c) {
     max_au = max_if;
     if ((rc = d_base.alloc((size_t)S * max_if))) return rc;
     if ((rc = d_audio.alloc((size_t)S * max_au))) return rc;
+    {
+      // time-parallel audio tail: DC-block transition matrices over one chunk and over the node scan's lane groups
+      const size_t nc = max_if / C_AM + 2;
+      if ((rc = d_dc_G.alloc((size_t)S * 2 * nc * 2))) return rc;
+      if ((rc = d_dc_start.alloc((size_t)S * 2 * nc * 2))) return rc;
+      if ((rc = d_af_nodes.alloc((size_t)S * (nc + 1)))) return rc;
+      if ((rc = d_af_G.alloc((size_t)S * nc))) return rc;
+      if ((rc = d_af_M.alloc((size_t)S * nc))) return rc;
+      if ((rc = d_af_out.alloc((size_t)S * max_if))) return rc;
+      am_dk.b0 = am_dcblock.b0; am_dk.b1 = am_dcblock.b1; am_dk.b2 = am_dcblock.b2; am_dk.a1 = am_dcblock.a1; am_dk.a2 = am_dcblock.a2;
+      auto mul = [](const double *x, const double *y, double *z) {
+        const double t[4] = {x[0] * y[0] + x[1] * y[2], x[0] * y[1] + x[1] * y[3], x[2] * y[0] + x[3] * y[2],
+                             x[2] * y[1] + x[3] * y[3]};
+        for (int j = 0; j < 4; j++) z[j] = t[j];
+      };
+      const double a[4] = {-am_dcblock.a1, -am_dcblock.a2, 1.0, 0.0};
+      double r[4] = {1, 0, 0, 1};
+      for (int i = 0; i < C_AM; i++) mul(a, r, r);
+      for (int j = 0; j < 4; j++) am_dk.ac[j] = r[j];
+      double gk[4] = {1, 0, 0, 1};
+      for (int i = 0; i < FMR_DC_K; i++) mul(am_dk.ac, gk, gk);
+      for (int lv = 0; lv < 6; lv++) { for (int j = 0; j < 4; j++) am_dk.agp[lv][j] = gk[j]; mul(gk, gk, gk); }
+    }
   }
   return FMR_OK;
 }
@@ -1340,10 +1366,34 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          d_bb_rms_blk.p, d_state.p, S, 0);
     });
     timed("am_tail", [&] {
+      const bool par_tail = !serial_mode && !getenv("FMR_AM_SERIAL_TAIL");
+      if (par_tail) {
+        // DC block -> AfSimpleAgc -> de-emphasis in time-parallel form (kernels_par.hpp); the serial kernel below only
+        // runs for a stream whose Newton rounds did not converge
+        const int nc = (int)((N_if + C_AM - 1) / C_AM);
+        const AfAgcCoef af{1.0, 1.5, af_ref, af_rate};      // AfSimpleAgc(1.0, 1.5, reference, rate): AmDecode.cpp:54-66
+        hipLaunchKernelGGL(k_dc_pass1<C_AM>, dim3((nc + 63) / 64, S, 1), dim3(64), 0, stream, d_base.p, (const double *)nullptr,
+                           (long long)max_if, (int)N_if, am_dk, d_dc_G.p, nc, 0);
+        const int dc_nw = std::max(1, std::min(16, (nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
+        hipLaunchKernelGGL(k_dc_nodes, dim3(S), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, nc, am_dk, d_state.p, S, 0);
+        hipLaunchKernelGGL(k_af_begin, dim3(S), dim3(256), 0, stream, d_flags.p, d_af_nodes.p, nc, d_state.p);
+        for (int it = 0; it < K_AF_ITERS; it++) {
+          hipLaunchKernelGGL(k_af_shoot<C_AM>, dim3((nc + 63) / 64, S), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
+                             am_dk, d_dc_start.p, af, d_af_nodes.p, d_af_G.p, d_af_M.p, d_af_out.p, (long long)max_if, nc,
+                             d_state.p, d_flags.p);
+          hipLaunchKernelGGL(k_af_nodes, dim3(S), dim3(64), 0, stream, d_af_nodes.p, d_af_G.p, d_af_M.p, nc, d_state.p, d_flags.p);
+        }
+        const int ncd = (int)((N_if + C_AM_DE - 1) / C_AM_DE);
+        hipLaunchKernelGGL(k_am_deemph_out<C_AM_DE>, dim3((ncd + 63) / 64, S), dim3(64), 0, stream, d_af_out.p, (long long)max_if,
+                           (int)N_if, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
+                           d_state.p, d_flags.p);
+        hipLaunchKernelGGL(k_am_commit, dim3((S + 63) / 64), dim3(64), 0, stream, d_state.p, d_flags.p, S);
+      }
       hipLaunchKernelGGL(k_am_tail, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
                          am_dcblock.b0, am_dcblock.b1, am_dcblock.b2, am_dcblock.a1, am_dcblock.a2, 1.0, 1.5, af_ref,
                          af_rate, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
-                         d_state.p, S);   // AfSimpleAgc(1.0, 1.5, reference, rate): AmDecode.cpp:54-66
+                         d_state.p, S, par_tail ? &d_flags.p->af_converged : (const int *)nullptr, (int)sizeof(IterFlags),
+                         par_tail ? &d_flags.p->af_fallback : (int *)nullptr);
     });
     add_halo(ifbuf, if_stride, H_if, N_if);
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)t_au_len[b];
@@ -1536,6 +1586,7 @@ int fmr_get_status(fmr_chain *c, int stream, fmr_status *st) {
   for (int i = 0; i < 8; i++) st->pll_residual_components[i] = f.pll_comp[i];
   for (int i = 0; i < 16; i++) st->pll_mismatch_history[i] = f.pll_rhist[i];
   st->pll_mismatch_accepted = f.pll_r_accepted;
+  st->af_agc_fallback = f.af_fallback;
   return FMR_OK;
 }
 

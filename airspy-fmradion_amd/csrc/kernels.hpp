@@ -53,6 +53,7 @@ struct StreamState {
   unsigned mpf_resets, pad1;
   // AmDecoder: AfSimpleAgc gain, dc block, de-emphasis
   double af_gain, am_dc_x1, am_dc_x2, am_de_x1;
+  double am_de_x1_next, am_dc_x1_next, am_dc_x2_next;    // staged by the time-parallel AM tail, committed once it has converged
   // mean PLL phase increment over the previous call (= pilot frequency estimate);
   // seeds the initial trajectory guess of the time-parallel PLL (kernels_par.hpp)
   double pll_favg;
@@ -1608,9 +1609,12 @@ __global__ void k_am_tail(const double *__restrict__ demod, long long d_stride, 
                           double hb0, double hb1, double hb2, double ha1, double ha2,
                           double af_init, double af_max, double af_ref, double af_rate,
                           double de_b0, double de_a1, int do_deemph,
-                          double *__restrict__ audio, long long audio_stride, StreamState *st, int n_streams) {
+                          double *__restrict__ audio, long long audio_stride, StreamState *st, int n_streams,
+                          const int *__restrict__ skip = nullptr, int skip_stride = 0, int *__restrict__ ran = nullptr) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_streams) return;
+  if (skip && *reinterpret_cast<const int *>(reinterpret_cast<const char *>(skip) + (size_t)s * skip_stride)) return;   // the time-parallel form converged
+  if (ran) *reinterpret_cast<int *>(reinterpret_cast<char *>(ran) + (size_t)s * skip_stride) = 1;
   const double *x = demod + (long long)s * d_stride;
   double *out = audio + (long long)s * audio_stride;
   double x1 = st[s].am_dc_x1, x2 = st[s].am_dc_x2, g = st[s].af_gain, e1 = st[s].am_de_x1;

@@ -37,6 +37,8 @@ struct IterFlags {
   double pll_comp[8];     // last round: residual per state component
   double pll_rhist[16];   // scaled boundary mismatch seen by each round's integration pass
   int pll_ticket, pll_r_accepted;
+  int af_converged, af_iters, af_fallback, af_pad;        // AmDecoder's audio AGC (time-parallel form)
+  double af_resid;
   unsigned long long pll_resid_bits, pll_comp_bits[8];   // atomicMax accumulators of the running round
 };
 
@@ -237,13 +239,14 @@ __global__ __launch_bounds__(1024) void k_dc_nodes(const double *__restrict__ G,
   __shared__ double tot[16][2];
   __shared__ double endst[2];
   const int t = blockIdx.x;
-  const int s = t / nch, ch = t % nch;
+  const int s = nch ? t / nch : t, ch = nch ? t % nch : 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
   if (s >= n_streams) return;
   const double *g = G + (((long long)s * 2 + ch) * nc) * 2;
   double *o = start + (((long long)s * 2 + ch) * nc) * 2;
   double c1 = ch ? st[s].dc_st_x1 : st[s].dc_mono_x1;     // carry: state at the start of the pass
   double c2 = ch ? st[s].dc_st_x2 : st[s].dc_mono_x2;
+  if (nch == 0) { c1 = st[s].am_dc_x1; c2 = st[s].am_dc_x2; }   // AmDecoder's DC block (one channel, its own state)
   constexpr int K = FMR_DC_K;
   // AG^64 = (AG^32)^2: transition over one wave segment
   double ag64[4];
@@ -489,8 +492,12 @@ __global__ __launch_bounds__(1024) void k_agc_nodes(float *__restrict__ nodes, c
     // (hazard H7), and atan2 is invariant to it: accept <= 5e-5 from round 2 on -- only where the consumer
     // is invariant to the gain (FM discriminator).  AM audio scales with the gain: there the rounds go on until
     // no node moves by more than one float ulp.
+    // Over thousands of nodes a float node somewhere keeps flipping its last bit, so "one ulp everywhere" is not
+    // reachable on long calls: from round 3 on a few ulps (1e-6: 2.5e-7 of audio at full scale, 40x inside the
+    // tolerance) are accepted as well.
     const float tight = gain_invariant ? 1.0e-6f : 1.5e-7f;
-    if (maxrel <= tight || (gain_invariant && fl[s].agc_iters >= 2 && maxrel <= 5.0e-5f)) {   // gains of the last shoot pass stand
+    if (maxrel <= tight || (gain_invariant && fl[s].agc_iters >= 2 && maxrel <= 5.0e-5f) ||
+        (!gain_invariant && fl[s].agc_iters >= 3 && maxrel <= 1.0e-6f)) {   // gains of the last shoot pass stand
       fl[s].agc_converged = 1;
       st[s].agc_gain = nd[nc];
     }
@@ -534,6 +541,145 @@ __global__ void k_if_agc_fallback(const float2 *__restrict__ x, long long x_stri
     else if (g > max_gain) g = max_gain;
   }
   st[s].agc_gain = g;
+}
+
+// ---------------------------------------------------------------------------
+// AmDecoder audio tail in time-parallel form (AmDecode.cpp:190-216): DC block -> AfSimpleAgc -> de-emphasis.
+//  * DC block: linear multiple shooting (k_dc_pass1 / k_dc_nodes above give every chunk its start state);
+//  * AfSimpleAgc (AfSimpleAgc.cpp:36-56): Newton multiple shooting on the gain, as the IF AGC -- every chunk is
+//    integrated with the reference's arithmetic from its node value together with d g_end / d g_start, the node pass
+//    solves the linearised boundary conditions; the DC block is re-run inside the shoot kernel (6 flops per sample),
+//    so no intermediate signal is stored; the gain clamp (1.5) makes most chunks end ON the clamp: zero sensitivity;
+//  * de-emphasis (tau = 4.8 samples): every chunk warms up over FMR_AM_DE_WARM samples (e^{-160/4.8} = 3e-15).
+// If the Newton rounds do not converge the serial kernel (k_am_tail) runs instead.
+// ---------------------------------------------------------------------------
+#define FMR_AM_DE_WARM 160
+struct AfAgcCoef { double init, maxg, ref, rate; };
+
+template <int C>
+__global__ void k_af_shoot(const double *__restrict__ demod, long long d_stride, int n, DcCoef k,
+                           const double *__restrict__ dc_start, AfAgcCoef af, const double *__restrict__ nodes,
+                           double *__restrict__ G, double *__restrict__ M, double *__restrict__ agc_out, long long o_stride,
+                           int nc, StreamState *st, const IterFlags *__restrict__ fl) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (c >= nc || fl[s].af_converged) return;
+  const double *x = demod + (long long)s * d_stride;
+  double *o = agc_out + (long long)s * o_stride;
+  const int i0 = c * C, i1 = min(i0 + C, n);
+  const double *sd = dc_start + (((long long)s * 2) * nc + c) * 2;
+  double x1 = sd[0], x2 = sd[1];
+  double g = nodes[(long long)s * (nc + 1) + c], dg = 1.0;
+  serial_prefetch<8>(x, i0, i1, [&](int i, double xv) {
+    const double x0 = xv - (k.a1 * x1 + k.a2 * x2);                 // Filter.cpp:243-250 (DF2)
+    const double v = k.b0 * x0 + k.b1 * x1 + k.b2 * x2;
+    x2 = x1; x1 = x0;
+    const double xg = v * g;                                         // AfSimpleAgc.cpp:41-47
+    o[i] = xg * af.ref;
+    const double sq = xg * xg;
+    const double z = 1.0 + (af.rate * (1.0 - sq));
+    dg *= (z - 2.0 * af.rate * sq);                                  // d(g z)/dg, sq ~ g^2
+    g *= z;
+    if (!isfinite(g)) { g = af.init; dg = 0.0; }
+    else if (g > af.maxg) { g = af.maxg; dg = 0.0; }
+  });
+  G[(long long)s * nc + c] = g;
+  M[(long long)s * nc + c] = dg;
+  if (c == nc - 1) { st[s].am_dc_x1_next = x1; st[s].am_dc_x2_next = x2; }   // DC-block state after the call (exact: linear pass)
+}
+
+// node pass of the AF AGC: v[c+1] = G[c] + M[c] (v[c] - old[c]); one wave per stream, K chunk maps per lane.
+__global__ __launch_bounds__(64) void k_af_nodes(double *__restrict__ nodes, const double *__restrict__ G,
+                                                 const double *__restrict__ M, int nc, StreamState *st, IterFlags *fl) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  if (fl[s].af_converged) return;
+  double *nd = nodes + (long long)s * (nc + 1);
+  const double *g = G + (long long)s * nc, *m = M + (long long)s * nc;
+  constexpr int K = 8;
+  double carry = nd[0], maxrel = 0.0;
+  for (int c0 = 0; c0 < nc; c0 += 64 * K) {
+    const int cb = c0 + lane * K;
+    double a[K], b[K], oldn[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const int c = cb + j;
+      if (c < nc) { a[j] = m[c]; b[j] = g[c] - a[j] * nd[c]; oldn[j] = nd[c + 1]; }
+      else { a[j] = 1.0; b[j] = 0.0; oldn[j] = 0.0; }
+    }
+    double ca = 1.0, cbv = 0.0;
+#pragma unroll
+    for (int j = 0; j < K; j++) { cbv = a[j] * cbv + b[j]; ca = a[j] * ca; }
+    double sa = ca, sb = cbv;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double pa = __shfl_up(sa, o, 64), pb = __shfl_up(sb, o, 64);
+      if (lane >= o) { sb = sa * pb + sb; sa = sa * pa; }
+    }
+    double ea = __shfl_up(sa, 1, 64), eb = __shfl_up(sb, 1, 64);
+    if (lane == 0) { ea = 1.0; eb = 0.0; }
+    double v = ea * carry + eb;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const int c = cb + j;
+      v = a[j] * v + b[j];
+      if (c < nc) { nd[c + 1] = v; maxrel = fmax(maxrel, fabs(v - oldn[j]) / fmax(fabs(v), 1e-300)); }
+    }
+    carry = readlane_d(sa, 63) * carry + readlane_d(sb, 63);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxrel = fmax(maxrel, __shfl_xor(maxrel, o, 64));
+  if (lane != 0) return;
+  fl[s].af_iters++;
+  fl[s].af_resid = maxrel;
+  // the trajectory of the last shoot pass stands once no node moves by more than 1e-13 relative; where the gain keeps
+  // touching its clamp inside chunks the map is only piecewise smooth and the last digits wander: 1e-9 from round 4 on
+  // (1e-9 of the audio, four orders inside the tolerance)
+  if (maxrel <= 1e-13 || (fl[s].af_iters >= 4 && maxrel <= 1e-9)) {
+    fl[s].af_converged = 1;
+    st[s].af_gain = nd[nc];
+  }
+}
+
+__global__ void k_af_begin(IterFlags *fl, double *__restrict__ nodes, int nc, const StreamState *st) {
+  const int s = blockIdx.x;
+  if (threadIdx.x == 0) { fl[s].af_converged = 0; fl[s].af_iters = 0; fl[s].af_fallback = 0; fl[s].af_resid = 0.0; }
+  const double g0 = st[s].af_gain;
+  for (int c = threadIdx.x; c <= nc; c += blockDim.x) nodes[(long long)s * (nc + 1) + c] = g0;
+}
+
+// de-emphasis + output (AmDecode.cpp:212-217); do_deemph = 0: copy (DSB / SSB / CW modes have none)
+template <int C>
+__global__ void k_am_deemph_out(const double *__restrict__ agc_out, long long o_stride, int n, double b0, double a1,
+                                int do_deemph, double *__restrict__ audio, long long audio_stride, StreamState *st,
+                                const IterFlags *__restrict__ fl) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  const int nc = (n + C - 1) / C;
+  if (c >= nc || !fl[s].af_converged) return;
+  const double *x = agc_out + (long long)s * o_stride;
+  double *out = audio + (long long)s * audio_stride;
+  const int i0 = c * C, i1 = min(i0 + C, n);
+  if (!do_deemph) { for (int i = i0; i < i1; i++) out[i] = x[i]; return; }
+  double e1;
+  int w0 = i0 - FMR_AM_DE_WARM;
+  if (w0 <= 0) { w0 = 0; e1 = st[s].am_de_x1; } else e1 = 0.0;     // the first chunks run from the carried state
+  for (int i = w0; i < i0; i++) e1 = x[i] - a1 * e1;
+  serial_prefetch<8>(x, i0, i1, [&](int i, double v) {
+    const double w = v - a1 * e1;
+    out[i] = b0 * w;
+    e1 = w;
+  });
+  if (c == nc - 1) {
+    // commit after every chunk that reads the carried state has done so: those are the first ceil(WARM / C) + 1 chunks,
+    // and they run in the first workgroup of the launch while this is the last lane of the last one -- unless the call
+    // is that short, in which case the state is staged and committed by k_am_commit
+    st[s].am_de_x1_next = e1;
+  }
+}
+__global__ void k_am_commit(StreamState *st, IterFlags *fl, int n_streams) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_streams) return;
+  if (fl[s].af_converged) { st[s].am_de_x1 = st[s].am_de_x1_next; st[s].am_dc_x1 = st[s].am_dc_x1_next; st[s].am_dc_x2 = st[s].am_dc_x2_next; }
 }
 
 // ---------------------------------------------------------------------------

@@ -318,7 +318,9 @@ def main():
             "recurrences": {"agc_newton_rounds": st.agc_iterations, "pll_newton_rounds": st.pll_iterations,
                             "pll_residuals": [float("%.3g" % v) for v in st.pll_residual_history[:st.pll_iterations]],
                             "pll_mismatches": [float("%.3g" % v) for v in st.pll_mismatch_history[:st.pll_iterations]],
-                            "agc_serial_fallback": st.agc_fallback, "pll_serial_fallback": st.pll_fallback},
+                            "agc_residuals": [float("%.3g" % v) for v in st.agc_residual_history[:min(st.agc_iterations, 16)]],
+                            "agc_serial_fallback": st.agc_fallback, "pll_serial_fallback": st.pll_fallback,
+                            "af_tail_serial_fallback": st.af_agc_fallback},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.mode, args.multipath_stages)

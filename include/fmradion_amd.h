@@ -114,7 +114,7 @@ typedef struct {
   double pll_residual_components[8];
   double pll_mismatch_history[16];  /* scaled chunk-boundary mismatch seen by each round's integration pass */
   int pll_mismatch_accepted;        /* 1: the last round was accepted on the mismatch alone (node pass skipped) */
-  int reserved0;
+  int af_agc_fallback;              /* AM: 1 = the audio tail (DC block / AfSimpleAgc / de-emphasis) ran in its serial form */
 } fmr_status;
 
 typedef struct fmr_chain fmr_chain;

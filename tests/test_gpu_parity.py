@@ -260,6 +260,7 @@ def test_am_decoder_48k(mode, am_narrow):
             agc_iters=st.agc_iterations, agc_fallback=st.agc_fallback, agc_hist=[float(v) for v in st.agc_residual_history[:st.agc_iterations]],
             af_agc=st.af_agc_gain, ref_af_agc=am.get_af_agc_current_gain())
     assert len(got) == len(ref) and err < 1e-6
+    assert st.agc_fallback == 0 and st.af_agc_fallback == 0        # both AGCs and the audio tail ran time-parallel
     assert st.if_agc_gain == pytest.approx(am.get_if_agc_current_gain(), rel=1e-5)
     assert st.af_agc_gain == pytest.approx(am.get_af_agc_current_gain(), rel=1e-6)
     assert st.if_rms == pytest.approx(am.get_if_rms(), rel=1e-5)
@@ -292,9 +293,11 @@ def test_am_decoder_ssb_cw_modes(mode, am_narrow):
     st = ch.status()
     _report(f"am_{mode}", audio_rms_err=err, audio_rms=rms(ref), if_rms=st.if_rms, ref_if_rms=am.get_if_rms(),
             if_agc=st.if_agc_gain, ref_if_agc=am.get_if_agc_current_gain(), af_agc=st.af_agc_gain,
-            ref_af_agc=am.get_af_agc_current_gain(), agc_iters=st.agc_iterations, agc_fallback=st.agc_fallback)
+            ref_af_agc=am.get_af_agc_current_gain(), agc_iters=st.agc_iterations, agc_fallback=st.agc_fallback,
+            af_fallback=st.af_agc_fallback, agc_hist=[float(v) for v in st.agc_residual_history[:st.agc_iterations]])
     assert rms(ref) > 1e-3
     assert err < 1e-6
+    assert st.agc_fallback == 0 and st.af_agc_fallback == 0        # CW / WSPR included: no serial fallback
     assert st.if_rms == pytest.approx(am.get_if_rms(), rel=1e-5)
     assert st.if_agc_gain == pytest.approx(am.get_if_agc_current_gain(), rel=1e-4)
     assert st.af_agc_gain == pytest.approx(am.get_af_agc_current_gain(), rel=1e-6)
@@ -315,8 +318,10 @@ def test_am_config3_full_chain(am_narrow):
     got, ref = np.concatenate(got), np.concatenate(ref)
     assert len(got) == len(ref)
     err = rms(got - ref)
-    _report("am_config3", audio_rms_err=err, audio_rms=rms(ref))
+    st = ch.status()
+    _report("am_config3", audio_rms_err=err, audio_rms=rms(ref), agc_fallback=st.agc_fallback, af_fallback=st.af_agc_fallback)
     assert err < 1e-5
+    assert st.agc_fallback == 0 and st.af_agc_fallback == 0
     ch.close()
 
 
