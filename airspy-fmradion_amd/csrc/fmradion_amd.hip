@@ -1117,9 +1117,16 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if (any_mpf) {
       const size_t lds = sizeof(float2) * ((size_t)2 * mpf_N + FMR_MPF_CH + 4);
       timed("mpf", [&] {
-        hipLaunchKernelGGL(k_mpf, dim3(S), dim3(64), lds, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
-                           bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
-                           d_mpf_ok.p, d_state.p);
+        auto go = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3(S), dim3(64), lds, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
+                             bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
+                             d_mpf_ok.p, d_state.p);
+        };
+        // v2: taps in registers (TPL per lane); v1 (taps in LDS) for FMR_MPF_V1=1
+        if (getenv("FMR_MPF_V1")) go(k_mpf);
+        else if (mpf_N <= 64 * 5) go(k_mpf2<5>);
+        else if (mpf_N <= 64 * 10) go(k_mpf2<10>);
+        else go(k_mpf2<19>);
       });
     }
     const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers

@@ -1027,6 +1027,144 @@ __global__ __launch_bounds__(64) void k_mpf(
 }
 
 // ---------------------------------------------------------------------------
+// K_mpf v2 : the same recurrence with the latency taken out of the per-group chain.  Still one wave per stream (the
+// taps depend on the previous outputs), but
+//  * the taps live in registers (lane l owns taps l, l+64, ...: TPL per lane), not in LDS;
+//  * the state window stays in LDS and is read once per group: the five values a lane needs for the four outputs of a
+//    group at one tap (xw[q+1+i .. q+4+i]) are loaded together, and sum |state|^2 of the update (MultipathFilter.cpp:130)
+//    is taken from the same registers as the last output's dot product instead of a second pass;
+//  * the 8 + 1 wave reductions of a group are issued together (independent DPP chains);
+//  * the tap update reuses the state values of the last output, still in registers.
+// Arithmetic per tap and per output is unchanged (same fmaf chains in the same order as k_mpf, same float / double
+// mix as MultipathFilter.cpp:92-161), so the two kernels agree bit for bit.
+// ---------------------------------------------------------------------------
+template <int TPL>
+__global__ __launch_bounds__(64) void k_mpf2(
+    const float2 *__restrict__ xin, long long x_stride, int x_off,
+    const float *__restrict__ gain, long long g_stride, BlockTab bt,
+    float2 *__restrict__ out, long long out_stride, float2 *__restrict__ coeff_g,
+    float2 *__restrict__ state_g, int N, int ref, int *__restrict__ mpf_ok, StreamState *st) {
+  extern __shared__ float2 lds_m[];
+  float2 *xw = lds_m;                       // [N + CH + 4]
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float2 *xs = xin + (long long)s * x_stride + x_off;
+  const float *gs = gain + (long long)s * g_stride;
+  float2 *os = out + (long long)s * out_stride;
+  float2 *cg = coeff_g + (long long)s * N;
+  float2 *sg = state_g + (long long)s * N;
+  float2 c[TPL];
+#pragma unroll
+  for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; c[j] = (i < N) ? cg[i] : make_float2(0.f, 0.f); }
+  double err_last = st[s].mpf_error;
+  unsigned resets = st[s].mpf_resets;
+  for (int b = 0; b < bt.nb; b++) {
+    const int n = bt.if_len[b];
+    int ok = 1;
+    if (n == 0 || !bt.mpf_active[b]) {
+      if (lane == 0) mpf_ok[(long long)s * bt.nb + b] = 0;
+      continue;
+    }
+    const int off = bt.if_off[b];
+    for (int i = lane; i < N; i += 64) xw[i] = sg[i];
+    __syncthreads();
+    for (int c0 = 0; c0 < n && ok; c0 += FMR_MPF_CH) {
+      const int cn = min(FMR_MPF_CH, n - c0);
+      for (int i = lane; i < cn; i += 64) {
+        const float2 v = xs[off + c0 + i];
+        const float g = gs[off + c0 + i];
+        xw[N + i] = make_float2(v.x * g, v.y * g);
+      }
+      if (lane < 4) xw[N + cn + lane] = make_float2(0.f, 0.f);      // slack read by the last (partial) group
+      __syncthreads();
+      int pushed = 0, q = 0;
+      while (q < cn) {
+        const int jg = c0 + q;                                  // index inside the block
+        const int glen = min(((jg + 3) & ~3) - jg + 1, cn - q);  // up to and including the next update sample
+        float2 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = make_float2(0.f, 0.f);
+        float2 sl[TPL];                                         // state values of the group's LAST output (update operand)
+        float ms = 0.f;
+        // state after the push of sample q+t = xw[q+t+1 .. q+t+N]; y = sum state[i]*coeff[i] (V9)
+#pragma unroll
+        for (int j = 0; j < TPL; j++) {
+          const int i = lane + 64 * j;
+          float2 sv[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) sv[t] = (i < N) ? xw[q + 1 + t + i] : make_float2(0.f, 0.f);   // lanes past the last tap add exact zeros
+          const float2 cv = c[j];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            acc[t].x = fmaf(sv[t].x, cv.x, acc[t].x); acc[t].x = fmaf(-sv[t].y, cv.y, acc[t].x);
+            acc[t].y = fmaf(sv[t].x, cv.y, acc[t].y); acc[t].y = fmaf(sv[t].y, cv.x, acc[t].y);
+          }
+          const float2 last = glen == 4 ? sv[3] : glen == 3 ? sv[2] : glen == 2 ? sv[1] : sv[0];
+          sl[j] = last;
+          if (i < N) ms += last.x * last.x + last.y * last.y;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) { acc[t].x = wave_sum_dpp(acc[t].x); acc[t].y = wave_sum_dpp(acc[t].y); }
+        const float sum = wave_sum_dpp(ms);
+        int bad = -1;
+#pragma unroll
+        for (int t = 3; t >= 0; t--)
+          if (t < glen && (!isfinite(acc[t].x) || !isfinite(acc[t].y))) bad = t;   // first non-finite output
+        if (bad >= 0) { pushed = q + bad + 1; ok = 0; break; }                      // :182-184
+        pushed = q + glen;
+        if (lane < glen) {
+          const float2 yv = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+          os[off + c0 + q + lane] = yv;
+        }
+        const int qlast = q + glen - 1;
+        if ((((c0 + qlast) & 3) == 0)) {                        // :176,186
+          const float2 y = glen == 1 ? acc[0] : glen == 2 ? acc[1] : glen == 3 ? acc[2] : acc[3];
+          const double env = (double)(y.x * y.x + y.y * y.y);
+          const double error = 1.0 - env;
+          const float mu = (float)(0.1 / ((double)sum + 1e-10));   // :130
+          const float factor = (float)(error * (double)mu);         // :133
+          const float fr = factor * y.x, fi = factor * y.y;
+#pragma unroll
+          for (int j = 0; j < TPL; j++) {                            // V10: lane l only ever touches its own taps
+            const int i = lane + 64 * j;
+            const float2 sv = sl[j];
+            float2 cv = c[j];
+            cv.x += sv.x * fr + sv.y * fi;
+            cv.y += sv.x * fi - sv.y * fr;
+            if (i == ref) cv = make_float2(1.f, 0.f);                // :158
+            if (i < N) c[j] = cv;
+          }
+          err_last = error;
+          if (!isfinite(error)) { ok = 0; break; }                   // :190-192
+        }
+        q += glen;
+      }
+      // new state = last N entries pushed so far
+      __syncthreads();
+      float2 tmp[TPL];
+#pragma unroll
+      for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; tmp[j] = (i < N) ? xw[pushed + i] : make_float2(0.f, 0.f); }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; if (i < N) xw[i] = tmp[j]; }
+      __syncthreads();
+    }
+    for (int i = lane; i < N; i += 64) sg[i] = xw[i];
+    if (!ok) {
+      // FmDecode.cpp:117-123: re-initialise the taps, block falls back to the AGC output
+#pragma unroll
+      for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; c[j] = make_float2(i == ref ? 1.f : 0.f, 0.f); }
+      resets++;
+    }
+    if (lane == 0) mpf_ok[(long long)s * bt.nb + b] = ok;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; if (i < N) cg[i] = c[j]; }
+  if (lane == 0) { st[s].mpf_error = err_last; st[s].mpf_resets = resets; }
+}
+
+// ---------------------------------------------------------------------------
 // K_disc : PhaseDiscriminator (PhaseDiscriminator.cpp:33-46) per decoder block,
 // fused with the float->double widening (FmDecode.cpp:143) and the block
 // mean / rms of the MPX signal (Utility.h:135-152).
