@@ -28,7 +28,7 @@ EXPORTS = [
     "fmr_create", "fmr_destroy", "fmr_last_error", "fmr_version", "fmr_resampler_info", "fmr_process",
     "fmr_process_blocks", "fmr_process_blocks_device", "fmr_synchronize", "fmr_resample", "fmr_get_status",
     "fmr_get_pps_events", "fmr_get_multipath_coefficients", "fmr_debug_read", "fmr_get_kernel_times",
-    "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert",
+    "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert", "fmr_design_taps",
 ]
 
 
@@ -123,6 +123,8 @@ def lib():
     L.fmr_enable_kernel_timing.argtypes = [vp, C.c_int]
     L.fmr_fourth_convert.restype = C.c_int
     L.fmr_fourth_convert.argtypes = [vp, fp, C.c_size_t, fp, C.c_int, C.POINTER(C.c_uint)]
+    L.fmr_design_taps.restype = C.c_longlong
+    L.fmr_design_taps.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, dp, C.c_longlong, C.POINTER(C.c_longlong)]
     L.fmr_filter_table.restype = C.c_int
     L.fmr_filter_table.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int)]
     _lib = L
@@ -137,6 +139,18 @@ def filter_table(name):
         raise FmrError(f"unknown filter table {name}")
     ct = C.c_double if dbl.value else C.c_float
     return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).copy()
+
+
+def design_taps(in_rate, out_rate, atten_db, stage):
+    """The product's resampler design (host arithmetic of csrc/design.hpp; no GPU needed): (taps, info dict)."""
+    info = (C.c_longlong * 5)()
+    n = lib().fmr_design_taps(in_rate, out_rate, atten_db, stage, None, 0, info)
+    if n < 0:
+        raise FmrError(f"fmr_design_taps failed ({n}): {lib().fmr_last_error().decode()}")
+    buf = np.empty(n, dtype=np.float64)
+    lib().fmr_design_taps(in_rate, out_rate, atten_db, stage, buf.ctypes.data_as(C.POINTER(C.c_double)), n, info)
+    d = dict(zip(["D", "NA", "LB", "MB", "TB"], [int(v) for v in info]))
+    return (buf.reshape(d["LB"], d["TB"]) if stage else buf), d
 
 
 DELAY_3TAPS = np.array([0.0, 1.0, 0.0], dtype=np.float32)  # FilterParameters::delay_3taps_only_iq

@@ -1446,6 +1446,18 @@ long long fmr_resampler_info(const fmr_chain *c, int which) {
   return -1;
 }
 
+long long fmr_design_taps(double in_rate, double out_rate, double atten_db, int stage, double *taps, long long cap,
+                          long long *info) {
+  ResamplerDesign d;
+  if (!d.design(in_rate, out_rate, atten_db)) { set_err("resampling ratio outside the design range"); return FMR_ERR_UNSUPPORTED; }
+  if (info) { info[0] = d.D; info[1] = d.NA; info[2] = d.LB; info[3] = d.MB; info[4] = d.TB; }
+  const std::vector<double> &h = stage ? d.hB : d.hA;
+  if (!taps) return (long long)h.size();
+  if ((long long)h.size() > cap) return FMR_ERR_CAPACITY;
+  for (size_t i = 0; i < h.size(); i++) taps[i] = h[i];
+  return (long long)h.size();
+}
+
 int fmr_synchronize(fmr_chain *c) {
   if (!c) return FMR_ERR_BAD_ARG;
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -128,6 +128,13 @@ const char *fmr_version(void);
  * specification").  which = 0:D 1:NA 2:LB 3:MB 4:TB ; -1 when no resampler. */
 long long fmr_resampler_info(const fmr_chain *c, int which);
 
+/* The product's resampler design on the host (no GPU needed): taps of stage A (stage = 0, NA doubles) or of the
+ * polyphase stage B (stage = 1, LB x TB doubles, row = phase) for in_rate -> out_rate at atten_db; info[0..4] receive
+ * D, NA, LB, MB, TB.  Returns the number of taps of the stage, or a negative error (cap too small / unsupported
+ * ratio).  Lets tests check the design against an independent construction without a device. */
+long long fmr_design_taps(double in_rate, double out_rate, double atten_db, int stage, double *taps, long long cap,
+                          long long *info);
+
 /* --- single block, host buffers: the shape of FmDecoder::process(IQSampleVector,
  * SampleVector&) (FmDecode.h:74) for stream 0 of a 1-stream chain.
  * iq: n interleaved complex float samples.  audio: doubles (interleaved L/R when

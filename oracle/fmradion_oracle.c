@@ -47,6 +47,8 @@ static long long gcd_ll(long long a, long long b) {
 
 struct ora_resampler {
   double in_rate, out_rate, atten;
+  double pass_frac;  /* pass band edge as a fraction of out_rate/2 (0.885: the product's specification) */
+  int stop_nyquist;  /* 1: stop band from out_rate/2 (nothing aliases at all, r8brain-class); 0: from out_rate - fpass */
   long long L, M;   /* out/in = L/M */
   int D;            /* stage A integer decimation (1 = bypass) */
   int NA;           /* stage A taps (odd), 0 when D == 1 */
@@ -66,8 +68,8 @@ static void rs_design(ora_resampler *rs) {
   const double A = rs->atten;
   const double beta = 0.1102 * (A - 8.7);
   const double i0b = bessel_i0(beta);
-  const double fpass = 0.885 * rs->out_rate * 0.5;
-  const double fstop = rs->out_rate - fpass;
+  const double fpass = rs->pass_frac * rs->out_rate * 0.5;
+  const double fstop = rs->stop_nyquist ? rs->out_rate * 0.5 : rs->out_rate - fpass;
   long long in_i = llround(rs->in_rate), out_i = llround(rs->out_rate);
   long long g = gcd_ll(in_i, out_i);
   rs->L = out_i / g;
@@ -128,11 +130,20 @@ static void rs_design(ora_resampler *rs) {
   }
 }
 
+/* ora_rs_create2: the same two-stage structure with another specification -- used by the tests to build an
+ * "r8brain-class" resampler (2 % transition band, >= 180 dB, the defaults of r8b::CDSPResampler24 the reference
+ * constructs at IfResampler.cpp:26-29) beside the product's, and measure what the difference does to the audio. */
+ora_resampler *ora_rs_create2(double in_rate, double out_rate, double atten_db, double pass_frac, int stop_nyquist);
 ora_resampler *ora_rs_create(double in_rate, double out_rate, double atten_db) {
+  return ora_rs_create2(in_rate, out_rate, atten_db, 0.885, 0);
+}
+ora_resampler *ora_rs_create2(double in_rate, double out_rate, double atten_db, double pass_frac, int stop_nyquist) {
   ora_resampler *rs = (ora_resampler *)calloc(1, sizeof(*rs));
   rs->in_rate = in_rate;
   rs->out_rate = out_rate;
   rs->atten = atten_db;
+  rs->pass_frac = pass_frac;
+  rs->stop_nyquist = stop_nyquist;
   rs_design(rs);
   rs->xa_cap = 1 << 12; rs->xa = (double *)malloc(sizeof(double) * rs->xa_cap);
   rs->xm_cap = 1 << 12; rs->xm = (double *)malloc(sizeof(double) * rs->xm_cap);
@@ -250,6 +261,12 @@ ora_ifr *ora_ifr_create(double in_rate, double out_rate) {
   ora_ifr *h = (ora_ifr *)calloc(1, sizeof(*h));
   h->re = ora_rs_create(in_rate, out_rate, ORA_IF_ATTEN_DB);
   h->im = ora_rs_create(in_rate, out_rate, ORA_IF_ATTEN_DB);
+  return h;
+}
+ora_ifr *ora_ifr_create2(double in_rate, double out_rate, double atten_db, double pass_frac, int stop_nyquist) {
+  ora_ifr *h = (ora_ifr *)calloc(1, sizeof(*h));
+  h->re = ora_rs_create2(in_rate, out_rate, atten_db, pass_frac, stop_nyquist);
+  h->im = ora_rs_create2(in_rate, out_rate, atten_db, pass_frac, stop_nyquist);
   return h;
 }
 void ora_ifr_destroy(ora_ifr *h) {

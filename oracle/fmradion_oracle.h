@@ -40,6 +40,7 @@ extern "C" {
 /* ---------- resampler specification (ours; stands in for r8brain) -------- */
 typedef struct ora_resampler ora_resampler;
 ora_resampler *ora_rs_create(double in_rate, double out_rate, double atten_db);
+ora_resampler *ora_rs_create2(double in_rate, double out_rate, double atten_db, double pass_frac, int stop_nyquist);
 void ora_rs_destroy(ora_resampler *rs);
 /* returns number of outputs written (<= cap), or -1 if cap is too small */
 int ora_rs_process(ora_resampler *rs, const double *in, int n, double *out,
@@ -53,6 +54,7 @@ const double *ora_rs_taps_b(const ora_resampler *rs);
  * lock-step on Re and Im, output narrowed to float. */
 typedef struct ora_ifr ora_ifr;
 ora_ifr *ora_ifr_create(double in_rate, double out_rate);
+ora_ifr *ora_ifr_create2(double in_rate, double out_rate, double atten_db, double pass_frac, int stop_nyquist);
 void ora_ifr_destroy(ora_ifr *h);
 int ora_ifr_process(ora_ifr *h, const float *iq, int n, float *out_iq, int cap);
 

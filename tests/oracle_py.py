@@ -37,6 +37,8 @@ def lib():
     vp = C.c_void_p
     sig = {
         "ora_rs_create": (vp, [C.c_double, C.c_double, C.c_double]),
+        "ora_rs_create2": (vp, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
+        "ora_ifr_create2": (vp, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
         "ora_rs_destroy": (None, [vp]),
         "ora_rs_process": (C.c_int, [vp, c_double_p, C.c_int, c_double_p, C.c_int]),
         "ora_rs_info": (C.c_longlong, [vp, C.c_int]),
@@ -255,8 +257,12 @@ def fast_atan_table():
 
 # ---- stateful objects ----------------------------------------------------------
 class Resampler:
-    def __init__(self, in_rate, out_rate, atten_db):
-        self.h = lib().ora_rs_create(in_rate, out_rate, atten_db)
+    def __init__(self, in_rate, out_rate, atten_db, pass_frac=None, stop_nyquist=False):
+        """pass_frac=None: the product's specification (0.885 x Nyquist, stop band from out - f_pass)."""
+        if pass_frac is None:
+            self.h = lib().ora_rs_create(in_rate, out_rate, atten_db)
+        else:
+            self.h = lib().ora_rs_create2(in_rate, out_rate, atten_db, pass_frac, int(stop_nyquist))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -286,8 +292,12 @@ class Resampler:
 
 
 class IfResampler:
-    def __init__(self, in_rate, out_rate):
-        self.h = lib().ora_ifr_create(in_rate, out_rate)
+    def __init__(self, in_rate, out_rate, atten_db=None, pass_frac=0.98, stop_nyquist=True):
+        """atten_db=None: the product's specification; otherwise another one (default: r8brain-class)."""
+        if atten_db is None:
+            self.h = lib().ora_ifr_create(in_rate, out_rate)
+        else:
+            self.h = lib().ora_ifr_create2(in_rate, out_rate, atten_db, pass_frac, int(stop_nyquist))
 
     def __del__(self):
         if getattr(self, "h", None):

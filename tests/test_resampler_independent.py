@@ -1,0 +1,148 @@
+"""The resampler design against constructions that share no code with it, and the audio cost of its specification.
+
+1. Taps.  Oracle (oracle/fmradion_oracle.c rs_design) and product (csrc/design.hpp, through fmr_design_taps -- host
+   arithmetic, no GPU) implement the same formulas; here both are checked against scipy.signal (kaiserord / firwin /
+   numpy.kaiser): an independent implementation of "Kaiser-windowed sinc, unit DC gain".  Tolerance 1e-12 relative.
+2. Frequency response of the cascade: pass band flat to 0.885 x Nyquist, every frequency that can alias into the pass
+   band rejected by the design attenuation.
+3. Specification gap: the reference's r8b::CDSPResampler24 (IfResampler.cpp:26-29) passes 98 % of
+   Nyquist and rejects from Nyquist on; the product is flat to 88.5 % and lets 170..192 kHz fall off.  An "r8brain-class"
+   resampler (same two-stage structure, 2 % transition, 180 dB, fp64) is built in the oracle and both decode the same
+   FM signals -- alone, and with a second carrier 200 kHz / 100 kHz away.  The audio difference is asserted below the
+   north-star tolerance where the band is clean and REPORTED (profiles/r02_resampler_spec_gap.json) where it is not.
+"""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy import signal
+
+import oracle_py as ora
+import siggen
+from conftest import ROOT
+
+fmr = importlib.import_module("airspy-fmradion_amd")
+
+CASES = [(10e6, 384e3, 140.0), (1e6, 384e3, 140.0), (384e3, 48e3, 180.0), (6e6, 384e3, 140.0)]
+
+
+def _scipy_stage_a(in_rate, out_rate, atten, D):
+    fpass = 0.885 * out_rate / 2
+    fstop = out_rate - fpass
+    mid = in_rate / D
+    f1, f2 = fpass, mid - fstop
+    n, beta = signal.kaiserord(atten, (f2 - f1) / (0.5 * in_rate))
+    if n % 2 == 0:
+        n += 1
+    return signal.firwin(n, 0.5 * (f1 + f2), window=("kaiser", beta), fs=in_rate, scale=False), beta
+
+
+@pytest.mark.parametrize("in_rate,out_rate,atten", CASES)
+def test_taps_match_scipy_construction(in_rate, out_rate, atten):
+    rs = ora.Resampler(in_rate, out_rate, atten)
+    info = rs.info()
+    ha_o, hb_o = rs.taps_a(), rs.taps_b()
+    ha_p, dp = fmr.design_taps(in_rate, out_rate, atten, 0)
+    hb_p, _ = fmr.design_taps(in_rate, out_rate, atten, 1)
+    assert dp == {k: info[k] for k in ("D", "NA", "LB", "MB", "TB")}
+    D, LB, TB = info["D"], info["LB"], info["TB"]
+    mid = in_rate / D
+    if D > 1:
+        h, beta = _scipy_stage_a(in_rate, out_rate, atten, D)
+        assert len(h) == info["NA"]
+        assert beta == pytest.approx(0.1102 * (atten - 8.7), rel=1e-12)
+        h = h / h.sum()
+        for got in (ha_o, ha_p):
+            assert np.max(np.abs(got - h)) < 1e-12 * np.max(np.abs(h))
+    # stage B: rows of the polyphase table are the samples of ONE Kaiser-windowed sinc prototype at rate LB * mid
+    n = TB * LB + 1
+    beta = signal.kaiser_beta(atten)
+    proto = signal.firwin(n, out_rate / 2, window=("kaiser", beta), fs=LB * mid, scale=False)
+    c = (n - 1) // 2
+    W = TB // 2
+    idx = c + np.arange(LB)[:, None] + (W - 1 - np.arange(TB))[None, :] * LB
+    tab = proto[idx]
+    tab = tab * (LB / tab.sum())
+    for got in (hb_o, hb_p):
+        assert got.shape == tab.shape
+        assert np.max(np.abs(got - tab)) < 1e-11 * np.max(np.abs(tab))
+
+
+@pytest.mark.parametrize("in_rate,out_rate,atten", CASES[:3])
+def test_cascade_frequency_response(in_rate, out_rate, atten):
+    """|H(f)| of stage A x stage B on a dense grid: flat pass band, aliases of the pass band rejected."""
+    ha, d = fmr.design_taps(in_rate, out_rate, atten, 0)
+    hb, _ = fmr.design_taps(in_rate, out_rate, atten, 1)
+    D, LB, TB = d["D"], d["LB"], d["TB"]
+    mid = in_rate / D
+    fpass, nyq = 0.885 * out_rate / 2, out_rate / 2
+    proto = np.zeros(TB * LB)
+    for p in range(LB):
+        proto[p + (TB - 1 - np.arange(TB)) * LB] = hb[p]          # prototype at rate LB * mid, gain LB
+    f = np.linspace(0, in_rate / 2, 40001)
+    Ha = np.abs(np.exp(-2j * np.pi * np.outer(f / in_rate, np.arange(len(ha)))) @ ha) if D > 1 else np.ones_like(f)
+    Hb = np.abs(np.exp(-2j * np.pi * np.outer(f / (LB * mid), np.arange(len(proto)))) @ proto) / LB
+    H = Ha * Hb
+    pb = f <= fpass
+    assert np.max(np.abs(20 * np.log10(H[pb]))) < 1e-3                       # ripple < 0.001 dB
+    # images of the pass band: anything within +-fpass of a multiple of out_rate (k >= 1)
+    k = np.round(f / out_rate)
+    alias = (k >= 1) & (np.abs(f - k * out_rate) <= fpass)
+    assert 20 * np.log10(np.max(H[alias]) + 1e-300) < -(atten - 3.0)
+    assert 20 * np.log10(np.max(H[f >= out_rate - fpass]) + 1e-300) < -(atten - 3.0)
+    assert 20 * np.log10(H[np.argmin(np.abs(f - nyq))]) < -5.0               # the transition band is on its way down
+
+
+def _decode(x, resampler, pilotcut, blk=65536):
+    fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
+    return np.concatenate([fm.process(resampler.process(b)) for b in siggen.blocks(x, blk)])
+
+
+def test_specification_gap_vs_r8brain_class(pilotcut):
+    """Same IQ through (a) the product's specification and (b) an r8brain-class one, then the same FmDecoder."""
+    fs, n = 10e6, 100 * 65536                       # 0.66 s: the pilot locks at 0.5 s
+    t = np.arange(n) / fs
+    want = siggen.fm_stereo_iq(n, fs, sigma=0.0).astype(np.complex128)
+    other = siggen.fm_stereo_iq(n, fs, stream_id=7, sigma=0.0).astype(np.complex128)      # another programme
+    noise = siggen.fm_stereo_iq(n, fs) - siggen.fm_stereo_iq(n, fs, sigma=0.0)            # the sigma = 1e-3 noise
+    scenes = {
+        "single station": want + noise,
+        "adjacent +200 kHz, equal power": want + other * np.exp(2j * np.pi * 200e3 * t) + noise,
+        "adjacent +100 kHz, -20 dB": want + 0.1 * other * np.exp(2j * np.pi * 100e3 * t) + noise,
+    }
+    post = slice(2 * 26000, None)                   # after the lock at 0.5 s (stereo interleaved, 48 kHz)
+    report = {}
+    clean = _decode(scenes["single station"].astype(np.complex64), ora.IfResampler(fs, 384e3, 180.0, 0.98, True), pilotcut)
+    for name, x in scenes.items():
+        x = x.astype(np.complex64)
+        a_prod = _decode(x, ora.IfResampler(fs, 384e3), pilotcut)
+        a_r8b = _decode(x, ora.IfResampler(fs, 384e3, 180.0, 0.98, True), pilotcut)
+        # both resamplers are latency compensated (output k sits at input time k M / L); the longer filter only ends earlier
+        m = min(len(a_prod), len(a_r8b))
+        assert m > 2 * 26000 + 4000 and abs(len(a_prod) - len(a_r8b)) < 400
+        a_prod, a_r8b = a_prod[:m], a_r8b[:m]
+        d = a_prod[post] - a_r8b[post]
+        report[name] = {"audio_rms": float(np.sqrt(np.mean(a_r8b[post] ** 2))),
+                        "rms_difference_product_vs_r8brain_class": float(np.sqrt(np.mean(d ** 2))),
+                        # what the neighbour does to the audio in the first place (against the station alone)
+                        "interference_rms_r8brain_class": float(np.sqrt(np.mean((a_r8b[post] - clean[:m][post]) ** 2))),
+                        "interference_rms_product": float(np.sqrt(np.mean((a_prod[post] - clean[:m][post]) ** 2)))}
+    out = os.path.join(ROOT, "profiles", "r02_resampler_spec_gap.json")
+    rs_p, rs_r = ora.Resampler(fs, 384e3, 140.0).info(), ora.Resampler(fs, 384e3, 180.0, 0.98, True).info()
+    report["designs"] = {"product (0.885 x Nyquist, 140 dB)": {k: rs_p[k] for k in ("D", "NA", "LB", "MB", "TB")},
+                         "r8brain-class (0.98 x Nyquist, stop band from Nyquist, 180 dB)": {k: rs_r[k] for k in ("D", "NA", "LB", "MB", "TB")}}
+    with open(out, "w") as f:
+        json.dump(report, f, indent=1)
+    # where nothing sits between 170 and 214 kHz the two specifications give the same audio
+    assert report["single station"]["rms_difference_product_vs_r8brain_class"] < 1e-5
+    # an equal-power neighbour 200 kHz away: its energy between 125 and 214 kHz reaches the discriminator either way
+    # (the reference has no IF filter by default, main.cpp:785-790)
+    # the product must not be the worse of the two, and its output may differ from the r8brain-class one by no more than
+    # the damage the neighbour does anyway (measured: interference 0.077 vs 0.086 RMS, difference 0.058)
+    r = report["adjacent +200 kHz, equal power"]
+    assert r["interference_rms_product"] < 1.1 * r["interference_rms_r8brain_class"]
+    assert r["rms_difference_product_vs_r8brain_class"] < r["interference_rms_r8brain_class"]
+    r = report["adjacent +100 kHz, -20 dB"]
+    assert r["rms_difference_product_vs_r8brain_class"] < 0.01 * r["interference_rms_r8brain_class"]
