@@ -39,7 +39,7 @@ AM_BLK, AM_FS = 2048, 384e3    # FileSource default block length (FileSource.h:3
 STAGE_KERNELS = ("ifr_fused", "ifr_decim", "ifr_poly", "disc")
 
 
-def synth_fm_stereo_torch(n, fs, stream_id, device):
+def synth_fm_stereo_torch(n, fs, stream_id, device, pilot=0.10):
     """S-FMst generated on the GPU; same formula as tests/siggen.py, except that
     every tone is snapped to an integer number of cycles in the n-sample buffer, so that replaying
     the buffer step after step is one continuous stream (no pilot-phase jump at the seam)."""
@@ -53,7 +53,7 @@ def synth_fm_stereo_torch(n, fs, stream_id, device):
     fl, fr, fp = snap(1000.0 + 10.0 * stream_id), snap(400.0 + 10.0 * stream_id), snap(19000.0)
     left, right = torch.sin(2 * np.pi * fl * t), torch.sin(2 * np.pi * fr * t)
     th = 2 * np.pi * fp * t
-    mpx = 0.45 * (left + right) + 0.10 * torch.sin(th) + 0.45 * (left - right) * torch.sin(2 * th)
+    mpx = 0.45 * (left + right) + pilot * torch.sin(th) + (0.45 * (left - right) * torch.sin(2 * th) if pilot > 0 else 0.0)
     del left, right, th
     mpx = mpx - mpx.mean()                      # exact zero mean: the FM phase closes on itself
     ph = 2 * np.pi * 75000.0 / fs * torch.cumsum(mpx, 0)
@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--api-mode", choices=["batch", "block"], default="batch",
                     help="block: one block per fmr_process() call through host buffers (the drop-in call, PCIe-inclusive; "
                          "never the headline)")
+    ap.add_argument("--no-pilot", action="store_true",
+                    help="FM stereo decoder on a mono station (no 19 kHz pilot): the unlocked steady state, where the "
+                         "PLL runs in its serial form (reported line, never the headline)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="test hook: gloo backend, the per-rank step is the CPU oracle on a tiny sample -- exercises the "
                          "launch / barrier / aggregation contract without a GPU (tests/test_multi_process.py)")
@@ -178,7 +181,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     fmr = importlib.import_module("airspy-fmradion_amd")
-    synth = synth_am_torch if am else synth_fm_stereo_torch
+    synth = synth_am_torch if am else ((lambda n_, fs_, sid, d: synth_fm_stereo_torch(n_, fs_, sid, d, pilot=0.0)) if args.no_pilot else synth_fm_stereo_torch)
     iq = torch.stack([synth(n, fs, rank * S + s, dev) for s in range(S)])  # (S, n, 2)
     max_au = int(n * (0.125 if am else 0.0048)) + 64
     audio = torch.zeros((S, (1 if am else 2) * max_au), dtype=torch.float64, device=dev)
@@ -258,7 +261,7 @@ def main():
         dt = float(tt.item())
     total_samples = world * S * n * args.steps
     value = total_samples / dt / 1e6
-    if not am:
+    if not am and not args.no_pilot:
         assert st.stereo_detected == 1, "PLL did not lock: the timed work is not the stereo path"
     assert int(alen.sum()) > 0 and bool(torch.isfinite(audio[0, :int(alen.sum())]).all())
 
@@ -284,6 +287,8 @@ def main():
             assert err < 1e-5, f"audio RMS error {err} vs oracle exceeds the north-star tolerance"
         if am:
             workload = "configs[2]: AM 384 kS/s complex-float IQ in HBM, IfResampler(48 k) + AmDecoder narrow filter -> f64 audio"
+        elif args.no_pilot:
+            workload = "FM stereo decoder on a mono station (no pilot): unlocked steady state, serial PLL"
         elif args.multipath_stages:
             workload = f"configs[3]: as configs[1] with the MultipathFilter equaliser -E {args.multipath_stages}"
         elif S > 1:
