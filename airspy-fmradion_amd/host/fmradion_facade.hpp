@@ -200,16 +200,48 @@ public:
     m_chain = fmr_detail::make(m_cfg);
   }
 
+  // Latency for throughput: hold back `blocks` - 1 calls and decode `blocks` blocks in ONE batched call.  process()
+  // then returns an empty vector ("nothing yet": the contract of FmDecode.cpp:89-92,185-188, which main.cpp:981-984
+  // already handles) until the batch is full, and the audio of all its blocks at once.  One 65536-sample block per
+  // call costs ~0.37 ms, almost all of it launch overhead (~100 kernel launches); a batch costs about the same.
+  // Default 1 = the reference's call-by-call behaviour.  Call before the first process().
+  void set_batch_blocks(unsigned blocks) {
+    if (blocks < 1) blocks = 1;
+    if (blocks == m_batch) return;
+    m_batch = blocks;
+    fmr_destroy(m_chain);
+    m_cfg.max_blocks = (int)blocks;
+    m_chain = fmr_detail::make(m_cfg);
+  }
+
   // samples_in by value, audio resized by the callee, empty = "nothing yet" (FmDecode.cpp:85-92)
   void process(IQSampleVector samples_in, SampleVector &audio) {
+    m_pps_fetched = false;       // PilotPhaseLock::process clears m_pps_events on every call (PilotPhaseLock.cpp:62)
+    m_pps.clear();
+    if (m_batch > 1) {
+      m_pending.insert(m_pending.end(), samples_in.begin(), samples_in.end());
+      m_pending_len.push_back((uint32_t)samples_in.size());
+      audio.clear();
+      if (m_pending_len.size() < m_batch) { m_pps_fetched = true; return; }
+      audio.resize(2 * (m_pending.size() + 64 * m_pending_len.size()));
+      std::vector<uint32_t> alen(m_pending_len.size());
+      fmr_detail::check(fmr_process_blocks(m_chain, reinterpret_cast<const float *>(m_pending.data()), m_pending.size(),
+                                           m_pending_len.data(), (int)m_pending_len.size(), audio.data(), audio.size(),
+                                           alen.data()),
+                        "fmr_process_blocks");
+      size_t n = 0;
+      for (uint32_t v : alen) n += v;
+      audio.resize(n);
+      m_pending.clear();
+      m_pending_len.clear();
+      return;
+    }
     audio.resize(2 * (samples_in.size() + 64));
     size_t n = 0;
     fmr_detail::check(fmr_process(m_chain, reinterpret_cast<const float *>(samples_in.data()), samples_in.size(),
                                   audio.data(), audio.size(), &n),
                       "fmr_process");
     audio.resize(n);
-    m_pps_fetched = false;       // PilotPhaseLock::process clears m_pps_events on every call (PilotPhaseLock.cpp:62)
-    m_pps.clear();
   }
   bool stereo_detected() { return status().stereo_detected != 0; }
   float get_tuning_offset() { return status().baseband_mean * freq_dev; }
@@ -252,6 +284,9 @@ private:
   bool m_stereo;
   bool m_pps_fetched = true;
   std::vector<PilotPhaseLock::PpsEvent> m_pps;
+  unsigned m_batch = 1;
+  IQSampleVector m_pending;
+  std::vector<uint32_t> m_pending_len;
   std::vector<std::complex<float>> m_coeff;
 };
 

@@ -44,6 +44,7 @@ int main(int argc, char **argv) {
     AmDecoder am(amfilter_coeff, modtype);
     FmDecoder fm(false, fmfilter_coeff, true, FmDecoder::deemphasis_time_eu, false, 0);
     NbfmDecoder nbfm(nbfmfilter_coeff, NbfmDecoder::freq_dev_normal);
+    if (const char *e = getenv("FMR_LOOP_BATCH")) fm.set_batch_blocks((unsigned)atoi(e));   // latency-for-throughput mode of the facade
     const float squelch_level = 0.0f;
     for (unsigned long long block = 0;; block++) {
       IQSampleVector iqsamples;

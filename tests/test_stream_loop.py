@@ -95,3 +95,18 @@ def test_stream_loop_48k_modes(tmp_path, mode, am_narrow, nbfm_default, nbfm_aud
     assert len(audio) == len(ref) > 1000
     err = float(np.sqrt(np.mean((audio - ref) ** 2)))
     assert err < 1e-5
+
+
+@pytest.mark.gpu
+def test_stream_loop_fm_batched_facade(tmp_path, pilotcut, monkeypatch):
+    """FmDecoder::set_batch_blocks(8): process() returns nothing for seven calls and the audio of eight blocks on the
+    eighth -- the same samples as call-by-call decoding (main.cpp:981-984 skips the empty returns)."""
+    fs, blk, nblk = 384e3, 2517, 160
+    x = siggen.fm_stereo_iq(nblk * blk, fs)
+    exe = _build(str(tmp_path))
+    monkeypatch.setenv("FMR_LOOP_BATCH", "8")
+    audio, _ = _run(exe, str(tmp_path), "fm", fs, False, blk, x)
+    fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
+    ref = np.concatenate([0.5 * fm.process(seg) for seg in siggen.blocks(x, blk)])
+    assert len(audio) == len(ref)
+    assert float(np.sqrt(np.mean((audio - ref) ** 2))) < 1e-6
