@@ -89,6 +89,7 @@ struct fmr_chain {
   hipStream_t stream = nullptr;
   // side stream: per-block bookkeeping (statistics EMAs, PLL lock logic / PPS) runs beside the
   // audio chain instead of in front of it
+  bool dec_valid = true;
   bool debug_taps = false;               // FMR_DEBUG_TAPS=1: keep the de-emphasised 384 kHz signal readable (fmr_debug_read 2,3)
   DeScan de_scan{};
   DevBuf<double> d_de_pow;
@@ -789,6 +790,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       use_fused = true;
       for (int b = 0; b < nb; b++) if (t_if_len[b] != 0 && t_if_len[b] < 128) use_fused = false;
     }
+    dec_valid = !use_fused || debug_taps;      // the float copy of the discriminator output is a debug tap of the fused kernel
     if (use_fused) {
       fused_geom = {mA_prev, kB_prev, n_prev, count_mid};
     } else if (count_mid > 0) {
@@ -1023,7 +1025,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     const int grid = fused_grid;
     a.wg_blk0 = d_tab_slot + (tab_ints - kMaxFusedWg);
     a.base = d_base.p; a.base_stride = H_b + (long long)max_if; a.base_off = H_b;
-    a.dec = d_dec.p; a.dec_stride = (long long)max_if;
+    a.dec = debug_taps ? d_dec.p : nullptr; a.dec_stride = (long long)max_if;
     a.nf = disc_nf; a.bound = disc_bound;
     a.st = d_state.p; a.hB_last = d_hB_last.p; a.part = d_fused_part.p;
     a.if_off = bt.if_off; a.if_len = bt.if_len; a.nb = nb;
@@ -1642,7 +1644,7 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
   size_t esz = 0;
   switch (which) {
   case 0: src = c->last_if + (size_t)stream * (c->H_if + c->max_if) + c->H_if; esz = sizeof(float2); break;
-  case 1: src = c->d_dec.p ? c->d_dec.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
+  case 1: src = (c->d_dec.p && c->dec_valid) ? c->d_dec.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
   case 2: src = c->d_raw_de.p ? c->d_raw_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 3: src = c->d_base_de.p ? c->d_base_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 4: src = c->d_gain.p ? c->d_gain.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;

@@ -307,7 +307,29 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_decim2(
     const float2 t0 = lds_a2[Q + 2 * tid];
     y0r = t0.x; y0i = t0.y;
   } else {
-    if (CV == 0) {
+    if (CV == 2) {
+    // ablation (tools/bench_acc64.hip): the same sums carried in fp64, rounded to fp32 once at the end
+    double d0r = 0., d0i = 0., d1r = 0., d1i = 0.;
+    for (int p = 0; p < D; p++) {
+      const float *h = hp + p * Q;
+      const float4 *row = reinterpret_cast<const float4 *>(lds_a2 + p * S_pad + Q + 2 * tid);
+#pragma unroll
+      for (int j = 0; j <= Q / 2; j++) {
+        const float4 ab = row[-j];
+        if (j < Q / 2) {
+          const double hb = h[2 * j], ha = h[2 * j + 1];
+          d1r = fma(hb, (double)ab.z, d1r); d1i = fma(hb, (double)ab.w, d1i);
+          d1r = fma(ha, (double)ab.x, d1r); d1i = fma(ha, (double)ab.y, d1i);
+          d0r = fma(hb, (double)ab.x, d0r); d0i = fma(hb, (double)ab.y, d0i);
+        }
+        if (j >= 1) {
+          const double h1 = h[2 * j - 1];
+          d0r = fma(h1, (double)ab.z, d0r); d0i = fma(h1, (double)ab.w, d0i);
+        }
+      }
+    }
+    y0r = (float)d0r; y0i = (float)d0i; y1r = (float)d1r; y1i = (float)d1i;
+    } else if (CV == 0) {
     for (int p = 0; p < D; p++) {
       const float *h = hp + p * Q;
       const float4 *row = reinterpret_cast<const float4 *>(lds_a2 + p * S_pad + Q + 2 * tid);

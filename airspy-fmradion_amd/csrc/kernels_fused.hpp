@@ -81,6 +81,8 @@ struct FusedShape {
   static constexpr int LPW = (ME + 4 * OPL - 1) / (4 * OPL);   // active lanes of each of the four stage-A waves
   static constexpr int RS = D * ME + 144;        // input samples per ring slot (pre-roll NA - D + parity + slack), even
   static constexpr int NPIECE = RS / 2;          // 16-byte pieces per slot
+  static constexpr int PRE = (RS - D * ME) / 2;  // pieces a region shares with the one before it
+  static_assert(PRE > 64 && PRE <= 128, "fused_fill / fused_copy_preroll handle the shared pieces in DMA instructions 0 and 1");
   static constexpr int NDMA = (NPIECE + 63) / 64;
   static constexpr int NSLOT = (OPL == 3) ? 3 : 5, AHEAD = NSLOT - 1;   // ring slots; the loader runs AHEAD epochs in front of stage A
   static constexpr int NWORDS = ((OPL - 1) * D + NA + 2) / 2;           // 16-byte words a stage-A lane reads
@@ -123,19 +125,25 @@ __device__ __forceinline__ void fused_barrier() { asm volatile("s_waitcnt lgkmcn
 
 // ---- role: loader ---------------------------------------------------------------------------------------
 template <int D, int NA>
+// The first 144 samples of a region are the last 144 of the region before it (regions advance by D * ME): only the
+// first region of a workgroup is read whole; later ones skip those 72 pieces and the stage-A waves copy them from
+// the previous slot (fused_copy_preroll) -- the input crosses HBM once.
 __device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, const float2 *hs, int jE,
-                                          unsigned char *slot, int lane) {
+                                          unsigned char *slot, int lane, bool whole) {
   using SH = FusedShape<D, NA>;
   const long long nb = a.nbase + (long long)D * jE;
   if (nb >= 0 && nb + SH::RS <= a.n_valid) {
     const float2 *src = xs + nb + 2 * lane;
+    if (whole)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)slot, 16, 0, FUSED_DMA_AUX);
 #pragma unroll
-    for (int c = 0; c < SH::NDMA; c++) {
-      if (c < SH::NDMA - 1 || 64 * c + lane < SH::NPIECE)
+    for (int c = 1; c < SH::NDMA; c++) {
+      if ((c < SH::NDMA - 1 || 64 * c + lane < SH::NPIECE) && (c > 1 || whole || 64 + lane >= SH::PRE))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 128 * c),
                                          (__attribute__((address_space(3))) void *)(slot + 1024 * c), 16, 0, FUSED_DMA_AUX);
     }
-    return SH::NDMA;
+    return whole ? SH::NDMA : SH::NDMA - 1;
   }
   // edge region (start / end of the call): guarded element loads, previous call's tail from in_halo, zeros elsewhere
   float4 *dst = reinterpret_cast<float4 *>(slot);
@@ -154,7 +162,18 @@ __device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, 
   return 0;
 }
 
-// wait until at most `young` DMA instructions are outstanding (young = those issued for later epochs)
+// stage-A side of the above: pieces [D*ME/2, D*ME/2 + PRE) of the slot of this epoch -> pieces [0, PRE) of the next
+template <int D, int NA>
+__device__ __forceinline__ void fused_copy_preroll(const unsigned char *cur, unsigned char *nxt, int lane) {
+  using SH = FusedShape<D, NA>;
+  const float4 *src = reinterpret_cast<const float4 *>(cur) + D * SH::ME / 2;
+  float4 *dst = reinterpret_cast<float4 *>(nxt);
+  dst[lane] = src[lane];
+  if (64 + lane < SH::PRE) dst[64 + lane] = src[64 + lane];
+}
+
+// wait until at most `young` DMA instructions are outstanding (young = those issued for later epochs; a batch is
+// NDMA instructions -- the template argument -- or one more for a whole region)
 template <int NDMA>
 __device__ __forceinline__ void fused_wait_dma(int young) {
   if (3 * NDMA <= 63 && young >= 3 * NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA <= 63 ? 3 * NDMA : 0) : "memory");
@@ -616,12 +635,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedT
     if (!(ABL & 4)) {
 #pragma unroll
       for (int k = 0; k < SH::AHEAD; k++)
-        if (k <= EA) { const int c = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME * k, lds_f + (size_t)k * SH::RS * 8, lane); if (k >= 1) cy[k - 1] = c; }
+        if (k <= EA) { const int c = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME * k, lds_f + (size_t)k * SH::RS * 8, lane, k == 0); if (k >= 1) cy[k - 1] = c; }
     }
     { int young = 0;
 #pragma unroll
       for (int k = 0; k < SH::AHEAD - 1; k++) young += cy[k];
-      fused_wait_dma<SH::NDMA>(young); }               // the slot of epoch 0 has landed
+      fused_wait_dma<SH::NDMA - 1>(young); }               // the slot of epoch 0 has landed
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int slot = SH::AHEAD;
     unsigned long long busy = 0, t_begin = FUSED_CLK();
@@ -629,13 +648,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedT
       const unsigned long long tb = FUSED_CLK();
       int cn = 0;
       if (!(ABL & 4) && e + SH::AHEAD <= EA)
-        cn = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME * (e + SH::AHEAD), lds_f + (size_t)slot * SH::RS * 8, lane);
+        cn = fused_fill<D, NA>(a, xs, hs, jE0 + SH::ME * (e + SH::AHEAD), lds_f + (size_t)slot * SH::RS * 8, lane, false);
       slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
       // the slot of epoch e+1 must have landed: everything but the AHEAD-1 younger batches (cy[0] is epoch e+1 itself)
       int young = cn;
 #pragma unroll
       for (int k = 1; k < SH::AHEAD - 1; k++) young += cy[k];
-      fused_wait_dma<SH::NDMA>(young);
+      fused_wait_dma<SH::NDMA - 1>(young);
 #pragma unroll
       for (int k = 0; k + 1 < SH::AHEAD - 1; k++) cy[k] = cy[k + 1];
       if (SH::AHEAD >= 2) cy[SH::AHEAD - 2] = cn;
@@ -668,6 +687,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedT
         if (half == 0) fused_stage_a_half<D, NA, PAR, 0>(a, taps, s, jE, pos0, sl, midr, side + (e & 1) * SH::ME, aw, lane, (ABL & 1) != 0);
         else fused_stage_a_half<D, NA, PAR, 1>(a, taps, s, jE, pos0, sl, midr, side + (e & 1) * SH::ME, aw, lane, (ABL & 1) != 0);
         slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
+        if (half == 1 && aw == 0 && e < EA) fused_copy_preroll<D, NA>(sl, lds_f + (size_t)slot * SH::RS * 8, lane);
       }
       if (e <= EA + 1) { pos0 += SH::ME; if (pos0 >= SH::MIDR) pos0 -= SH::MIDR; jE += SH::ME; }
       if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -686,8 +706,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedT
     for (int e = 0; e < NE; e++) {
       const unsigned long long tb = FUSED_CLK();
       if (e <= EA) {
-        fused_stage_a<D, NA, PAR>(a, tv, s, jE, pos0, lds_f + (size_t)slot * SH::RS * 8, midr, aw, lane, (ABL & 1) != 0, ABL & 24);
+        const unsigned char *sl = lds_f + (size_t)slot * SH::RS * 8;
+        fused_stage_a<D, NA, PAR>(a, tv, s, jE, pos0, sl, midr, aw, lane, (ABL & 1) != 0, ABL & 24);
         slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
+        if (aw == 0 && e < EA) fused_copy_preroll<D, NA>(sl, lds_f + (size_t)slot * SH::RS * 8, lane);
         pos0 += SH::ME; if (pos0 >= SH::MIDR) pos0 -= SH::MIDR;
         jE += SH::ME;
       }

@@ -14,6 +14,17 @@ python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o ${tag} -- python bench.py --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_write.log 2>&1
+# the three-kernel front end (FMR_NO_FUSED=1) under the same counters, for the traffic comparison
+FMR_NO_FUSED=1 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_nofused.json 2> gpurun_out/${tag}_bench_nofused.err
+FMR_NO_FUSED=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch_nofused -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch_nofused.log 2>&1
+FMR_NO_FUSED=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write_nofused -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_write_nofused.log 2>&1
+# the other configs of BASELINE.json (lines only)
+python bench.py --streams 32 --blocks 128 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_config5_32streams.json 2>/dev/null
+python bench.py --multipath-stages 64 --blocks 64 --steps 5 --warmup 3 > gpurun_out/${tag}_bench_config4_E64.json 2>/dev/null
+python bench.py --multipath-stages 64 --streams 32 --blocks 64 --steps 3 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_config4_E64_32streams.json 2>/dev/null
+python bench.py --mode am --steps 20 --warmup 3 > gpurun_out/${tag}_bench_config3_am.json 2>/dev/null
+python bench.py --mode am --streams 32 --blocks 1024 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_config3_am_32streams.json 2>/dev/null
+python bench.py --no-pilot --steps 3 --warmup 1 --blocks 256 --no-cpu-baseline > gpurun_out/${tag}_bench_no_pilot.json 2>/dev/null
 tail -3 gpurun_out/${tag}_pytest_gpu.log
 cat gpurun_out/${tag}_smoke.log | tail -2
 cut -c1-400 gpurun_out/${tag}_bench.json

@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out/c9
+timeout 120 tools/bench_ldsread.bin > gpurun_out/c9/ldsread.log 2>&1
+timeout 300 tools/bench_fused.bin > gpurun_out/c9/fused.log 2>&1
+echo "fused rc=$?" >> gpurun_out/c9/fused.log
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -x -q > gpurun_out/c9/tests.log 2>&1
+echo "tests rc=$?" >> gpurun_out/c9/tests.log
+timeout 300 python bench.py --no-cpu-baseline > gpurun_out/c9/bench.json 2> gpurun_out/c9/bench.err
+tail -3 gpurun_out/c9/tests.log; grep -v "^call\|^mid tail" gpurun_out/c9/fused.log | head -30; cut -c1-600 gpurun_out/c9/bench.json

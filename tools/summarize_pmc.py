@@ -26,5 +26,6 @@ for k in sorted(set(fetch) | set(write)):
     out["kernels"][k] = {"fetch_size_kib_raw": fetch.get(k, 0.0), "write_size_kib_raw": write.get(k, 0.0),
                          "read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-k = [n for n in out["kernels"] if "k_ifr_decim" in n][0]
-print(k, out["kernels"][k])
+for k in out["kernels"]:
+    if "k_ifr_fused" in k or "k_ifr_decim" in k or "k_ifr_poly" in k or "k_disc" in k:
+        print(k, out["kernels"][k])
