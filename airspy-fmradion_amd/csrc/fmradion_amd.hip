@@ -1029,6 +1029,14 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     a.nf = disc_nf; a.bound = disc_bound;
     a.st = d_state.p; a.hB_last = d_hB_last.p; a.part = d_fused_part.p;
     a.if_off = bt.if_off; a.if_len = bt.if_len; a.nb = nb;
+    {   // the first block k_stats walks (kernels.hpp, same rule): earlier blocks need no partial sums
+      int seen = 0, b_first = 0;
+      for (int b0 = ((nb - 1) / 64) * 64; b0 > 0 && !b_first; b0 -= 64) {
+        for (int b = b0; b < std::min(b0 + 64, nb); b++) seen += t_if_len[b] != 0;
+        if (seen >= 400) b_first = b0;
+      }
+      a.part_from = t_if_off[b_first];
+    }
     if ((size_t)a.n_tiles * 3 * S > d_fused_part.n) { set_err("internal capacity exceeded (fused tiles)"); return FMR_ERR_CAPACITY; }
     constexpr size_t kLds = FusedShape<D, NA>::LDS_BYTES;
     timed("ifr_fused", [&] {

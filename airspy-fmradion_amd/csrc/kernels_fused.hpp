@@ -54,6 +54,7 @@ struct FusedArgs {
   const float *hB_last;                                       // stage-B tap row of position 47 (TB taps): the IF sample before a run
   FusedPart *part;                                            // [S][3 n_tiles] partial sums per 128-sample third of a macro tile
   const int *if_off; const int *if_len; int nb;               // block table (IF index space, this call)
+  int part_from;                                              // partial sums are needed from this IF index on (k_stats walks the last ~400 blocks)
   const int *wg_blk0;                                         // [gridDim.x]: block that holds the first IF sample of each workgroup's run
   unsigned long long *dbg;                                    // tools/bench_fused.hip: per wave {busy, total} shader cycles of workgroup 0
 };
@@ -353,6 +354,130 @@ __device__ __forceinline__ void fused_stage_a_half(const FusedArgs &a, const Fus
   }
 }
 
+// ---- role: stage A, quad form (12-wave workgroup, FUSED_A_FORM = 2) ------------------------------------------
+// Four neighbouring lanes share four consecutive outputs: lane 4 g + q runs quarter q of the tap window (QS = 19 of
+// the 76 word steps) for outputs 4 g .. 4 g + 3, the quad adds its partial sums with two DPP steps and lane q stores
+// output 4 g + q -- a wave stores 64 consecutive mid samples.  Why this shape (tools/bench_ldsread.hip,
+// tools/bench_pkfma.hip): a ds_read_b128 costs ~5.4 cycles of the CU's LDS pipe whether 16 or 64 lanes are active, and
+// one wave issues a packed FMA only every ~6 cycles.  Against three outputs on 42 lanes of a wave this form reads
+// 8 x 34 instead of 8 x 48 words per epoch and issues 152 instead of 228 packed FMAs per wave, with all 64 lanes
+// busy, no partial sums in LDS and no extra epoch of latency.  Lane addresses 20 g + 19 q (16-byte words) are distinct
+// mod 16 over any 16 consecutive lanes: conflict-free.  Words are consumed in load order (word w feeds output o at
+// step w - 5 o), so a word's registers die after its eight FMAs; the quarter's 38 taps stay in VGPR pairs.
+template <int D, int NA, int PAR>
+struct FusedQuad {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  static constexpr int HD = D / 2, OQ = 4, NSTEP = (PAR + NA - 1) / 2 + 1, QS = NSTEP / 4, NW = QS + (OQ - 1) * HD;
+  static_assert(NSTEP % 4 == 0 && D == 10, "quarter windows of equal length; lane addresses 20 g + 19 q");
+  v2f tp[QS];                               // tap pair of step t of this lane's quarter: (even sample, odd sample) of the word
+  __device__ __forceinline__ void load(const float *h, int q) {     // h = a.taps + FUSED_TAP_PAD (zero padded both sides)
+#pragma unroll
+    for (int t = 0; t < QS; t++) {
+      const int k0 = PAR + NA - 1 - 2 * (QS * q + t);
+      tp[t] = (v2f){h[k0], h[k0 - 1]};
+      asm volatile("" : "+v"(tp[t]));
+    }
+  }
+  template <int W>
+  __device__ __forceinline__ void word(v2f (&acc)[OQ][2], const v4f xx) const {
+#pragma unroll
+    for (int o = 0; o < OQ; o++) {
+      const int t = W - HD * o;
+      if (t >= 0 && t < QS) {
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[o][0]) : "v"(tp[t]), "v"((v2f){xx.x, xx.y}));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[o][1]) : "v"(tp[t]), "v"((v2f){xx.z, xx.w}));
+      }
+    }
+  }
+  // ROT: the i-th word a wave handles is word (i + ROT) mod NW.  A word feeds 1, 2, 3, 4, 3, 2, 1 outputs along the
+  // window, so a wave is LDS-bound at both ends and issue-bound in the middle; the two stage-A waves of a SIMD run
+  // half a window apart (ROT = 0 / NW / 2) and the FMA density of the pair is flat.
+  template <int ROT, int I0, int I1>
+  __device__ __forceinline__ void words(v2f (&acc)[OQ][2], const v4f *x) const {
+    if constexpr (I0 < I1) { word<(I0 + ROT) % NW>(acc, x[I0]); words<ROT, I0 + 1, I1>(acc, x); }
+  }
+  template <int ROT, int I0, int I1>
+  __device__ __forceinline__ void words(v2f (&acc)[OQ][2], const v4f *, const v4f z) const {     // ablation form
+    if constexpr (I0 < I1) { word<(I0 + ROT) % NW>(acc, z); words<ROT, I0 + 1, I1>(acc, nullptr, z); }
+  }
+  template <int ROT, int G, int PF, int GI>
+  __device__ __forceinline__ void groups(v2f (&acc)[OQ][2], const v4f *w, v4f *x) const {
+    constexpr int NGRP = (NW + G - 1) / G;
+    if constexpr (GI < NGRP) {
+#pragma unroll
+      for (int t = 0; t < G; t++) { const int i = PF + G * GI + t; if (i < NW) x[i] = w[(i + ROT) % NW]; }
+      words<ROT, G * GI, (G * GI + G < NW ? G * GI + G : NW)>(acc, x);
+      __builtin_amdgcn_sched_barrier(0);
+      groups<ROT, G, PF, GI + 1>(acc, w, x);
+    }
+  }
+  // one epoch: ME outputs from the slot; aw = 0..7
+  template <int ROT, int ABL = 0>
+  __device__ __forceinline__ void run(const FusedArgs &a, int s, int jE, int pos0, const unsigned char *slot, float2 *midr,
+                                      int aw, int lane, bool no_math) const {
+    using SH = FusedShape<D, NA>;
+    const int jl = 64 * aw + lane;                      // = 4 g + q: the output this lane stores
+    if ((jl & ~3) >= SH::ME) return;                    // whole quads only (ME is a multiple of 4)
+    const int g = jl >> 2, q = lane & 3;
+    const v4f *w = reinterpret_cast<const v4f *>(__builtin_assume_aligned(slot, 16)) + (OQ * HD) * g + QS * q;
+    v2f acc[OQ][2];
+#pragma unroll
+    for (int o = 0; o < OQ; o++) acc[o][0] = acc[o][1] = (v2f){0.f, 0.f};
+    if (!no_math) {
+      constexpr int G = 4, PF = 8;
+      v4f x[NW + G + PF];
+      if (ABL & 8) {            // ablation: the FMAs alone (operands from registers)
+        v4f z = {1.f, 2.f, 3.f, 4.f};
+        asm volatile("" : "+v"(z));
+        words<ROT, 0, NW>(acc, &z - 0, z);
+      } else if (ABL & 16) {    // ablation: the LDS reads alone
+        v4f sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NW; i++) { const v4f t = w[i]; sum += t; }
+        acc[0][0] = (v2f){sum.x + sum.z, sum.y + sum.w};
+      } else {
+#pragma unroll
+        for (int i = 0; i < PF && i < NW; i++) x[i] = w[(i + ROT) % NW];
+        groups<ROT, G, PF, 0>(acc, w, x);
+      }
+    }
+    // quad reduce-scatter: lane q ends with the total of output q.  Step 1 pairs q with q ^ 2 (each keeps two outputs,
+    // hands over its partial sums of the other two), step 2 pairs q with q ^ 1: ((q) + (q^2)) + ((q^1) + (q^3)).
+    auto xq = [](v2f v, auto ctrl) {
+      constexpr int C = decltype(ctrl)::value;
+      return (v2f){__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), C, 0xF, 0xF, true)),
+                   __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), C, 0xF, 0xF, true))};
+    };
+    v2f y[OQ];
+#pragma unroll
+    for (int o = 0; o < OQ; o++) y[o] = acc[o][0] + acc[o][1];
+    const bool hi = (q & 2) != 0, od = (q & 1) != 0;
+    v2f ka = hi ? y[2] : y[0], kb2 = hi ? y[3] : y[1];
+    const v2f sa = hi ? y[0] : y[2], sb = hi ? y[1] : y[3];
+    ka += xq(sa, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    kb2 += xq(sb, std::integral_constant<int, 0x4E>{});
+    v2f ke = od ? kb2 : ka;
+    const v2f se = od ? ka : kb2;
+    ke += xq(se, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    float2 yo = make_float2(ke.x, ke.y);
+    const int j = jE + jl;
+    if (jE < 0) {                    // (wave-uniform test first: only a call's first epochs reach back)
+      if (j < 0) {                   // produced by an earlier call: its tail is the prefix halo of d_mid, older samples are never used
+        const int h = j + a.H_mid;
+        yo = (h >= 0) ? a.mid[(long long)s * a.mid_stride + h] : make_float2(0.f, 0.f);
+      }
+    }
+    int pos = pos0 + jl;
+    if (pos >= SH::MIDR) pos -= SH::MIDR;
+    midr[pos] = yo;
+    if (pos < SH::MIDM) midr[pos + SH::MIDR] = yo;
+    // the next call's stage-B history: the last H_mid mid samples of this call, at their d_mid positions (k_shift_halo re-seats them)
+    if (jE + SH::ME > a.count_mid - a.H_mid)
+      if (j >= a.count_mid - a.H_mid && j < a.count_mid && j >= 0) a.mid[(long long)s * a.mid_stride + a.H_mid + j] = yo;
+  }
+};
+
 // One epoch later: ring += second half's partial sum (the sum of two operands does not depend on the order), the
 // overrides for samples of earlier calls, the mirror of the ring's first positions and the next call's history.
 template <int D, int NA>
@@ -443,19 +568,49 @@ struct FusedBlkWin {
   __device__ __forceinline__ int len(int blk) const { return __builtin_amdgcn_readlane(len_l, __builtin_amdgcn_readfirstlane(blk - base)); }
 };
 
+// atan2 for the discriminator: |error| <= 2.9e-7 rad over the plane (rms 7.4e-8, the same as atan2f -- the fp32
+// rounding of the quotient dominates; tests/test_gpu_parity.py holds the discriminator to the oracle).  22 VALU
+// instructions against ~70 of the library call: the epilogue shares a SIMD with two stage-A waves, and what bounds the
+// kernel beside the input stream is VALU issue (~5 cycles per instruction and SIMD, tools/bench_fused.hip).
+// atan(t) = t + t s P(s), s = t^2, t in [0, 1]: degree-7 minimax fit of (atan(t) / t - 1) / s.
+__device__ __forceinline__ float fused_atan2(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float t = mn * __builtin_amdgcn_rcpf(mx);
+  if (mx == 0.f) t = 0.f;                                     // atan2(+-0, +-0)
+  const float sq = t * t;
+  float p = 0.0026222190354019403f;
+  p = fmaf(p, sq, -0.015132431872189045f);
+  p = fmaf(p, sq, 0.04112168401479721f);
+  p = fmaf(p, sq, -0.07366690784692764f);
+  p = fmaf(p, sq, 0.10573924332857132f);
+  p = fmaf(p, sq, -0.1418597251176834f);
+  p = fmaf(p, sq, 0.1999039649963379f);
+  p = fmaf(p, sq, -0.33332985639572144f);
+  float r = fmaf(t, p * sq, t);
+  if (ay > ax) r = 1.57079637f - r;
+  if (__float_as_int(x) < 0) r = 3.14159274f - r;
+  r = copysignf(r, y);
+  if (__builtin_isunordered(x, y)) r = __builtin_nanf("");   // NaN in -> NaN out (the caller zeroes the difference, Utility.h:336-343)
+  return r;
+}
+
 // The discriminator of one staged third (PhaseDiscriminator.cpp:33-46, FmDecode.cpp:141-150): lane l owns samples
 // idx0 + l and idx0 + 64 + l.  prev0 = normalised phase of the sample before idx0 (wave-uniform); save0 = the previous
 // call's last phase (m_save_value), which precedes the call's sample 0.
-template <int MT0>
+template <int MT0, int ABL = 0>
 __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const float2 *stage, int kb, int tile_g, int &blk,
                                                FusedBlkWin &win, float prev0, float save0, float2 *os, int lane) {
   const int idx0 = 128 * MT0, k0 = kb + idx0;
   if (k0 >= a.n_if || k0 + 128 <= 0) return;
   const float2 x0 = stage[idx0 + lane], x1 = stage[idx0 + 64 + lane];
-  const float ph0 = atan2f(x0.y, x0.x) / a.nf, ph1 = atan2f(x1.y, x1.x) / a.nf;     // V4
-  float pv0 = __shfl_up(ph0, 1, 64), pv1 = __shfl_up(ph1, 1, 64);
-  const float ph0_last = __shfl(ph0, 63, 64);
-  if (lane == 0) { pv0 = prev0; pv1 = ph0_last; }
+  const float inv_nf = 1.0f / a.nf;
+  const float ph0 = (ABL & 64) ? x0.x : fused_atan2(x0.y, x0.x) * inv_nf, ph1 = (ABL & 64) ? x1.x : fused_atan2(x1.y, x1.x) * inv_nf;     // V4
+  auto shr1 = [](float v, float first) {       // lane l <- lane l - 1, lane 0 <- first   (DPP wave_shr:1, no LDS crossbar)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xF, 0xF, false));
+  };
+  const float ph0_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ph0), 63));
+  float pv0 = shr1(ph0, prev0), pv1 = shr1(ph1, ph0_last);
   const int ka = k0 + lane, kc = k0 + 64 + lane;
   if (ka == 0) pv0 = save0;
   if (kc == 0) pv1 = save0;
@@ -469,10 +624,11 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
   const float d0 = diff(ph0, pv0), d1 = diff(ph1, pv1);
   const bool va = ka >= 0 && ka < a.n_if, vc = kc >= 0 && kc < a.n_if;
   double *bs = a.base + (long long)s * a.base_stride + a.base_off;
-  if (va) { os[ka] = x0; bs[ka] = (double)d0; if (a.dec) a.dec[(long long)s * a.dec_stride + ka] = d0; }
-  if (vc) { os[kc] = x1; bs[kc] = (double)d1; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
+  if (va && !((ABL & 128) && d0 != 12345.f)) { os[ka] = x0; bs[ka] = (double)d0; if (a.dec) a.dec[(long long)s * a.dec_stride + ka] = d0; }
+  if (vc && !((ABL & 128) && d1 != 12345.f)) { os[kc] = x1; bs[kc] = (double)d1; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
   if (ka == a.n_if - 1) { a.st[s].disc_save_next = ph0; a.st[s].disc_save_valid = 1; }
   if (kc == a.n_if - 1) { a.st[s].disc_save_next = ph1; a.st[s].disc_save_valid = 1; }
+  if ((ABL & 256) || k0 + 128 <= a.part_from) return;
   // ---- per-block partial sums: walk to the block of the first valid sample, cut at its end
   const int kf = k0 < 0 ? 0 : k0;
   for (;;) {
@@ -523,10 +679,10 @@ __device__ __forceinline__ float fused_prev_phase(const FusedArgs &a, const floa
     re = fmaf(h, x.x, re); im = fmaf(h, x.y, im);
     if (++pos == 3000) pos = 0;
   }
-  return atan2f(im, re) / a.nf;
+  return fused_atan2(im, re) * (1.0f / a.nf);
 }
 
-template <int EPT, int LAG, int MT0, bool OFF, bool DBG>
+template <int EPT, int LAG, int MT0, bool OFF, bool DBG, int ABL = 0>
 __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, int t3, int nt, int NE, const float2 *midr, float2 *stage, int lane, int wave) {
   FusedB<MT0, 1> b;
   b.load(a.afrag, lane);
@@ -552,9 +708,9 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
         // phase of the sample before this wave's third: the previous tile's last sample (wave 0) or staged sample 128 MT0 - 1
         float prev0;
         if (MT0 == 0) prev0 = prev_tile;
-        else { const float2 xp = stage[128 * MT0 - 1]; prev0 = atan2f(xp.y, xp.x) / a.nf; }
-        if (MT0 == 0) { const float2 xl = stage[383]; prev_tile = atan2f(xl.y, xl.x) / a.nf; }
-        fused_epilogue<MT0>(a, s, stage, kb, tile_g, blk, win, prev0, save0, os, lane);
+        else { const float2 xp = stage[128 * MT0 - 1]; prev0 = fused_atan2(xp.y, xp.x) * (1.0f / a.nf); }
+        if (MT0 == 0) { const float2 xl = stage[383]; prev_tile = fused_atan2(xl.y, xl.x) * (1.0f / a.nf); }
+        fused_epilogue<MT0, ABL>(a, s, stage, kb, tile_g, blk, win, prev0, save0, os, lane);
       } else {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -603,10 +759,14 @@ __global__ void k_fused_blk_reduce(const FusedPart *__restrict__ part, int n_til
 }
 
 // ABL: ablation mask for tools/bench_fused.hip (0 = product; 1 no stage-A arithmetic, 2 no stage-B MFMAs, 4 no input DMA)
-#ifndef FUSED_KSPLIT
-#define FUSED_KSPLIT 1        // 12-wave workgroup, stage A split over two waves per SIMD (needs FUSED_OPL = 3)
+// FUSED_A_FORM: how stage A is laid over waves.  2 = quad form (product): 12-wave workgroup, eight stage-A waves, four
+// lanes per group of four outputs.  1 = k-split halves (12 waves, two waves per 42 x 3 outputs, partial sums through
+// LDS, one more epoch of latency).  0 = 8-wave workgroup, one wave per 42 x 3 outputs.  1 and 0 need FUSED_OPL = 3.
+#ifndef FUSED_A_FORM
+#define FUSED_A_FORM 2
 #endif
-#define FUSED_THREADS (FUSED_KSPLIT ? 768 : 512)
+#define FUSED_KSPLIT (FUSED_A_FORM == 1)
+#define FUSED_THREADS (FUSED_A_FORM ? 768 : 512)
 template <int D, int NA, int PAR, int ABL = 0>
 __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedTaps taps) {
   using SH = FusedShape<D, NA>;
@@ -664,11 +824,35 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedT
     if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[0] = busy; a.dbg[1] = FUSED_CLK() - t_begin; }
   } else if (wave == 1) {
     // ------------------------------------------------------------------ stage B (one row tile per wave) + a third of the epilogue
-    fused_role_b<SH::EPT, FUSED_KSPLIT, 0, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, FUSED_KSPLIT, 0, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
   } else if (wave == 2) {
-    fused_role_b<SH::EPT, FUSED_KSPLIT, 1, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, FUSED_KSPLIT, 1, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
   } else if (wave == 3) {
-    fused_role_b<SH::EPT, FUSED_KSPLIT, 2, (ABL & 2) != 0, (ABL & 32) != 0>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, FUSED_KSPLIT, 2, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+  } else if (FUSED_A_FORM == 2) {
+    // ------------------------------------------------------------------ stage A, quad form
+    const int aw = wave - 4;
+    FusedQuad<D, NA, PAR> qa;
+    qa.load(a.taps + FUSED_TAP_PAD, lane & 3);
+    fused_barrier();
+    int slot = 0, pos0 = pos00, jE = jE0;
+    unsigned long long busy = 0, t_begin = FUSED_CLK();
+    for (int e = 0; e < NE; e++) {
+      const unsigned long long tb = FUSED_CLK();
+      if (e <= EA) {
+        const unsigned char *sl = lds_f + (size_t)slot * SH::RS * 8;
+        if (aw < 4) qa.template run<0, (ABL & 24)>(a, s, jE, pos0, sl, midr, aw, lane, (ABL & 1) != 0);
+        else qa.template run<FusedQuad<D, NA, PAR>::NW / 2, (ABL & 24)>(a, s, jE, pos0, sl, midr, aw, lane, (ABL & 1) != 0);
+        slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
+        if (aw == 7 && e < EA) fused_copy_preroll<D, NA>(sl, lds_f + (size_t)slot * SH::RS * 8, lane);
+        pos0 += SH::ME; if (pos0 >= SH::MIDR) pos0 -= SH::MIDR;
+        jE += SH::ME;
+      }
+      if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      busy += FUSED_CLK() - tb;
+      fused_barrier();
+    }
+    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[2 * wave] = busy; a.dbg[2 * wave + 1] = FUSED_CLK() - t_begin; }
   } else if (FUSED_KSPLIT) {
     // ------------------------------------------------------------------ stage A, two half-waves per output group
     const int aw = (wave - 4) & 3, half = (wave - 4) >> 2;
@@ -694,7 +878,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedT
       busy += FUSED_CLK() - tb;
       fused_barrier();
     }
-    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wave < 8) { a.dbg[2 * wave] = busy; a.dbg[2 * wave + 1] = FUSED_CLK() - t_begin; }
+    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[2 * wave] = busy; a.dbg[2 * wave + 1] = FUSED_CLK() - t_begin; }
   } else {
     // ------------------------------------------------------------------ stage A (8-wave workgroup: one wave per output group)
     const int aw = wave - 4;

@@ -10,7 +10,8 @@ __global__ __launch_bounds__(256) void k(float *out, int stride_words, int iters
   for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = (v4f){1.f, 2.f, 3.f, (float)i};
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const v4f *p = lds + (lane * stride_words + wave * 7) % 4096;
+  // stride_words < 0: the quad pattern of the fused kernel's stage A (lane 4 g + q reads word 20 g + 19 q)
+  const v4f *p = lds + (stride_words < 0 ? 20 * (lane >> 2) + 19 * (lane & 3) + wave * 320 : (lane * stride_words + wave * 7) % 4096);
   v4f acc = {0.f, 0.f, 0.f, 0.f};
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters && lane < active; it++) {
@@ -37,7 +38,7 @@ int main() {
     printf("ds_read_b128, lane stride %2d words, 4 waves/CU: %.2f cycles per wave-instruction per wave => %.2f per CU-instr\n", stride, (double)c / (iters * 32.0), (double)c / (iters * 32.0) / 4);
   }
   // active lanes per wave (the rest of the wave is masked off): does a partly filled ds_read_b128 cost less?
-  for (int stride : {15, 10, 20, 21})
+  for (int stride : {-1, 15, 10, 20, 21})
     for (int active : {64, 63, 48, 42, 32, 16}) {
       for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(k<32>, dim3(256), dim3(256), 8192 * 16, 0, out, stride, iters, cyc, active); CK(hipDeviceSynchronize()); }
       unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
