@@ -143,14 +143,15 @@ def filter_table(name):
 
 def design_taps(in_rate, out_rate, atten_db, stage):
     """The product's resampler design (host arithmetic of csrc/design.hpp; no GPU needed): (taps, info dict)."""
-    info = (C.c_longlong * 5)()
+    info = (C.c_longlong * 6)()
     n = lib().fmr_design_taps(in_rate, out_rate, atten_db, stage, None, 0, info)
     if n < 0:
         raise FmrError(f"fmr_design_taps failed ({n}): {lib().fmr_last_error().decode()}")
     buf = np.empty(n, dtype=np.float64)
     lib().fmr_design_taps(in_rate, out_rate, atten_db, stage, buf.ctypes.data_as(C.POINTER(C.c_double)), n, info)
-    d = dict(zip(["D", "NA", "LB", "MB", "TB"], [int(v) for v in info]))
-    return (buf.reshape(d["LB"], d["TB"]) if stage else buf), d
+    d = dict(zip(["D", "NA", "LB", "MB", "TB", "LT"], [int(v) for v in info]))
+    rows = d["LT"] + 1 if d["LT"] else d["LB"]          # fractional-phase form: LT + 1 rows, interpolated
+    return (buf.reshape(rows, d["TB"]) if stage else buf), d
 
 
 DELAY_3TAPS = np.array([0.0, 1.0, 0.0], dtype=np.float32)  # FilterParameters::delay_3taps_only_iq
@@ -199,7 +200,7 @@ class Chain:
         return rc
 
     def resampler_info(self):
-        return {k: lib().fmr_resampler_info(self.h, i) for i, k in enumerate(["D", "NA", "LB", "MB", "TB"])}
+        return {k: lib().fmr_resampler_info(self.h, i) for i, k in enumerate(["D", "NA", "LB", "MB", "TB", "LT"])}
 
     # --- host-buffer API ---------------------------------------------------------
     def process(self, iq):

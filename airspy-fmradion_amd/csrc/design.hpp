@@ -49,8 +49,12 @@ struct ResamplerDesign {
   int D = 1, NA = 0;
   long long LB = 1, MB = 1;
   int TB = 2;
+  // LT = 0: one table row per phase.  LT > 0, the fractional-phase form for ratios whose LB rows would not fit (ppm
+  // corrected source rates, main.cpp:708-711): rows are the prototype at mu = p / LT, p = 0 .. LT, and the taps of
+  // the output at mu = (k MB mod LB) / LB are interpolated linearly between rows floor(mu LT) and floor(mu LT) + 1.
+  int LT = 0;
   std::vector<double> hA;  // [NA]
-  std::vector<double> hB;  // [LB][TB]
+  std::vector<double> hB;  // [LB][TB], or [LT + 1][TB]
 
   bool design(double in_r, double out_r, double atten_db) {
     in_rate = in_r; out_rate = out_r; atten = atten_db;
@@ -59,8 +63,12 @@ struct ResamplerDesign {
     const double i0b = bessel_i0(beta);
     const double fpass = 0.885 * out_rate * 0.5;
     const double fstop = out_rate - fpass;
-    const long long in_i = llround(in_rate), out_i = llround(out_rate);
-    if (in_i <= 0 || out_i <= 0 || std::fabs(in_rate - in_i) > 1e-6 || std::fabs(out_rate - out_i) > 1e-6) return false;
+    long long in_i = llround(in_rate), out_i = llround(out_rate);
+    if (!(in_rate > 0.5) || !(out_rate > 0.5) || in_rate > 4e9 || out_rate > 4e9) return false;
+    if (std::fabs(in_rate - in_i) > 1e-6 || std::fabs(out_rate - out_i) > 1e-6) {
+      // rates that are not whole hertz are taken to the millihertz: the ratio stays an exact rational
+      in_i = llround(in_rate * 1000.0); out_i = llround(out_rate * 1000.0);
+    }
     const long long g = gcd_ll(in_i, out_i);
     L = out_i / g; M = in_i / g;
     D = (int)std::floor(in_rate / (2.6 * out_rate));
@@ -95,20 +103,22 @@ struct ResamplerDesign {
     if (T & 1) T++;
     if (T < 2) T = 2;
     TB = T;
-    if (LB * (long long)T > (1ll << 22)) return false;  // table too large: unsupported ratio
-    hB.resize(size_t(LB) * T);
+    if (T > 4096 || LB >= (1ll << 36) || MB >= (1ll << 36)) return false;   // outside the kernels' index arithmetic
+    LT = (LB * (long long)T > (1ll << 22)) ? 1024 : 0;
+    const long long rows = LT ? LT + 1 : LB, prow = LT ? LT : LB;
+    hB.resize(size_t(rows) * T);
     const double W = 0.5 * T;
     const double fc = 0.5 * out_rate / mid;
     double sum = 0;
-    for (long long p = 0; p < LB; p++)
+    for (long long p = 0; p < rows; p++)
       for (int j = 0; j < T; j++) {
-        const double t = double(p) / double(LB) + W - 1.0 - j, r = t / W;
+        const double t = double(p) / double(prow) + W - 1.0 - j, r = t / W;
         const double w = bessel_i0(beta * std::sqrt(std::fmax(0.0, 1.0 - r * r))) / i0b;
         const double v = 2.0 * fc * sinc_pi(2.0 * fc * t) * w;
         hB[size_t(p) * T + j] = v;
-        sum += v;
+        if (p < prow) sum += v;
       }
-    const double scale = double(LB) / sum;
+    const double scale = double(prow) / sum;
     for (auto &v : hB) v *= scale;
     return true;
   }
@@ -129,7 +139,7 @@ struct ResamplerCounter {
   static long long kB_avail(const ResamplerDesign &d, long long mA_) {
     const int W = d.W();
     if (mA_ < W + 1) return 0;
-    return ((mA_ - W) * d.LB + d.MB - 1) / d.MB;
+    return (long long)(((__int128)(mA_ - W) * d.LB + d.MB - 1) / d.MB);
   }
   // advance by n inputs; returns the number of new outputs
   long long advance(const ResamplerDesign &d, long long n) {

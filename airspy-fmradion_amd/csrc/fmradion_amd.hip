@@ -148,6 +148,7 @@ struct fmr_chain {
   DevBuf<float> d_hBp;                 // zero-padded tap rows for v3
   DevBuf<float> d_hpA;                 // stage-A taps in polyphase order [D][Q] (k_ifr_decim2)
   int qa = 0;                          // taps per phase (even), 0 = v2 kernel not applicable
+  int hB_pitch = 0;                    // fractional-phase stage B: row pitch of d_hB (floats)
   DevBuf<float> d_gain, d_dec, d_hA, d_hB, d_coeff, d_atan, d_if_rms_blk, d_bb_mean_blk, d_bb_rms_blk;
   DevBuf<double> d_base, d_raw, d_am0, d_am1, d_a10, d_a11, d_pc0, d_pc1, d_audio, d_ahA, d_ahB, d_pilotcut;
   DevBuf<int> d_tab, d_mpf_ok, d_stereo_blk;
@@ -331,6 +332,12 @@ int fmr_chain::init(const fmr_config *c) {
     max_mid = max_in / rs.D + 2;
     max_if = (size_t)((double)max_in * rs.L / rs.M) + 4;
     std::vector<float> fa(rs.hA.begin(), rs.hA.end()), fb(rs.hB.begin(), rs.hB.end());
+    if (rs.LT) {            // fractional-phase form: rows padded to a multiple of four taps (float4 row loads)
+      hB_pitch = (rs.TB + 3) & ~3;
+      fb.assign((size_t)(rs.LT + 1) * hB_pitch, 0.f);
+      for (int p = 0; p <= rs.LT; p++)
+        for (int j = 0; j < rs.TB; j++) fb[(size_t)p * hB_pitch + j] = (float)rs.hB[(size_t)p * rs.TB + j];
+    }
     int rc;
     if ((rc = upload(d_hA, fa.data(), fa.size()))) return rc;
     if ((rc = upload(d_hB, fb.data(), fb.size()))) return rc;
@@ -360,7 +367,7 @@ int fmr_chain::init(const fmr_config *c) {
         return FMR_ERR_UNSUPPORTED;
       }
     }
-    {
+    if (!rs.LT) {
       // stage-B v2: 64 periods per tile must fit in LDS, odd MB keeps the lane stride conflict-free
       std::vector<int> phi((size_t)rs.LB), off((size_t)rs.LB);
       for (long long q = 0; q < rs.LB; q++) { phi[q] = (int)((q * rs.MB) % rs.LB); off[q] = (int)((q * rs.MB) / rs.LB); }
@@ -872,6 +879,16 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       const dim3 grid((unsigned)((N_if + BL - 1) / BL), S);
       const int span = (int)(((unsigned long long)(BL - 1) * rs.MB) / rs.LB) + rs.TB + 2;
       timed_on(fes, "ifr_poly", [&] {
+        if (rs.LT) {
+          // fractional-phase form: exact integer positions, call-relative on the device
+          const __int128 tt = (__int128)kB_prev * rs.MB;
+          const long long nk0 = (long long)(tt / rs.LB);
+          const unsigned long long rem0 = (unsigned long long)(tt % rs.LB);
+          hipLaunchKernelGGL(k_ifr_poly_frac<BL>, grid, dim3(BL), sizeof(float2) * (span + 4), fes, d_mid.p,
+                             (long long)(H_mid + max_mid), nk0 - rs.W() + 1 - (mA_prev - H_mid), H_mid + count_mid, d_hB.p,
+                             rs.TB, hB_pitch, rs.LT, (unsigned long long)rs.LB, (unsigned long long)rs.MB, rem0, (int)N_if,
+                             ifbuf, (long long)(H_if + max_if), H_if);
+        } else
         hipLaunchKernelGGL(k_ifr_poly<BL>, grid, dim3(BL), sizeof(float2) * span, fes, d_mid.p,
                            (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_hB.p, rs.TB,
                            (unsigned)rs.LB, (unsigned)rs.MB, (unsigned long long)kB_prev * rs.MB, (int)N_if,
@@ -1452,6 +1469,7 @@ long long fmr_resampler_info(const fmr_chain *c, int which) {
   case 2: return c->rs.LB;
   case 3: return c->rs.MB;
   case 4: return c->rs.TB;
+  case 5: return c->rs.LT;
   }
   return -1;
 }
@@ -1460,7 +1478,7 @@ long long fmr_design_taps(double in_rate, double out_rate, double atten_db, int 
                           long long *info) {
   ResamplerDesign d;
   if (!d.design(in_rate, out_rate, atten_db)) { set_err("resampling ratio outside the design range"); return FMR_ERR_UNSUPPORTED; }
-  if (info) { info[0] = d.D; info[1] = d.NA; info[2] = d.LB; info[3] = d.MB; info[4] = d.TB; }
+  if (info) { info[0] = d.D; info[1] = d.NA; info[2] = d.LB; info[3] = d.MB; info[4] = d.TB; info[5] = d.LT; }
   const std::vector<double> &h = stage ? d.hB : d.hA;
   if (!taps) return (long long)h.size();
   if ((long long)h.size() > cap) return FMR_ERR_CAPACITY;

@@ -430,6 +430,59 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_poly(
 }
 
 // ---------------------------------------------------------------------------
+// K_B frac  ifr_poly_frac : stage B for ratios whose phase table would not fit -- ppm-corrected source rates
+// (main.cpp:708-711: LB of the order 1e5 .. 1e8).  The table holds the prototype at mu = p / LT, p = 0 .. LT; the taps of
+// an output are interpolated linearly between the two rows around its exact phase (design.hpp).  Positions are exact
+// integers, call-relative: t = rem0 + k MB in units of 1 / LB mid sample, n_k = nk0 + t / LB, mu = (t mod LB) / LB.
+// x0: index in the stream's mid buffer of the first sample output 0 reads (nk0 - W + 1); TBP: row pitch (TB rounded up
+// to a multiple of 4, zero padded).
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ifr_poly_frac(
+    const float2 *__restrict__ mid, long long mid_stride, long long x0, int mid_valid,
+    const float *__restrict__ tab, int TB, int TBP, int LT, unsigned long long LB, unsigned long long MB,
+    unsigned long long rem0, int count, float2 *__restrict__ out, long long out_stride, int out_off) {
+  extern __shared__ float2 lds_b[];
+  const int s = blockIdx.y;
+  const int tid = threadIdx.x;
+  const unsigned long long tk0 = rem0 + (unsigned long long)(blockIdx.x * BLOCK) * MB;
+  const long long n_lo = (long long)(tk0 / LB);
+  const long long x_lo = x0 + n_lo;
+  const int span = (int)(((unsigned long long)(BLOCK - 1) * MB) / LB) + TB + 2 + 4;
+  const float2 *ms = mid + (long long)s * mid_stride;
+  for (int i = tid; i < span; i += BLOCK) {
+    const long long idx = x_lo + i;
+    float2 v = make_float2(0.f, 0.f);
+    if (idx >= 0 && idx < mid_valid) v = ms[idx];
+    lds_b[i] = v;
+  }
+  __syncthreads();
+  const int k = blockIdx.x * BLOCK + tid;
+  if (k < count) {
+    const unsigned long long t = rem0 + (unsigned long long)k * MB;
+    const long long nk = (long long)(t / LB);
+    const unsigned long long xx = (t - (unsigned long long)nk * LB) * (unsigned long long)LT;   // (t mod LB) LT < 2^46
+    const unsigned long long row = xx / LB;
+    const float a = (float)(xx - row * LB) / (float)LB;
+    const float4 *h0 = reinterpret_cast<const float4 *>(tab + (size_t)row * TBP);
+    const float4 *h1 = reinterpret_cast<const float4 *>(tab + (size_t)(row + 1) * TBP);
+    const float2 *xp = lds_b + (int)(nk - n_lo);
+    float ax = 0.f, ay = 0.f;
+    for (int j4 = 0; j4 < TBP / 4; j4++) {
+      const float4 c0 = h0[j4], c1 = h1[j4];
+      const float c[4] = {fmaf(a, c1.x - c0.x, c0.x), fmaf(a, c1.y - c0.y, c0.y), fmaf(a, c1.z - c0.z, c0.z), fmaf(a, c1.w - c0.w, c0.w)};
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float2 x = xp[4 * j4 + u];
+        ax = fmaf(c[u], x.x, ax);
+        ay = fmaf(c[u], x.y, ay);
+      }
+    }
+    out[(long long)s * out_stride + out_off + k] = make_float2(ax, ay);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K_B v2  ifr_poly2 : rational polyphase stage with WAVE-UNIFORM taps.
 // Output k = P*LB + p (P = period, p = position in the period) uses tap phase
 // phi[p] = (p*MB) % LB at mid sample P*MB + off[p], off[p] = (p*MB) / LB.  Lanes own

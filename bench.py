@@ -112,6 +112,26 @@ def _cpu_worker(args):
             return done, dt
 
 
+def committed_pmc_traffic(dom_name, blocks, streams, args):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN_pmc_traffic.json,
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/collect_profiles.sh): counters
+    cannot be read from inside the timed run.  None when no summary matches this configuration."""
+    import glob
+    if streams != 1 or args.mode != "fm" or args.input_format != "cf32" or args.multipath_stages or args.no_pilot:
+        return None, None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(fn))
+        except (OSError, ValueError):
+            continue
+        if d.get("blocks_per_step") != blocks:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if ("k_" + dom_name) in k:
+                return v["hbm_bytes"], os.path.relpath(fn, ROOT) + " (PMC pass of the same command; read bytes = 2 x FETCH_SIZE x 1024, gfx950)"
+    return None, None
+
+
 def cpu_baseline(mode, stages, seconds=8.0):
     """The CPU oracle on the same workload: (i) 1 core, 1 stream -- the reference is single-threaded per stream;
     (ii) N streams on N cores, N = the box's core count."""
@@ -299,6 +319,7 @@ def main():
         else:
             workload = ("configs[1]: single FM stereo stream per GPU, 10 MS/s complex-float IQ in HBM, "
                         "PilotPhaseLock on, IfResampler+FmDecoder -> f64 stereo 48 kHz")
+        pmc_traffic = committed_pmc_traffic(dom_name, B, S, args)
         out = {
             "metric": ("IQ MS/s (AM, 384 kS/s in), whole job" if am else "IQ MS/s (FM stereo, 10 MS/s in), whole job"),
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -310,7 +331,7 @@ def main():
                        "resampler": ch.resampler_info()},
             "roofline": {"bound": "hbm", "kernel": f"{dom_name} (reads every IQ sample)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic[0], "traffic_source": pmc_traffic[1],
                          "avg_launch_ms": round(dec_ms, 5), "algorithmic_bytes_per_launch": bytes_per_launch,
                          "stage": {"what": "FIR + discriminator stage (north star): sum of the average launch durations of "
                                            + " + ".join(k for k in STAGE_KERNELS if k in stage_src),

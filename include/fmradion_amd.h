@@ -125,12 +125,14 @@ const char *fmr_last_error(void);
 const char *fmr_version(void);
 
 /* Design introspection of the resampler stand-in (DESIGN.md "Resampler
- * specification").  which = 0:D 1:NA 2:LB 3:MB 4:TB ; -1 when no resampler. */
+ * specification").  which = 0:D 1:NA 2:LB 3:MB 4:TB 5:LT (rows of the interpolated
+ * phase table of the fractional-phase form, 0 = one row per phase); -1 when no resampler. */
 long long fmr_resampler_info(const fmr_chain *c, int which);
 
 /* The product's resampler design on the host (no GPU needed): taps of stage A (stage = 0, NA doubles) or of the
- * polyphase stage B (stage = 1, LB x TB doubles, row = phase) for in_rate -> out_rate at atten_db; info[0..4] receive
- * D, NA, LB, MB, TB.  Returns the number of taps of the stage, or a negative error (cap too small / unsupported
+ * polyphase stage B (stage = 1, LB x TB doubles, row = phase; (LT + 1) x TB in the fractional-phase form that ratios
+ * with very large LB take, e.g. ppm-corrected source rates, main.cpp:708-711) for in_rate -> out_rate at atten_db;
+ * info[0..5] receive D, NA, LB, MB, TB, LT.  Rates that are not whole hertz are taken to the millihertz.  Returns the number of taps of the stage, or a negative error (cap too small / unsupported
  * ratio).  Lets tests check the design against an independent construction without a device. */
 long long fmr_design_taps(double in_rate, double out_rate, double atten_db, int stage, double *taps, long long cap,
                           long long *info);

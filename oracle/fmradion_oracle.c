@@ -55,7 +55,11 @@ struct ora_resampler {
   double *hA;
   long long LB, MB; /* stage B ratio out/mid = LB/MB */
   int TB;           /* stage B taps per phase (even) */
-  double *hB;       /* [LB][TB] */
+  double *hB;       /* [LB][TB]; fractional-phase form: [LT + 1][TB] */
+  int LT;           /* 0: one table row per phase.  > 0 (fractional-phase form, ratios whose LB rows would not fit, e.g.
+                     * ppm-corrected rates, main.cpp:708-711): rows are the prototype at mu = p / LT, p = 0 .. LT, and the
+                     * taps of an output at mu = (k MB mod LB) / LB are interpolated linearly between rows
+                     * floor(mu LT) and floor(mu LT) + 1 */
   /* streaming state */
   long long n_in;   /* inputs consumed so far */
   long long mA;     /* stage A outputs produced so far */
@@ -71,6 +75,10 @@ static void rs_design(ora_resampler *rs) {
   const double fpass = rs->pass_frac * rs->out_rate * 0.5;
   const double fstop = rs->stop_nyquist ? rs->out_rate * 0.5 : rs->out_rate - fpass;
   long long in_i = llround(rs->in_rate), out_i = llround(rs->out_rate);
+  if (fabs(rs->in_rate - (double)in_i) > 1e-6 || fabs(rs->out_rate - (double)out_i) > 1e-6) {
+    /* rates that are not whole hertz are taken to the millihertz: the ratio stays an exact rational */
+    in_i = llround(rs->in_rate * 1000.0); out_i = llround(rs->out_rate * 1000.0);
+  }
   long long g = gcd_ll(in_i, out_i);
   rs->L = out_i / g;
   rs->M = in_i / g;
@@ -111,22 +119,24 @@ static void rs_design(ora_resampler *rs) {
     if (T & 1) T++;
     if (T < 2) T = 2;
     rs->TB = T;
-    rs->hB = (double *)malloc(sizeof(double) * (size_t)rs->LB * T);
+    rs->LT = (rs->LB * (long long)T > (1ll << 22)) ? 1024 : 0;
+    const long long rows = rs->LT ? rs->LT + 1 : rs->LB, prow = rs->LT ? rs->LT : rs->LB;
+    rs->hB = (double *)malloc(sizeof(double) * (size_t)rows * T);
     const double W = 0.5 * T;
     const double fc = 0.5 * rs->out_rate / mid; /* cycles per mid sample */
     double sum = 0;
-    for (long long p = 0; p < rs->LB; p++) {
+    for (long long p = 0; p < rows; p++) {
       for (int j = 0; j < T; j++) {
-        double t = (double)p / (double)rs->LB + W - 1.0 - j;
+        double t = (double)p / (double)prow + W - 1.0 - j;
         double r = t / W;
         double w = bessel_i0(beta * sqrt(fmax(0.0, 1.0 - r * r))) / i0b;
         double v = 2.0 * fc * sinc_pi(2.0 * fc * t) * w;
         rs->hB[p * T + j] = v;
-        sum += v;
+        if (p < prow) sum += v;
       }
     }
-    const double scale = (double)rs->LB / sum;
-    for (long long i = 0; i < rs->LB * T; i++) rs->hB[i] *= scale;
+    const double scale = (double)prow / sum;
+    for (long long i = 0; i < rows * T; i++) rs->hB[i] *= scale;
   }
 }
 
@@ -171,6 +181,7 @@ long long ora_rs_info(const ora_resampler *rs, int which) {
   case 4: return rs->TB;
   case 5: return rs->L;
   case 6: return rs->M;
+  case 7: return rs->LT;
   }
   return -1;
 }
@@ -221,23 +232,31 @@ int ora_rs_process(ora_resampler *rs, const double *in, int n, double *out, int 
   long long kB_avail = 0;
   if (rs->mA >= W + 1) {
     long long q1 = rs->mA - W; /* Q + 1 */
-    kB_avail = (q1 * rs->LB + rs->MB - 1) / rs->MB;
+    kB_avail = (long long)(((__int128)q1 * rs->LB + rs->MB - 1) / rs->MB);
   }
   int nout = (int)(kB_avail - rs->kB);
   if (nout > cap) return -1;
   for (long long k = rs->kB; k < kB_avail; k++) {
-    long long t = k * rs->MB;
-    long long nk = t / rs->LB;
-    long long p = t % rs->LB;
-    const double *h = rs->hB + p * rs->TB;
+    const __int128 t = (__int128)k * rs->MB;
+    long long nk = (long long)(t / rs->LB);
+    long long p = (long long)(t % rs->LB);
     const double *xp = rs->xm + (nk - W + 1 - rs->xm_base);
     double acc = 0.0;
-    for (int j = 0; j < rs->TB; j++) acc += h[j] * xp[j];
+    if (rs->LT) {
+      const __int128 x = (__int128)p * rs->LT;
+      const long long row = (long long)(x / rs->LB);
+      const double a = (double)(long long)(x % rs->LB) / (double)rs->LB;
+      const double *h0 = rs->hB + row * rs->TB, *h1 = h0 + rs->TB;
+      for (int j = 0; j < rs->TB; j++) acc += (h0[j] + a * (h1[j] - h0[j])) * xp[j];
+    } else {
+      const double *h = rs->hB + p * rs->TB;
+      for (int j = 0; j < rs->TB; j++) acc += h[j] * xp[j];
+    }
     out[k - rs->kB] = acc;
   }
   rs->kB = kB_avail;
   {
-    long long nk = (rs->kB * rs->MB) / rs->LB;
+    long long nk = (long long)(((__int128)rs->kB * rs->MB) / rs->LB);
     long long keep_from = nk - W + 1;
     if (keep_from > rs->xm_base) {
       int drop = (int)(keep_from - rs->xm_base);

@@ -270,7 +270,7 @@ class Resampler:
             self.h = None
 
     def info(self):
-        names = ["D", "NA", "LB", "MB", "TB", "L", "M"]
+        names = ["D", "NA", "LB", "MB", "TB", "L", "M", "LT"]
         return {n: lib().ora_rs_info(self.h, i) for i, n in enumerate(names)}
 
     def taps_a(self):
@@ -281,7 +281,8 @@ class Resampler:
 
     def taps_b(self):
         i = self.info()
-        return np.ctypeslib.as_array(lib().ora_rs_taps_b(self.h), shape=(i["LB"], i["TB"])).copy()
+        rows = i["LT"] + 1 if i["LT"] else i["LB"]     # fractional-phase form: LT + 1 rows, interpolated
+        return np.ctypeslib.as_array(lib().ora_rs_taps_b(self.h), shape=(rows, i["TB"])).copy()
 
     def process(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -46,7 +46,7 @@ def test_taps_match_scipy_construction(in_rate, out_rate, atten):
     ha_o, hb_o = rs.taps_a(), rs.taps_b()
     ha_p, dp = fmr.design_taps(in_rate, out_rate, atten, 0)
     hb_p, _ = fmr.design_taps(in_rate, out_rate, atten, 1)
-    assert dp == {k: info[k] for k in ("D", "NA", "LB", "MB", "TB")}
+    assert dp == {k: info[k] for k in ("D", "NA", "LB", "MB", "TB", "LT")} and dp["LT"] == 0
     D, LB, TB = info["D"], info["LB"], info["TB"]
     mid = in_rate / D
     if D > 1:
@@ -146,3 +146,67 @@ def test_specification_gap_vs_r8brain_class(pilotcut):
     assert r["rms_difference_product_vs_r8brain_class"] < r["interference_rms_r8brain_class"]
     r = report["adjacent +100 kHz, -20 dB"]
     assert r["rms_difference_product_vs_r8brain_class"] < 0.01 * r["interference_rms_r8brain_class"]
+
+
+# ---- fractional-phase form: ppm-corrected (non-integer-ratio) rates, main.cpp:708-711 -----------------------------
+PPM_CASES = [(10e6 * (1 + 1.5e-6), 384e3), (10000003.7, 384e3), (1e6 * (1 - 37e-6), 384e3), (384000.4, 48e3)]
+
+
+def _prototype(t, W, fc, beta):
+    """Kaiser-windowed sinc of the specification at (fractional) tap position t -- numpy only."""
+    r = np.clip(1.0 - (t / W) ** 2, 0.0, None)
+    return 2 * fc * np.sinc(2 * fc * t) * np.i0(beta * np.sqrt(r)) / np.i0(beta)
+
+
+@pytest.mark.parametrize("in_rate,out_rate", PPM_CASES)
+def test_fractional_phase_table_and_interpolation(in_rate, out_rate):
+    """Oracle and product build the same interpolated table; its rows are the prototype sampled at mu = p / LT
+    (independent numpy evaluation), and linear interpolation between rows is within 2e-7 of the prototype at any mu."""
+    atten = 140.0
+    rs = ora.Resampler(in_rate, out_rate, atten)
+    info = rs.info()
+    hb_o = rs.taps_b()
+    hb_p, dp = fmr.design_taps(in_rate, out_rate, atten, 1)
+    assert dp == {k: info[k] for k in ("D", "NA", "LB", "MB", "TB", "LT")}
+    LT, TB, D = info["LT"], info["TB"], info["D"]
+    assert LT == 1024 and hb_o.shape == (LT + 1, TB) == hb_p.shape
+    # the exact rational the rates are taken to (millihertz when not whole hertz)
+    scale = 1 if abs(in_rate - round(in_rate)) < 1e-6 else 1000
+    assert info["LB"] * round(in_rate * scale) == info["MB"] * round(out_rate * scale) * D
+    assert np.max(np.abs(hb_o - hb_p)) < 1e-13
+    mid = in_rate / D
+    W, fc, beta = TB / 2, 0.5 * out_rate / mid, signal.kaiser_beta(atten)
+    j = np.arange(TB)
+    rows = np.stack([_prototype(p / LT + W - 1.0 - j, W, fc, beta) for p in range(LT + 1)])
+    gain = LT / rows[:LT].sum()               # unit mean DC gain over the phases
+    rows *= gain
+    assert np.max(np.abs(hb_o - rows)) < 1e-11 * np.max(np.abs(rows))
+    # interpolation error against the prototype evaluated AT the phase
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for mu in rng.uniform(0, 1, 200):
+        x = mu * LT
+        p = int(np.floor(x))
+        lerp = hb_o[p] + (x - p) * (hb_o[p + 1] - hb_o[p])
+        exact = _prototype(mu + W - 1.0 - j, W, fc, beta) * gain
+        worst = max(worst, np.max(np.abs(lerp - exact)))
+    assert worst < 2e-7 * np.max(np.abs(hb_o))
+
+
+@pytest.mark.parametrize("in_rate,out_rate", PPM_CASES)
+def test_fractional_phase_resampling_of_an_analytic_signal(in_rate, out_rate):
+    """Two tones sampled at in_rate go in; the output must be the same continuous signal sampled at k / out_rate (the
+    resampler is latency compensated) -- the check needs no second resampler.  Streaming: block sizes vary."""
+    rs = ora.Resampler(in_rate, out_rate, 140.0)
+    D = rs.info()["D"]
+    n = 60000 * D
+    f0 = 0.13 * out_rate
+    t = np.arange(n) / in_rate
+    sig = lambda tt: np.cos(2 * np.pi * f0 * tt) + 0.3 * np.cos(2 * np.pi * 0.31 * f0 * tt + 1.0)
+    x = sig(t)
+    cuts = [0, 1, 17, 4096, 4097, n // 3 + 11, n // 2, n]
+    y = np.concatenate([rs.process(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert abs(len(y) - n * out_rate / in_rate) < 300
+    ref = sig(np.arange(len(y)) / out_rate)
+    err = (y - ref)[3000:]
+    assert np.sqrt(np.mean(err ** 2)) < 3e-7
