@@ -1,6 +1,6 @@
-"""Copy the summaries tools/collect_profiles.sh left under gpurun_out/<tag>_* into profiles/ and write
-profiles/<tag>_summary.json (the numbers DESIGN.md section 7 quotes).   python tools/finish_profiles.py r02"""
-import csv, glob, json, os, shutil, subprocess, sys
+"""Copy the summaries tools/collect_profiles.sh left under gpurun_out/<tag>_* into profiles/, write
+profiles/<tag>_summary.json and refresh the measured rows of DESIGN.md section 7.   python tools/finish_profiles.py r02"""
+import csv, glob, json, os, re, shutil, subprocess, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = lambda *a: os.path.join(root, "gpurun_out", *a)
@@ -68,3 +68,39 @@ summary = {
 }
 json.dump(summary, open(prof(f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:6000])
+
+# ---- rows keyed by their first column
+rf, cb = bench["roofline"], bench.get("cpu_baseline") or {}
+pm = summary["pmc_traffic"]["kernels"]
+fk = [v for k, v in pm.items() if "k_ifr_fused" in k]
+alg = rf["algorithmic_bytes_per_launch"]
+o = lambda name: others.get(name) or {}
+nf = bench_line(g(f"{tag}_bench_nofused.json"))
+pm3 = json.load(open(prof(f"{tag}_pmc_traffic_three_kernel_front_end.json")))["kernels"] if os.path.exists(prof(f"{tag}_pmc_traffic_three_kernel_front_end.json")) else {}
+three = sum(v["hbm_bytes"] for k, v in pm3.items() if any(n in k for n in ("k_ifr_decim", "k_ifr_poly", "k_disc")))
+gs = lambda v: f"{v / 1e3:.1f} GS/s" if v and v >= 1e4 else (f"{v / 1e3:.2f} GS/s" if v and v >= 1e3 else f"{v:.1f} MS/s")
+rs = summary["rocprofv3_stats"]
+rows = {
+    "whole-job throughput, config 2 (1 stream)": f"{gs(bench['value'])} ({bench['ms_per_step']:.3f} ms per 2^27-sample step)",
+    "`k_ifr_fused` average launch (HIP events in the timed region / rocprofv3)":
+        f"{rf['avg_launch_ms'] * 1e3:.1f} µs (bench run) / {summary['hip_events_profiled_run_ms'] * 1e3:.1f} µs vs {rs['average_us_full_batch_launches']:.1f} µs (events vs rocprofv3 kernel trace, the {rs['full_batch_launches']} full-batch launches of the profiled run; `--stats` average over all {rs['calls']} launches incl. the shorter set-up launches: {rs['average_us_all_launches']:.1f} µs)",
+    "`roofline` (HBM, 8 B × 2^27 per launch ÷ launch time ÷ 8 TB/s) — dominant kernel = the whole FIR + discriminator stage": f"{rf['achieved']:.0f} GB/s = **{rf['frac']:.3f}** of peak",
+    "same stage with the three-kernel front end (`FMR_NO_FUSED=1`, round 1's path, same box)":
+        (f"{nf['roofline']['stage']['ms']:.3f} ms = {nf['roofline']['stage']['frac']:.3f}; whole job {gs(nf['value'])}" if nf else "not collected"),
+    "PMC traffic of the stage (FETCH_SIZE×2 + WRITE_SIZE, separate passes)":
+        (f"{fk[0]['hbm_bytes'] / 1e9:.3f} GB per launch = {fk[0]['hbm_bytes'] / alg:.3f} × algorithmic ({fk[0]['read_bytes'] / 1e9:.3f} GB read, {fk[0]['write_bytes'] / 1e9:.3f} GB write: IF + f64 MPX)" if fk else "n/a")
+        + (f"; three-kernel front end {three / 1e9:.3f} GB = {three / alg:.2f} ×" if three else ""),
+    "CPU oracle (`cpu_baseline`, kind \"port\"), same stream":
+        (f"{cb.get('value', 0):.1f} MS/s on 1 core; {((cb.get('all_cores') or {}).get('value') or 0):.0f} MS/s with one oracle process per core ({(cb.get('all_cores') or {}).get('cores', '?')} cores)" if cb else "n/a"),
+    "audio check inside the bench run (stream 0, first call, vs oracle)": f"RMS error {bench['audio_check'].get('audio_rms_err_vs_oracle')} over {bench['audio_check'].get('audio_samples_checked')} samples (tolerance 1e-5)",
+    "config 5 shard: 32 FM stereo streams per GPU": (f"{gs(o('config5_32streams').get('value'))} ({o('config5_32streams').get('ms_per_step')} ms per step of 32 × 128 blocks)" if o('config5_32streams') else "n/a"),
+    "config 4: `-E 64`, one stream / 32 streams": (f"{gs(o('config4_E64').get('value'))} / {gs(o('config4_E64_32streams').get('value'))}" if o('config4_E64') else "n/a"),
+    "config 3: AM 384 kS/s → 48 k, one stream / 32 streams": (f"{gs(o('config3_am').get('value'))} / {gs(o('config3_am_32streams').get('value'))}" if o('config3_am') else "n/a"),
+    "stereo decoder on a mono station (unlocked PLL, serial fallback)": (f"{gs(o('no_pilot').get('value'))}" if o('no_pilot') else "n/a"),
+}
+pd = os.path.join(root, "DESIGN.md")
+sd = open(pd).read()
+for k, v in rows.items():
+    sd, n = re.subn(r"^\| " + re.escape(k) + r" \|.*\|$", lambda m: f"| {k} | {v} |", sd, flags=re.M)
+    assert n == 1, k
+open(pd, "w").write(sd)
