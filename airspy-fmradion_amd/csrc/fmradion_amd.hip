@@ -81,7 +81,41 @@ struct KernelTime { const char *name; hipEvent_t a, b; };
 
 using namespace fmr;
 
+// Diagnostic switches from the environment, read ONCE when a chain is created (INTEGRATION.md section 4 lists them);
+// nothing on the call path touches the environment.
+struct EnvKnobs {
+  bool serial = false;          // FMR_SERIAL=1       serial recurrence kernels (reference loop order on one lane)
+  bool pipeline = false;        // FMR_PIPELINE=1     front end of call N+1 beside the decoder of call N
+  bool debug_taps = false;      // FMR_DEBUG_TAPS=1   keep intermediate signals readable through fmr_debug_read
+  bool host_prof = false;       // FMR_HOST_PROF=1    host enqueue time per call on stderr
+  bool decim_v1 = false;        // FMR_DECIM_V1=1     round-1 first stage-A kernel
+  bool poly_v1 = false, poly_v2 = false, poly_v3 = false;   // FMR_POLY_V1/V2/V3=1  older stage-B kernels
+  bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end
+  bool agc_early = false;       // FMR_AGC_EARLY      side-stream AGC before the PLL's first pass
+  bool mpf_v1 = false;          // FMR_MPF_V1         round-1 equaliser kernel
+  bool no_split = false;        // FMR_NO_SPLIT       mono and L-R audio tails on one stream
+  bool am_serial_tail = false;  // FMR_AM_SERIAL_TAIL serial AM audio tail
+  int decim_bl = 128;           // FMR_DECIM_BL=256   wider stage-A workgroups
+  int c_pll = 0;                // FMR_C_PLL          PLL chunk length (0 = default)
+  int pll_jac = 0;              // FMR_PLL_JAC        rounds that re-integrate the sensitivities (0 = default)
+  double pll_rtol = -1.0;       // FMR_PLL_RTOL       PLL acceptance threshold (< 0 = default)
+  static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
+  static bool set(const char *n) { return getenv(n) != nullptr; }
+  void load() {
+    serial = on("FMR_SERIAL"); pipeline = on("FMR_PIPELINE"); debug_taps = on("FMR_DEBUG_TAPS");
+    host_prof = on("FMR_HOST_PROF"); decim_v1 = on("FMR_DECIM_V1"); poly_v1 = on("FMR_POLY_V1");
+    poly_v2 = on("FMR_POLY_V2"); poly_v3 = on("FMR_POLY_V3"); no_fused = on("FMR_NO_FUSED");
+    agc_early = set("FMR_AGC_EARLY"); mpf_v1 = set("FMR_MPF_V1"); no_split = set("FMR_NO_SPLIT");
+    am_serial_tail = set("FMR_AM_SERIAL_TAIL");
+    if (const char *e = getenv("FMR_DECIM_BL")) if (atoi(e) == 256) decim_bl = 256;
+    if (const char *e = getenv("FMR_C_PLL")) c_pll = atoi(e);
+    if (const char *e = getenv("FMR_PLL_JAC")) if (e[0] >= '1' && e[0] <= '9') pll_jac = e[0] - '0';
+    if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
+  }
+};
+
 struct fmr_chain {
+  EnvKnobs env;
   fmr_config cfg{};
   int S = 1, mode = FMR_MODE_FM;
   bool has_rs = false, has_dec = true, fir_enable = false, stereo = false, pilot_shift = false;
@@ -282,6 +316,7 @@ static int upload(DevBuf<T> &b, const T *src, size_t n) {
 }
 
 int fmr_chain::init(const fmr_config *c) {
+  env.load();
   cfg = *c;
   S = c->n_streams;
   mode = c->mode;
@@ -351,10 +386,7 @@ int fmr_chain::init(const fmr_config *c) {
         if ((rc = upload(d_hpA, hp.data(), hp.size()))) return rc;
       }
     }
-    {
-      const char *e = getenv("FMR_DECIM_V1");
-      if (e && e[0] == '1') qa = 0;
-    }
+    if (env.decim_v1) qa = 0;
     if (in_fmt != 0) {
       // the fused sample conversion lives in the v2 front-end kernel only: refuse the chain now, not on every call
       constexpr int BL2 = 128, T2 = 2 * BL2;
@@ -372,8 +404,7 @@ int fmr_chain::init(const fmr_config *c) {
       std::vector<int> phi((size_t)rs.LB), off((size_t)rs.LB);
       for (long long q = 0; q < rs.LB; q++) { phi[q] = (int)((q * rs.MB) % rs.LB); off[q] = (int)((q * rs.MB) / rs.LB); }
       const long long tl = 64 * rs.MB + off[rs.LB - 1] + rs.TB;
-      const char *e = getenv("FMR_POLY_V1");
-      if (tl * 8 <= 98304 && rs.LB <= 4096 && !(e && e[0] == '1')) {
+      if (tl * 8 <= 98304 && rs.LB <= 4096 && !env.poly_v1) {
         poly2_tile = (int)tl;
         if ((rc = upload(d_bphi, phi.data(), phi.size()))) return rc;
         if ((rc = upload(d_boff, off.data(), off.size()))) return rc;
@@ -384,8 +415,7 @@ int fmr_chain::init(const fmr_config *c) {
         int dmax = 0;
         for (long long g = 0; g * Q3 < rs.LB; g++)
           dmax = std::max(dmax, off[std::min<long long>(g * Q3 + Q3 - 1, rs.LB - 1)] - off[g * Q3]);
-        const char *e3 = getenv("FMR_POLY_V2");
-        if (dmax <= FMR_POLY_PADZ - 8 && (tl + 64) * 8 <= 98304 && !(e3 && e3[0] == '1')) {
+        if (dmax <= FMR_POLY_PADZ - 8 && (tl + 64) * 8 <= 98304 && !env.poly_v2) {
           const int TBP = rs.TB + 2 * FMR_POLY_PADZ;
           std::vector<float> hp((size_t)rs.LB * TBP, 0.f);
           for (long long r = 0; r < rs.LB; r++)
@@ -396,8 +426,7 @@ int fmr_chain::init(const fmr_config *c) {
           HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly3<384, Q3>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
         }
-        const char *e4 = getenv("FMR_POLY_V3");
-        if (poly3 && rs.LB == 48 && rs.MB == 125 && rs.TB == 210 && !(e4 && e4[0] == '1')) {
+        if (poly3 && rs.LB == 48 && rs.MB == 125 && rs.TB == 210 && !env.poly_v3) {
           using SH = Poly4Shape<48, 125, 210>;
           std::vector<float> af((size_t)SH::MT * SH::NK * 64, 0.f);
           for (int mt = 0; mt < SH::MT; mt++)
@@ -412,11 +441,10 @@ int fmr_chain::init(const fmr_config *c) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
           // fused front end: the 10 MS/s shape (D = 10, NA = 151) with a symmetric stage-A filter; FM without IF FIR /
           // equaliser (the discriminator then reads the IF directly), cf32 input, no Fs/4 shift
-          const char *ef = getenv("FMR_NO_FUSED");
           bool sym = rs.D == 10 && rs.NA == 151;
           for (int k = 0; sym && k < rs.NA / 2; k++) sym = (fa[k] == fa[rs.NA - 1 - k]);
           if (sym && mode == FMR_MODE_FM && !c->fmfilter_enable && c->multipath_stages == 0 && in_fmt == 0 &&
-              !c->enable_fourth_down && !(ef && ef[0] == '1')) {
+              !c->enable_fourth_down && !env.no_fused) {
             for (int k = 0; k < FUSED_TAP_LEN; k++) fused_taps.h[k] = 0.f;
             for (int k = 0; k < rs.NA; k++) fused_taps.h[FUSED_TAP_PAD + k] = fa[k];
             if ((rc = upload(d_hB_last, fb.data() + (size_t)phi[47] * rs.TB, (size_t)rs.TB))) return rc;
@@ -450,16 +478,13 @@ int fmr_chain::init(const fmr_config *c) {
   H_if = has_dec ? (ntaps > 1 ? ntaps - 1 : 1) : 1;
   if ((rc = d_if.alloc((size_t)S * (H_if + max_if)))) return rc;
   last_if = d_if.p;
-  { const char *e = getenv("FMR_HOST_PROF"); host_prof = e && e[0] == '1'; }
-  { const char *e = getenv("FMR_DECIM_BL"); if (e && atoi(e) == 256) decim_bl = 256; }
-  { const char *e = getenv("FMR_DEBUG_TAPS"); debug_taps = e && e[0] == '1'; }
-  { const char *e = getenv("FMR_PLL_RTOL"); if (e && e[0]) pll_rtol = atof(e); }
-  { const char *e = getenv("FMR_PLL_JAC"); if (e && e[0] >= '1' && e[0] <= '9') pll_jac_rounds = e[0] - '0'; }
+  host_prof = env.host_prof; decim_bl = env.decim_bl; debug_taps = env.debug_taps;
+  if (env.pll_rtol >= 0.0) pll_rtol = env.pll_rtol;
+  if (env.pll_jac) pll_jac_rounds = env.pll_jac;
   {
     // Opt-in (FMR_PIPELINE=1): +5 % whole-job rate on config 2, but the front-end kernel then shares HBM
     // with the decoder's tail and its own launch takes 0.28 ms instead of 0.20 ms.
-    const char *e = getenv("FMR_PIPELINE");
-    pipelined = has_rs && has_dec && !fir_enable && e && e[0] == '1';
+    pipelined = has_rs && has_dec && !fir_enable && env.pipeline;
     if (pipelined) {
       // HIP multiplexes streams onto 4 hardware queues: a fifth stream would share one with the AGC stream and the
       // front end would queue behind 0.45 ms of AGC kernels.  The AGC moves onto `side` (after the statistics).
@@ -488,10 +513,8 @@ int fmr_chain::init(const fmr_config *c) {
   h_flags.assign(S, IterFlags{});
   if ((rc = d_flags.alloc((size_t)S))) return rc;
   {
-    const char *e = getenv("FMR_SERIAL");
-    serial_mode = (e && e[0] == '1');
-    const char *cp = getenv("FMR_C_PLL");
-    if (cp && atoi(cp) >= C_PLL_MIN) c_pll = atoi(cp);
+    serial_mode = env.serial;
+    if (env.c_pll >= C_PLL_MIN) c_pll = env.c_pll;
   }
   max_agc_nc = max_if / C_AGC + 2;
   if (has_dec) {
@@ -1116,7 +1139,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     hipStream_t as = agc_aside ? side2 : stream;
     // With the PLL on, the side-stream AGC starts only after the PLL's first (Jacobian) integration pass: that
     // pass runs one wave per SIMD and every co-resident AGC wave stretches it (measured 118 -> 160 us).
-    agc_deferred = agc_aside && stereo && !getenv("FMR_AGC_EARLY");
+    agc_deferred = agc_aside && stereo && !env.agc_early;
     enqueue_agc = [=]() -> int {
     if (agc_aside) {
       HIPCHK(hipEventRecord(ev_if, stream));
@@ -1150,7 +1173,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                              d_mpf_ok.p, d_state.p);
         };
         // v2: taps in registers (TPL per lane); v1 (taps in LDS) for FMR_MPF_V1=1
-        if (getenv("FMR_MPF_V1")) go(k_mpf);
+        if (env.mpf_v1) go(k_mpf);
         else if (mpf_N <= 64 * 5) go(k_mpf2<5>);
         else if (mpf_N <= 64 * 10) go(k_mpf2<10>);
         else go(k_mpf2<19>);
@@ -1263,7 +1286,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         });
     };
     const bool split_mono = stereo && !serial_mode && de_fused && (ars.LB == 3 && ars.MB == 8) &&
-                            n_pilotcut <= FMR_PCUT_MAXTAPS && !getenv("FMR_NO_SPLIT");
+                            n_pilotcut <= FMR_PCUT_MAXTAPS && !env.no_split;
     bool mono_enqueued = false;
     if (stereo) {
       if (serial_mode) {
@@ -1400,7 +1423,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          d_bb_rms_blk.p, d_state.p, S, 0);
     });
     timed("am_tail", [&] {
-      const bool par_tail = !serial_mode && !getenv("FMR_AM_SERIAL_TAIL");
+      const bool par_tail = !serial_mode && !env.am_serial_tail;
       if (par_tail) {
         // DC block -> AfSimpleAgc -> de-emphasis in time-parallel form (kernels_par.hpp); the serial kernel below only
         // runs for a stream whose Newton rounds did not converge

@@ -3,25 +3,25 @@
 // 384 kHz IF's second read) never goes through HBM.  Rows a1 + a7 (+ a3/a8 partial sums) of SURVEY.md 8a:
 // sfmbase/IfResampler.cpp:37-78, sfmbase/PhaseDiscriminator.cpp:33-46, sfmbase/FmDecode.cpp:95,141-150.
 //
-// Shape: source rates whose stage A lands on 1 MHz with D = 2 (mod 4) -- 10 MS/s (D = 10, NA = 151) and
-// 6 MS/s -- followed by the LB/MB = 48/125, TB = 210 polyphase stage (the k_ifr_poly4 shape).
+// Shape: the 10 MS/s class -- stage A D = 10, NA = 151 onto 1 MHz, followed by the LB/MB = 48/125, TB = 210
+// polyphase stage (the k_ifr_poly4 shape).
 //
-// One 512-lane workgroup per CU owns a CONTIGUOUS run of "macro tiles" (8 periods of stage B = 384 IF samples
-// = 1000 mid samples = 10 000 input samples) of one stream and walks it in EPOCHS of a quarter macro tile
-// (250 mid samples, 2 500 input samples, 20 KB).  Wave roles (one s_barrier per epoch, nothing else synchronises):
-//   wave 0      loader   : LDS-DMA (global_load_lds_dwordx4) of the input region of epoch e+4 into a 5-slot ring,
-//                          60-80 KB in flight per CU; it never reads LDS, so the compiler puts no wait in its
-//                          path and its loads stay in flight across the barriers (s_waitcnt vmcnt(63) by hand)
-//   waves 4..7  stage A  : one output per lane out of the natural-order slot: lane stride D / 2 = 5 sixteen-byte
-//                          words (odd => conflict-free ds_read_b128), two packed FMAs per word, the 76 distinct
-//                          taps of the symmetric filter live in VGPRs; results go to a 3-window `mid` ring in LDS
-//   waves 1, 2  stage B  : the 48 x 332 banded polyphase matrix as v_mfma_f32_16x16x4_f32 (rows = 16 positions,
-//                          columns = 8 periods x (re, im)); wave 1 holds row tiles 0-1, wave 2 row tile 2; the 83
-//                          k-steps of a macro tile are spread over the four epochs that follow its last input
-//   wave 3      epilogue : IF samples of the finished macro tile: atan2 / wrapped difference (the
+// One 768-lane workgroup per CU owns a CONTIGUOUS run of "macro tiles" (8 periods of stage B = 384 IF samples
+// = 1000 mid samples = 10 000 input samples) of one stream and walks it in EPOCHS of half a macro tile
+// (500 mid samples, 5 000 input samples, 40 KB).  Wave roles (one s_barrier per epoch, nothing else synchronises):
+//   wave 0       loader  : LDS-DMA (global_load_lds_dwordx4) of the input region of epoch e+2 into a 3-slot ring,
+//                          80 KB in flight per CU; it never reads LDS, so the compiler puts no wait in its path and
+//                          its loads stay in flight across the barriers (s_waitcnt vmcnt(40) by hand)
+//   waves 4..11  stage A : quad form (FusedQuad): four lanes share four consecutive outputs, a quarter of the tap
+//                          window each, out of the natural-order slot; results go to a 3-window `mid` ring in LDS
+//   waves 1..3   stage B : the 48 x 332 banded polyphase matrix as v_mfma_f32_16x16x4_f32 (rows = 16 positions,
+//                          columns = 8 periods x (re, im)), one row tile per wave, the 63 live k-steps of a macro tile
+//                          spread over the two epochs that follow its last input; then a third each of the
+//                          EPILOGUE: IF samples of the finished macro tile -> atan2 / wrapped difference (the
 //                          discriminator), float -> double widening, per-block partial sums, coalesced stores
-// Arithmetic: every stage-A output is two fp32 FMA chains (even / odd samples of the window) in tap order; stage B
-// is bit-identical to k_ifr_poly4 (an f32 MFMA is a k-ordered fmaf chain).
+// (FUSED_A_FORM selects two older stage-A layouts for tools/bench_fused.hip.)
+// Arithmetic: every stage-A output is fp32 FMAs in a fixed order (quarter of the window, word, even / odd sample, then
+// the quad's reduction tree); stage B is bit-identical to k_ifr_poly4 (an f32 MFMA is a k-ordered fmaf chain).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
