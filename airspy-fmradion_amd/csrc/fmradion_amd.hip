@@ -59,7 +59,10 @@ constexpr double kAudioAtten = 180.0;
 constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
 constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 512, K_AF_ITERS = 6;
-constexpr int C_PLL_MIN = 64;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
+#ifndef FMR_C_PLL_MIN
+#define FMR_C_PLL_MIN 64
+#endif
+constexpr int C_PLL_MIN = FMR_C_PLL_MIN;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
 constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 4;   // PLL: 2 rounds in lock, 2 spare (each unused round costs ~18 us of launches)
 
 template <class T>
