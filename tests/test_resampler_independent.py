@@ -81,9 +81,11 @@ def test_cascade_frequency_response(in_rate, out_rate, atten):
     proto = np.zeros(TB * LB)
     for p in range(LB):
         proto[p + (TB - 1 - np.arange(TB)) * LB] = hb[p]          # prototype at rate LB * mid, gain LB
-    f = np.linspace(0, in_rate / 2, 40001)
-    Ha = np.abs(np.exp(-2j * np.pi * np.outer(f / in_rate, np.arange(len(ha)))) @ ha) if D > 1 else np.ones_like(f)
-    Hb = np.abs(np.exp(-2j * np.pi * np.outer(f / (LB * mid), np.arange(len(proto)))) @ proto) / LB
+    # both responses on ONE grid of step mid / 65536 by FFT: stage A at in_rate = D mid, the prototype at LB mid
+    nb = 65536
+    f = np.arange(D * nb // 2 + 1) * (mid / nb)
+    Ha = np.abs(np.fft.fft(ha, D * nb))[:len(f)] if D > 1 else np.ones_like(f)
+    Hb = np.abs(np.fft.fft(proto, LB * nb))[np.arange(len(f)) % (LB * nb)] / LB
     H = Ha * Hb
     pb = f <= fpass
     assert np.max(np.abs(20 * np.log10(H[pb]))) < 1e-3                       # ripple < 0.001 dB
