@@ -95,10 +95,11 @@ struct EnvKnobs {
   bool poly_v1 = false, poly_v2 = false, poly_v3 = false;   // FMR_POLY_V1/V2/V3=1  older stage-B kernels
   bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end
   bool agc_early = false;       // FMR_AGC_EARLY      side-stream AGC before the PLL's first pass
-  bool mpf_v1 = false;          // FMR_MPF_V1         round-1 equaliser kernel
+  bool mpf_v1 = false, mpf_v2 = false;   // FMR_MPF_V1 / V2   round-1 / one-wave equaliser kernels
   bool no_split = false;        // FMR_NO_SPLIT       mono and L-R audio tails on one stream
   bool am_serial_tail = false;  // FMR_AM_SERIAL_TAIL serial AM audio tail
   int decim_bl = 128;           // FMR_DECIM_BL=256   wider stage-A workgroups
+  int mpf_nw = 4;               // FMR_MPF_NW=1|2|4   waves per stream in the equaliser kernel
   int c_pll = 0;                // FMR_C_PLL          PLL chunk length (0 = default)
   int pll_jac = 0;              // FMR_PLL_JAC        rounds that re-integrate the sensitivities (0 = default)
   double pll_rtol = -1.0;       // FMR_PLL_RTOL       PLL acceptance threshold (< 0 = default)
@@ -108,10 +109,11 @@ struct EnvKnobs {
     serial = on("FMR_SERIAL"); pipeline = on("FMR_PIPELINE"); debug_taps = on("FMR_DEBUG_TAPS");
     host_prof = on("FMR_HOST_PROF"); decim_v1 = on("FMR_DECIM_V1"); poly_v1 = on("FMR_POLY_V1");
     poly_v2 = on("FMR_POLY_V2"); poly_v3 = on("FMR_POLY_V3"); no_fused = on("FMR_NO_FUSED");
-    agc_early = set("FMR_AGC_EARLY"); mpf_v1 = set("FMR_MPF_V1"); no_split = set("FMR_NO_SPLIT");
+    agc_early = set("FMR_AGC_EARLY"); mpf_v1 = set("FMR_MPF_V1"); mpf_v2 = set("FMR_MPF_V2"); no_split = set("FMR_NO_SPLIT");
     am_serial_tail = set("FMR_AM_SERIAL_TAIL");
     if (const char *e = getenv("FMR_DECIM_BL")) if (atoi(e) == 256) decim_bl = 256;
     if (const char *e = getenv("FMR_C_PLL")) c_pll = atoi(e);
+    if (const char *e = getenv("FMR_MPF_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) mpf_nw = v; }
     if (const char *e = getenv("FMR_PLL_JAC")) if (e[0] >= '1' && e[0] <= '9') pll_jac = e[0] - '0';
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
   }
@@ -1169,17 +1171,34 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   if (mode == FMR_MODE_FM) {
     if (any_mpf) {
       const size_t lds = sizeof(float2) * ((size_t)2 * mpf_N + FMR_MPF_CH + 4);
+      const size_t lds3 = sizeof(float2) * ((size_t)mpf_N + FMR_MPF_CH + 8) + sizeof(float) * (FMR_MPF_CH / 4 + 2) +
+                          sizeof(float2) * (2 * 4 * 4 + FMR_MPF_CH);
       timed("mpf", [&] {
-        auto go = [&](auto kern) {
-          hipLaunchKernelGGL(kern, dim3(S), dim3(64), lds, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
+        auto go = [&](auto kern, int threads, size_t bytes) {
+          hipLaunchKernelGGL(kern, dim3(S), dim3(threads), bytes, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
                              bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
                              d_mpf_ok.p, d_state.p);
         };
-        // v2: taps in registers (TPL per lane); v1 (taps in LDS) for FMR_MPF_V1=1
-        if (env.mpf_v1) go(k_mpf);
-        else if (mpf_N <= 64 * 5) go(k_mpf2<5>);
-        else if (mpf_N <= 64 * 10) go(k_mpf2<10>);
-        else go(k_mpf2<19>);
+        // v3: four waves per stream (kernels.hpp); v2 (one wave, taps in registers) for FMR_MPF_V2=1, v1 for FMR_MPF_V1=1
+        if (env.mpf_v1) go(k_mpf, 64, lds);
+        else if (env.mpf_v2) {
+          if (mpf_N <= 64 * 5) go(k_mpf2<5>, 64, lds);
+          else if (mpf_N <= 64 * 10) go(k_mpf2<10>, 64, lds);
+          else go(k_mpf2<19>, 64, lds);
+        } else {
+          // FMR_MPF_NW = 1, 2, 4 waves per stream (4: product)
+          const int nw = env.mpf_nw;
+          auto pick = [&](auto nwc) {
+            constexpr int NWc = decltype(nwc)::value;
+            if (mpf_N <= 16 * NWc * (80 / NWc)) go(k_mpf3<NWc, 80 / NWc>, 64 * NWc, lds3);        // N <= 1280
+            else set_err("equaliser length out of range");
+          };
+          if (mpf_N <= 64 * 5 && nw == 4) go(k_mpf3<4, 5>, 256, lds3);
+          else if (mpf_N <= 64 * 5 && nw == 2) go(k_mpf3<2, 10>, 128, lds3);
+          else if (mpf_N <= 64 * 5 && nw == 1) go(k_mpf3<1, 20>, 64, lds3);
+          else if (mpf_N <= 64 * 10) go(k_mpf3<4, 10>, 256, lds3);
+          else pick(std::integral_constant<int, 4>{});
+        }
       });
     }
     const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers

@@ -1240,6 +1240,196 @@ __global__ __launch_bounds__(64) void k_mpf2(
 }
 
 // ---------------------------------------------------------------------------
+// K_mpf v3: FOUR waves per stream.  The recurrence is a chain of ~N_if / 4 dependent steps (dot products -> error ->
+// coefficient update), and one wave issues an instruction only every 5-8 cycles when each waits for the one before:
+// what a step costs is its instruction count on the slowest wave.  So the step is spread over 16 rows of 16 lanes:
+//   * wave w owns taps 16 w + 64 j + (lane & 15); its row r = lane >> 4 computes the dot product of output r of the
+//     group (the four outputs behind an update share their coefficients, MultipathFilter.cpp:176,186) over the wave's
+//     taps -- every coefficient is held (and updated identically) by the four rows of its wave;
+//   * a row's sum is four DPP steps on one complex value; the four waves meet through 32 floats of LDS and ONE barrier
+//     per group (double buffered);
+//   * mu = 0.1 / (|state|^2 + 1e-10) (:130) depends on the input alone: all update positions of a chunk are evaluated
+//     in parallel before the chain starts, which takes the window energy reduction and an fp64 division out of it.
+// Complex multiply-accumulates are two v_pk_fma_f32 with op_sel / neg_lo (same rounding as the four fmaf of k_mpf2).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void mpf_cmac(float __attribute__((ext_vector_type(2))) &acc, float2 sv, float2 cv) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f s = {sv.x, sv.y}, c = {cv.x, cv.y};
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(s), "v"(c));                                    // += s.x * (c.x, c.y)
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(acc) : "v"(s), "v"(c));      // += s.y * (-c.y, c.x)
+}
+__device__ __forceinline__ float row_sum_dpp(float v) {        // every lane of a 16-lane row gets the row's sum
+  auto dpp_add = [](float x, auto ctrl) {
+    constexpr int C = decltype(ctrl)::value;
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), C, 0xF, 0xF, true));
+  };
+  v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  return v;
+}
+
+template <int NW, int TPLR>
+__global__ __launch_bounds__(64 * NW) void k_mpf3(
+    const float2 *__restrict__ xin, long long x_stride, int x_off,
+    const float *__restrict__ gain, long long g_stride, BlockTab bt,
+    float2 *__restrict__ out, long long out_stride, float2 *__restrict__ coeff_g,
+    float2 *__restrict__ state_g, int N, int ref, int *__restrict__ mpf_ok, StreamState *st) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int NT = 64 * NW, SL = 16 * NW;      // SL: taps per slice j (one per row lane of every wave)
+  extern __shared__ float2 lds_m[];
+  float2 *xw = lds_m;                                                     // [N + CH + 8]
+  float *smu = reinterpret_cast<float *>(xw + N + FMR_MPF_CH + 8);        // [CH / 4 + 2]
+  float2 *exch = reinterpret_cast<float2 *>(smu + FMR_MPF_CH / 4 + 2);    // [2][NW][4]
+  float2 *yo = exch + 2 * NW * 4;                                         // [CH] outputs of the chunk
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = lane >> 4, r16 = lane & 15;
+  const float2 *xs = xin + (long long)s * x_stride + x_off;
+  const float *gs = gain + (long long)s * g_stride;
+  float2 *os = out + (long long)s * out_stride;
+  float2 *cg = coeff_g + (long long)s * N;
+  float2 *sg = state_g + (long long)s * N;
+  float2 c[TPLR];
+#pragma unroll
+  for (int j = 0; j < TPLR; j++) { const int i = SL * j + 16 * w + r16; c[j] = (i < N) ? cg[i] : make_float2(0.f, 0.f); }
+  int ic[TPLR];                 // tap index, clamped for the lanes past the last tap (their coefficient stays zero)
+  bool valid[TPLR], isref[TPLR];
+#pragma unroll
+  for (int j = 0; j < TPLR; j++) { const int i = SL * j + 16 * w + r16; valid[j] = i < N; isref[j] = i == ref; ic[j] = min(i, N - 1); }
+  double err_last = st[s].mpf_error;
+  unsigned resets = st[s].mpf_resets;
+  int buf = 0;
+  for (int b = 0; b < bt.nb; b++) {
+    const int n = bt.if_len[b];
+    int ok = 1;
+    if (n == 0 || !bt.mpf_active[b]) {
+      if (tid == 0) mpf_ok[(long long)s * bt.nb + b] = 0;
+      continue;
+    }
+    const int off = bt.if_off[b];
+    for (int i = tid; i < N; i += NT) xw[i] = sg[i];
+    __syncthreads();
+    for (int c0 = 0; c0 < n && ok; c0 += FMR_MPF_CH) {
+      const int cn = min(FMR_MPF_CH, n - c0);
+      for (int i = tid; i < cn; i += NT) {
+        const float2 v = xs[off + c0 + i];
+        const float g = gs[off + c0 + i];
+        xw[N + i] = make_float2(v.x * g, v.y * g);
+      }
+      if (tid < 8) xw[N + cn + tid] = make_float2(0.f, 0.f);      // slack read by the last (partial) group
+      __syncthreads();
+      // mu of every update position of the chunk: q = q0 + 4 u, window xw[q + 1 .. q + N]
+      const int q0 = (4 - (c0 & 3)) & 3;
+      const int nu = (q0 < cn) ? (cn - q0 + 3) / 4 : 0;
+      for (int u = tid; u < nu; u += NT) {
+        const float2 *wv = xw + q0 + 4 * u + 1;
+        double e = 0.0;
+        for (int i = 0; i < N; i++) { const float2 v = wv[i]; e += (double)(v.x * v.x + v.y * v.y); }
+        smu[u] = (float)(0.1 / ((double)(float)e + 1e-10));        // :130
+      }
+      __syncthreads();
+      int pushed = 0, stored = 0, q = 0;
+      // group = the outputs up to and including the next update sample (block index = 0 mod 4)
+      auto group_len = [&](int qq) { const int jg = c0 + qq; return min(((jg + 3) & ~3) - jg + 1, cn - qq); };
+      while (q < cn) {
+        const int glen = group_len(q);
+        const int qlast = q + glen - 1;
+        // state after the push of sample q+t = xw[q+t+1 .. q+t+N]; y = sum state[i]*coeff[i] (V9); this row: t = row.
+        // All LDS reads first (lanes past the last tap read a clamped address against a zero coefficient), then the
+        // multiply-accumulates on two chains: no branch and one wait inside the step.
+        float2 sv[TPLR], sl[TPLR];                              // sl: state values of the group's LAST output (update operand)
+#pragma unroll
+        for (int j = 0; j < TPLR; j++) { sv[j] = xw[q + 1 + row + ic[j]]; sl[j] = xw[qlast + 1 + ic[j]]; }
+        v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TPLR; j++) mpf_cmac((j & 1) ? acc1 : acc0, sv[j], c[j]);
+        const v2f acc = acc0 + acc1;
+        const float ax = row_sum_dpp(acc.x), ay = row_sum_dpp(acc.y);
+        float2 y[4];
+        if (NW == 1) {                                          // one wave: the four row sums travel through SGPRs
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            y[t] = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), 16 * t)),
+                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), 16 * t)));
+        } else {
+          if (r16 == 0) exch[(buf * NW + w) * 4 + row] = make_float2(ax, ay);
+          __syncthreads();
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            float2 p = exch[(buf * NW + 0) * 4 + t];
+#pragma unroll
+            for (int ww = 1; ww < NW; ww++) { const float2 e = exch[(buf * NW + ww) * 4 + t]; p.x += e.x; p.y += e.y; }
+            y[t] = p;
+          }
+          buf ^= 1;
+        }
+        bool fin = true;
+#pragma unroll
+        for (int t = 0; t < 4; t++) fin = fin && (t >= glen || (isfinite(y[t].x) && isfinite(y[t].y)));
+        if (!fin) {                                             // :182-184: stop at the first non-finite output
+          int bad = 3;
+#pragma unroll
+          for (int t = 3; t >= 0; t--)
+            if (t < glen && (!isfinite(y[t].x) || !isfinite(y[t].y))) bad = t;
+          pushed = q + bad + 1; ok = 0; break;
+        }
+        pushed = q + glen;
+        {                                                       // outputs leave through LDS, one coalesced copy per chunk:
+          const float2 yv = tid == 0 ? y[0] : tid == 1 ? y[1] : tid == 2 ? y[2] : y[3];   // a global store per step would
+          if (tid < glen) yo[q + tid] = yv;                     // put its round trip (vmcnt) into the chain
+          stored = q + glen;
+        }
+        if ((((c0 + qlast) & 3) == 0)) {                        // :176,186
+          const float2 yl = glen == 1 ? y[0] : glen == 2 ? y[1] : glen == 3 ? y[2] : y[3];
+          const double env = (double)(yl.x * yl.x + yl.y * yl.y);
+          const double error = 1.0 - env;
+          const float mu = smu[(qlast - q0) >> 2];
+          const float factor = (float)(error * (double)mu);         // :133
+          const float fr = factor * yl.x, fi = factor * yl.y;
+#pragma unroll
+          for (int j = 0; j < TPLR; j++) {                            // V10: a tap is only ever touched by its owners
+            float2 cv = c[j];
+            cv.x += sl[j].x * fr + sl[j].y * fi;
+            cv.y += sl[j].x * fi - sl[j].y * fr;
+            if (isref[j]) cv = make_float2(1.f, 0.f);                // :158
+            c[j] = valid[j] ? cv : c[j];
+          }
+          err_last = error;
+          if (!isfinite(error)) { ok = 0; break; }                   // :190-192
+        }
+        q += glen;
+      }
+      // new state = last N entries pushed so far
+      __syncthreads();
+      for (int i = tid; i < stored; i += NT) os[off + c0 + i] = yo[i];
+      constexpr int TPS = (SL * TPLR + NT - 1) / NT;
+      float2 tmp[TPS];
+#pragma unroll
+      for (int j = 0; j < TPS; j++) { const int i = tid + NT * j; tmp[j] = (i < N) ? xw[pushed + i] : make_float2(0.f, 0.f); }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TPS; j++) { const int i = tid + NT * j; if (i < N) xw[i] = tmp[j]; }
+      __syncthreads();
+    }
+    for (int i = tid; i < N; i += NT) sg[i] = xw[i];
+    if (!ok) {
+      // FmDecode.cpp:117-123: re-initialise the taps, block falls back to the AGC output
+#pragma unroll
+      for (int j = 0; j < TPLR; j++) { const int i = SL * j + 16 * w + r16; c[j] = make_float2(i == ref ? 1.f : 0.f, 0.f); }
+      resets++;
+    }
+    if (tid == 0) mpf_ok[(long long)s * bt.nb + b] = ok;
+    __syncthreads();
+  }
+  if (row == 0) {
+#pragma unroll
+    for (int j = 0; j < TPLR; j++) { const int i = SL * j + 16 * w + r16; if (i < N) cg[i] = c[j]; }
+  }
+  if (tid == 0) { st[s].mpf_error = err_last; st[s].mpf_resets = resets; }
+}
+
+// ---------------------------------------------------------------------------
 // K_disc : PhaseDiscriminator (PhaseDiscriminator.cpp:33-46) per decoder block,
 // fused with the float->double widening (FmDecode.cpp:143) and the block
 // mean / rms of the MPX signal (Utility.h:135-152).
