@@ -231,3 +231,34 @@ def test_if_phase_discontinuity(pilotcut):
     assert err < 1e-5
     assert ch.status().stereo_detected == int(fm.stereo_detected()) == 1
     ch.close()
+
+
+def test_carrier_dropout_and_nan_samples(pilotcut):
+    """The source delivers 8000 zero samples (carrier off: atan2(0, 0), AGC running up) and, later, three NaN samples
+    (a corrupted buffer).  NaN spreads over the resampler's windows, the discriminator zeroes the affected differences
+    (Utility.h:336-343), the AGC resets (IfSimpleAgc.cpp:49-50); nothing downstream may see a NaN.
+    Through the dropout the chain must follow the oracle to the usual tolerance.  Around the NaN samples the two differ
+    in HOW MANY IF samples turn NaN -- the kernels multiply NaN by the structural zeros of their padded tap tables and
+    banded MFMA tiles (96 instead of 86 IF samples here; the reference's own FFT resampler would spread it over a whole
+    FFT block) -- i.e. by a few more zeroed MPX samples: a click of the order of 1e-3 that dies with the DC block's
+    47 ms time constant.  Asserted: identical before the event, bounded during it, identical again 0.35 s later."""
+    blk, nblk, batch = 65536, 160, 40
+    x = siggen.fm_stereo_iq(nblk * blk, 10e6).copy()
+    k0 = 50 * blk + 777
+    x[k0:k0 + 8000] = 0
+    k1 = 85 * blk + 4321
+    x[k1:k1 + 3] = np.complex64(complex(np.nan, np.nan))
+    ch, fm, got, ref, hist = _run_pair(x, blk, batch, pilotcut)
+    assert len(got) == len(ref)
+    assert not np.isnan(got).any() and not np.isnan(ref).any()
+    a0 = 2 * int((k1 / 10e6 - 0.002) * 48000)          # interleaved stereo samples before the event
+    a1 = 2 * int((k1 / 10e6 + 0.35) * 48000)
+    assert a1 + 10000 < len(got)
+    err_before, err_during, err_after = rms((got - ref)[:a0]), float(np.max(np.abs((got - ref)[a0:a1]))), rms((got - ref)[a1:])
+    _report("carrier_dropout_and_nan", audio_rms_err_before=err_before, audio_max_err_during=err_during,
+            audio_rms_err_after=err_after, calls=hist)
+    assert err_before < 1e-5                           # cold start, lock and the carrier dropout included
+    assert err_during < 0.5
+    assert err_after < 1e-5
+    assert ch.status().stereo_detected == int(fm.stereo_detected()) == 1
+    ch.close()
