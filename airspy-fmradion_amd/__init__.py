@@ -22,7 +22,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 MODE_NONE, MODE_FM, MODE_NBFM, MODE_AM, MODE_DSB, MODE_USB, MODE_LSB, MODE_CW, MODE_WSPR = -1, 0, 1, 2, 3, 4, 5, 6, 7
 IQ_CF32, IQ_S16, IQ_U8, IQ_S8 = 0, 1, 2, 3
 _IQ_DTYPE = {0: np.complex64, 1: np.int16, 2: np.uint8, 3: np.int8}
-OK = 0
+OK, ERR_NO_DEVICE, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP = 0, -1, -2, -3, -4, -5
 
 EXPORTS = [
     "fmr_create", "fmr_destroy", "fmr_last_error", "fmr_version", "fmr_resampler_info", "fmr_process",
