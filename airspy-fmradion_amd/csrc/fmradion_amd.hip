@@ -63,6 +63,7 @@ constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 512, K_A
 #define FMR_C_PLL_MIN 64
 #endif
 constexpr int C_PLL_MIN = FMR_C_PLL_MIN;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
+constexpr long long kSmallCall = 8192;   // IF samples: calls up to this size enqueue fewer spare Newton rounds
 constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 4;   // PLL: 2 rounds in lock, 2 spare (each unused round costs ~18 us of launches)
 
 template <class T>
@@ -1141,6 +1142,9 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     // -- still solved exactly as before, its state carries -- runs on the side stream, off the
     // critical path (the two paths differ by 3.8e-8 RMS of float rounding).
     const bool agc_aside = (mode == FMR_MODE_FM);
+    // a short call (one or two source blocks) is launch-bound on the host: one spare round instead of two to four; if
+    // that is not enough the serial kernel runs over these few thousand samples (milliseconds)
+    const int agc_iters = (agc_aside && N_if <= kSmallCall) ? 3 : K_AGC_ITERS;
     hipStream_t as = agc_aside ? side2 : stream;
     // With the PLL on, the side-stream AGC starts only after the PLL's first (Jacobian) integration pass: that
     // pass runs one wave per SIMD and every co-resident AGC wave stretches it (measured 118 -> 160 us).
@@ -1152,7 +1156,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     }
     const int agc_nw = std::max(1, std::min(16, (agc_nc + 64 * FMR_AGC_PER_LANE - 1) / (64 * FMR_AGC_PER_LANE)));
     timed_on(as, "if_agc", [&] {
-      for (int it = 0; it < K_AGC_ITERS; it++) {
+      for (int it = 0; it < agc_iters; it++) {
         hipLaunchKernelGGL(k_agc_shoot<C_AGC>, dim3((agc_nc + 63) / 64, S), dim3(64), 0, as, xin, x_stride, x_off,
                            (int)N_if, d_gain.p, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            agc_init, agc_max, agc_rate, d_flags.p);
@@ -1321,7 +1325,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         timed("pll", [&] {
           const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
           const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
-          for (int it = 0; it < K_PLL_ITERS; it++) {
+          const int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
+          for (int it = 0; it < pll_iters; it++) {
             // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
             // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
             if (it < pll_jac_rounds)
@@ -1345,7 +1350,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
             if (it == 0 && agc_deferred) { agc_deferred = false; if (enqueue_agc()) return; }
             hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
                                (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
-            if (it == K_PLL_ITERS - 1) break;      // nothing integrates the nodes a last update would give
+            if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
             hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                                nck, d_pll_PQ.p, d_flags.p);
             hipLaunchKernelGGL(k_pll_nodes_a2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_PQ2.p,
