@@ -28,7 +28,8 @@ EXPORTS = [
     "fmr_create", "fmr_destroy", "fmr_last_error", "fmr_version", "fmr_resampler_info", "fmr_process",
     "fmr_process_blocks", "fmr_process_blocks_device", "fmr_synchronize", "fmr_resample", "fmr_get_status",
     "fmr_get_pps_events", "fmr_get_multipath_coefficients", "fmr_debug_read", "fmr_get_kernel_times",
-    "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert", "fmr_design_taps",
+    "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert", "fmr_design_taps", "fmr_host_alloc",
+    "fmr_host_free",
 ]
 
 

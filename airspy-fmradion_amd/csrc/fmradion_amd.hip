@@ -1536,6 +1536,19 @@ long long fmr_design_taps(double in_rate, double out_rate, double atten_db, int 
   return (long long)h.size();
 }
 
+void *fmr_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_err("no HIP device"); return nullptr; }
+  const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+  if (e != hipSuccess) { set_err("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+  return p;
+}
+
+void fmr_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int fmr_synchronize(fmr_chain *c) {
   if (!c) return FMR_ERR_BAD_ARG;
   HIPCHK(hipStreamSynchronize(c->stream));

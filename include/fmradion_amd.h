@@ -137,6 +137,16 @@ long long fmr_resampler_info(const fmr_chain *c, int which);
 long long fmr_design_taps(double in_rate, double out_rate, double atten_db, int stage, double *taps, long long cap,
                           long long *info);
 
+/* --- live sources: page-locked host memory for the ring between a driver's callback thread and the decoder thread.
+ * Replaces the heap vectors that AirspySource::callback (sfmbase/AirspySource.cpp:488-500) and RtlSdrSource::get_samples
+ * (sfmbase/RtlSdrSource.cpp:359-365) fill and DataBuffer (include/DataBuffer.h:35-90) queues: the callback copies the
+ * driver's RAW buffer (float pairs, or offset-binary bytes -- fmr_config.input_format converts on the GPU) into a block
+ * of the ring, and fmr_process_blocks reads the block in place -- from page-locked memory the host-to-device copy is a
+ * DMA at the link rate, without the runtime's pageable staging.  host/fmradion_ring.hpp holds the ring itself.
+ * Returns NULL (fmr_last_error() says why) without a HIP device: there is no fallback to pageable memory. */
+void *fmr_host_alloc(size_t bytes);
+void fmr_host_free(void *p);
+
 /* --- single block, host buffers: the shape of FmDecoder::process(IQSampleVector,
  * SampleVector&) (FmDecode.h:74) for stream 0 of a 1-stream chain.
  * iq: n interleaved complex float samples.  audio: doubles (interleaved L/R when
