@@ -99,6 +99,7 @@ struct EnvKnobs {
   bool mpf_v1 = false, mpf_v2 = false;   // FMR_MPF_V1 / V2   round-1 / one-wave equaliser kernels
   bool no_split = false;        // FMR_NO_SPLIT       mono and L-R audio tails on one stream
   bool am_serial_tail = false;  // FMR_AM_SERIAL_TAIL serial AM audio tail
+  bool fmblock_v1 = false;      // FMR_FMBLOCK_V1     IF filter out of global memory (round-1 kernel)
   int decim_bl = 128;           // FMR_DECIM_BL=256   wider stage-A workgroups
   int mpf_nw = 4;               // FMR_MPF_NW=1|2|4   waves per stream in the equaliser kernel
   int c_pll = 0;                // FMR_C_PLL          PLL chunk length (0 = default)
@@ -111,7 +112,7 @@ struct EnvKnobs {
     host_prof = on("FMR_HOST_PROF"); decim_v1 = on("FMR_DECIM_V1"); poly_v1 = on("FMR_POLY_V1");
     poly_v2 = on("FMR_POLY_V2"); poly_v3 = on("FMR_POLY_V3"); no_fused = on("FMR_NO_FUSED");
     agc_early = set("FMR_AGC_EARLY"); mpf_v1 = set("FMR_MPF_V1"); mpf_v2 = set("FMR_MPF_V2"); no_split = set("FMR_NO_SPLIT");
-    am_serial_tail = set("FMR_AM_SERIAL_TAIL");
+    am_serial_tail = set("FMR_AM_SERIAL_TAIL"); fmblock_v1 = set("FMR_FMBLOCK_V1");
     if (const char *e = getenv("FMR_DECIM_BL")) if (atoi(e) == 256) decim_bl = 256;
     if (const char *e = getenv("FMR_C_PLL")) c_pll = atoi(e);
     if (const char *e = getenv("FMR_MPF_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) mpf_nw = v; }
@@ -1106,6 +1107,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   const bool rms_in_disc = (mode == FMR_MODE_FM) && !fir_enable && !serial_mode;
   if (!rms_in_disc) {
     timed("fm_block", [&] {
+      constexpr int TL = 1024;
+      const size_t lds_fb = sizeof(float2) * ((size_t)(ntaps - 1) + TL) + sizeof(float) * (size_t)ntaps;
+      if (fir_enable && ntaps >= 2 && lds_fb <= 60000 && !env.fmblock_v1)
+        hipLaunchKernelGGL((k_fm_block2<256, TL>), dim3(nb, S), dim3(256), lds_fb, stream, ifbuf, if_stride, H_if, bt,
+                           d_coeff.p, ntaps, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if, d_if_rms_blk.p);
+      else
       hipLaunchKernelGGL(k_fm_block<256>, dim3(nb, S), dim3(256), 0, stream, ifbuf, if_stride, H_if, bt, d_coeff.p,
                          ntaps, (int)fir_enable, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if,
                          d_if_rms_blk.p);

@@ -873,6 +873,72 @@ __global__ __launch_bounds__(BLOCK) void k_fm_block(
   if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);
 }
 
+// K_blk v2: the same arithmetic (identical operation order, bit-identical results) out of LDS.  The block is walked in
+// tiles of TL outputs; a tile's window (order history samples + TL) and the coefficients are staged once, so a tap costs
+// two LDS reads instead of two cached global loads -- the AM / SSB filters have 255 / 2049 taps, and with the 48 kHz
+// modes' short blocks almost every output takes the sequential block-head path (hazard H1).
+template <int BLOCK, int TL>
+__global__ __launch_bounds__(BLOCK) void k_fm_block2(
+    const float2 *__restrict__ ifb, long long if_stride, int if_halo, BlockTab bt,
+    const float *__restrict__ coeff, int ntaps, int rms_after_fir,
+    float2 *__restrict__ firb, long long fir_stride, float *__restrict__ if_rms_blk) {
+  extern __shared__ float2 lds_fb[];
+  __shared__ float scratch[BLOCK / 64];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int n = bt.if_len[b];
+  if (n == 0) return;
+  const int order = ntaps - 1;
+  const int half_order = (order - 1) / 2;
+  float2 *xs = lds_fb;                                              // [order + TL]: xs[order + t] = x[i0 + t]
+  float *cs = reinterpret_cast<float *>(lds_fb + order + TL);       // [ntaps]
+  const float2 *x = ifb + (long long)s * if_stride + if_halo + bt.if_off[b];
+  float2 *y = firb + (long long)s * fir_stride + bt.if_off[b];
+  for (int k = threadIdx.x; k < ntaps; k += BLOCK) cs[k] = coeff[k];
+  float acc = 0.f;
+  for (int i0 = 0; i0 < n; i0 += TL) {
+    const int tn = min(TL, n - i0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < order + tn; k += BLOCK) xs[k] = x[i0 - order + k];    // (reaches into the prefix halo)
+    __syncthreads();
+    for (int t = threadIdx.x; t < tn; t += BLOCK) {
+      const int i = i0 + t;
+      const float2 *xl = xs + order + t;                            // xl[-j] = x[i - j]
+      float yr = 0.f, yi = 0.f;
+      if (i < order) {
+        // head: lags 1..order, state part first then in-block part (Filter.cpp:59-68)
+        for (int j = i + 1; j <= order; j++) {
+          const float2 tt = xl[-j];
+          const float c = cs[j];
+          yr += tt.x * c; yi += tt.y * c;
+        }
+        for (int j = 1; j <= i; j++) {
+          const float2 tt = xl[-j];
+          const float c = cs[j];
+          yr += tt.x * c; yi += tt.y * c;
+        }
+      } else {
+        // body: folded symmetric form incl. lag 0 (Filter.cpp:73-82)
+        for (int k = 0; k <= half_order; k++) {
+          const float2 a = xl[-k], bb = xl[-(order - k)];
+          const float c = cs[k];
+          yr += (a.x + bb.x) * c; yi += (a.y + bb.y) * c;
+        }
+        if ((order % 2) == 0) {
+          const float2 tt = xl[-(order / 2)];
+          const float c = cs[order / 2];
+          yr += tt.x * c; yi += tt.y * c;
+        }
+      }
+      const float2 o = make_float2(yr, yi);
+      y[i] = o;
+      const float2 v = rms_after_fir ? o : xl[0];
+      acc += v.x * v.x + v.y * v.y;
+    }
+  }
+  const float tot = block_sum<BLOCK>(acc, scratch);
+  if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);
+}
+
 // ---------------------------------------------------------------------------
 // K_finetune : FineTuner::process (FineTuner.cpp:55-73), the table-driven mixer of the SSB / CW / WSPR modes
 // (AmDecode.cpp:107-136), in place, one workgroup per block.  idx0 = table index of the call's first sample
