@@ -6,6 +6,7 @@
 #include <cstdio>
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <int MODE>
@@ -52,6 +53,20 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, unsigned long lo
       }
     for (int i = 0; i < 4; i++) r += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
   }
+  else if (MODE == 4 || MODE == 5) {
+    v4f acc[4];
+    for (int i = 0; i < 4; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    h8 a, b;
+    for (int e = 0; e < 8; e++) { a[e] = (_Float16)(threadIdx.x * 1e-3f + e); b[e] = (_Float16)1.f; }
+    asm volatile("" : "+v"(a), "+v"(b));
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+      for (int u = 0; u < 9; u++) {
+        const int c = (MODE == 5) ? (u % 3) : 0;
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[c], 0, 0, 0);
+      }
+    for (int i = 0; i < 4; i++) r += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+  }
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
@@ -59,13 +74,16 @@ int main() {
   float *out; unsigned long long *cyc;
   CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&cyc, 8));
   const int iters = 2000;
-  const char *names[4] = {"other wave of the SIMD idle", "other wave: v_pk_fma_f32 too", "other wave: f32 MFMA, one dependent chain", "other wave: f32 MFMA, four independent chains"};
-  for (int m = 0; m < 4; m++) {
+  const char *names[6] = {"other wave of the SIMD idle", "other wave: v_pk_fma_f32 too", "other wave: f32 MFMA, one dependent chain", "other wave: f32 MFMA, four independent chains",
+                          "other wave: 9 x mfma_f32_16x16x32_f16, one chain", "other wave: 9 x mfma_f32_16x16x32_f16, three chains"};
+  for (int m = 0; m < 6; m++) {
     for (int rep = 0; rep < 2; rep++) {
       if (m == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
       if (m == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
       if (m == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
       if (m == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
+      if (m == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
+      if (m == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
       CK(hipDeviceSynchronize());
     }
     unsigned long long c;
