@@ -1503,7 +1503,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
 extern "C" {
 
 const char *fmr_last_error(void) { return g_err.c_str(); }
-const char *fmr_version(void) { return "fmradion_amd 0.1 (gfx950)"; }
+const char *fmr_version(void) { return "fmradion_amd 0.2 (gfx950)"; }
 
 int fmr_create(const fmr_config *cfg, fmr_chain **out) {
   if (!cfg || !out) return FMR_ERR_BAD_ARG;
