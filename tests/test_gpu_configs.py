@@ -262,3 +262,43 @@ def test_carrier_dropout_and_nan_samples(pilotcut):
     assert err_after < 1e-5
     assert ch.status().stereo_detected == int(fm.stereo_detected()) == 1
     ch.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fused_and_three_kernel_front_ends_agree_on_random_partitions(seed, monkeypatch):
+    """Property test without the oracle (cheap, so it can roam): the same two 10 MS/s streams, cut into random blocks
+    (1 .. 65536 samples) and random calls (1 .. 40 blocks, so short calls that take the three-kernel path alternate
+    with long ones on the fused kernel), through a default chain and through one built with FMR_NO_FUSED=1.  The two
+    front ends round differently (fp32), nothing else may differ: audio within 1e-6 RMS, identical block lengths,
+    lock decisions and PPS events."""
+    rng = np.random.default_rng(seed)
+    lens = []
+    while sum(lens) < 6_500_000:
+        lens.append(int(rng.integers(1, 65537)) if rng.random() < 0.5 else 65536)
+    n = sum(lens)
+    xs = np.stack([siggen.fm_stereo_iq(n, 10e6, stream_id=s) for s in range(2)])
+    calls, i = [], 0
+    while i < len(lens):
+        k = int(rng.integers(1, 41))
+        calls.append(lens[i:i + k]); i += k
+
+    def run():
+        ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, n_streams=2,
+                       max_block_len=65536, max_blocks=40)
+        out, alens, locks, pps, pos = [[], []], [], [], [], 0
+        for ll in calls:
+            m = sum(ll)
+            a, alen = ch.process_blocks(xs[:, pos:pos + m], ll)
+            out[0].append(a[0]); out[1].append(a[1])
+            alens += list(alen); pos += m
+            locks.append((ch.status(0).stereo_detected, ch.status(1).stereo_detected))
+            pps.append([(e[0], e[1], e[3]) for e in ch.pps_events(0)])
+        ch.close()
+        return np.concatenate(out[0]), np.concatenate(out[1]), alens, locks, pps
+
+    a0, a1, al_a, lk_a, pp_a = run()
+    monkeypatch.setenv("FMR_NO_FUSED", "1")
+    b0, b1, al_b, lk_b, pp_b = run()
+    assert al_a == al_b and lk_a == lk_b and pp_a == pp_b
+    assert lk_a[-1] == (1, 1)
+    assert rms(a0 - b0) < 1e-6 and rms(a1 - b1) < 1e-6
