@@ -82,10 +82,11 @@ def test_stream_loop_fm_zero_if_with_pps(tmp_path, pilotcut):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["am", "nbfm"])
-def test_stream_loop_48k_modes(tmp_path, mode, am_narrow, nbfm_default, nbfm_audio):
-    """AM / NBFM: 384 kS/s IQ -> IfResampler(384 k, 48 k) -> decoder, the `-m am` / `-m nbfm` chains (main.cpp:718-723,775-777)."""
-    fs, blk, nblk = 384e3, 2048, 200
+@pytest.mark.parametrize("mode,fs", [("am", 384e3), ("nbfm", 384e3), ("am", 384e3 * (1 + 25e-6))])
+def test_stream_loop_48k_modes(tmp_path, mode, fs, am_narrow, nbfm_default, nbfm_audio):
+    """AM / NBFM: 384 kS/s IQ -> IfResampler(384 k, 48 k) -> decoder, the `-m am` / `-m nbfm` chains (main.cpp:718-723,775-777);
+    the third case with `-r 25` (ifrate * (1 + 25e-6), main.cpp:708-711): the facade's IfResampler takes the fractional-phase form."""
+    blk, nblk = 2048, 200
     x = siggen.am_iq(nblk * blk, fs) if mode == "am" else siggen.nbfm_iq(nblk * blk, fs)
     exe = _build(str(tmp_path))
     audio, _ = _run(exe, str(tmp_path), mode, fs, False, blk, x)
