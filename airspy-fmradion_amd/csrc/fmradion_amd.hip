@@ -98,6 +98,7 @@ struct EnvKnobs {
   bool agc_early = false;       // FMR_AGC_EARLY      side-stream AGC before the PLL's first pass
   bool mpf_v1 = false, mpf_v2 = false;   // FMR_MPF_V1 / V2   round-1 / one-wave equaliser kernels
   bool no_split = false;        // FMR_NO_SPLIT       mono and L-R audio tails on one stream
+  bool pll_v1 = false;          // FMR_PLL_V1         seven launches per Newton round of the PLL instead of three
   bool am_serial_tail = false;  // FMR_AM_SERIAL_TAIL serial AM audio tail
   bool fmblock_v1 = false;      // FMR_FMBLOCK_V1     IF filter out of global memory (round-1 kernel)
   int decim_bl = 128;           // FMR_DECIM_BL=256   wider stage-A workgroups
@@ -111,7 +112,7 @@ struct EnvKnobs {
     serial = on("FMR_SERIAL"); pipeline = on("FMR_PIPELINE"); debug_taps = on("FMR_DEBUG_TAPS");
     host_prof = on("FMR_HOST_PROF"); decim_v1 = on("FMR_DECIM_V1"); poly_v1 = on("FMR_POLY_V1");
     poly_v2 = on("FMR_POLY_V2"); poly_v3 = on("FMR_POLY_V3"); no_fused = on("FMR_NO_FUSED");
-    agc_early = set("FMR_AGC_EARLY"); mpf_v1 = set("FMR_MPF_V1"); mpf_v2 = set("FMR_MPF_V2"); no_split = set("FMR_NO_SPLIT");
+    agc_early = set("FMR_AGC_EARLY"); mpf_v1 = set("FMR_MPF_V1"); mpf_v2 = set("FMR_MPF_V2"); no_split = set("FMR_NO_SPLIT"); pll_v1 = set("FMR_PLL_V1");
     am_serial_tail = set("FMR_AM_SERIAL_TAIL"); fmblock_v1 = set("FMR_FMBLOCK_V1");
     if (const char *e = getenv("FMR_DECIM_BL")) if (atoi(e) == 256) decim_bl = 256;
     if (const char *e = getenv("FMR_C_PLL")) c_pll = atoi(e);
@@ -140,7 +141,9 @@ struct fmr_chain {
   // setting (third pass) the audio moves by 1.7e-9 RMS -- a tenth of the float32 front end's own 1.8e-8 deviation
   // from the fp64-accumulating oracle, 6000x inside the 1e-5 target -- and get_pilot_level by 2e-6 .. 2e-5 relative.
   double pll_rtol = 10.0;
-  DevBuf<double> d_pll_wgr;
+  DevBuf<double> d_pll_wgr, d_pll_pre;
+  DevBuf<PllSync> d_pll_sync;
+  DevBuf<unsigned int> d_pll_tick2;
   int pll_jac_rounds = 1;                // rounds that re-integrate the sensitivities (env FMR_PLL_JAC)
   double hp_fe = 0, hp_tab = 0, hp_dec = 0; long long hp_calls = 0; bool host_prof = false;   // FMR_HOST_PROF=1
   hipStream_t fe = nullptr;              // front-end stream (cross-call pipelining)
@@ -246,7 +249,7 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_taps.release(); d_fused_part.release(); d_afrag.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_pll_wgr.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_pll_wgr.release(); d_pll_pre.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     d_af_nodes.release(); d_af_G.release(); d_af_M.release(); d_af_out.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
@@ -625,6 +628,9 @@ int fmr_chain::init(const fmr_config *c) {
       const size_t max_grp2 = max_grp / FMR_NODE_GRP2 + 2;
       if ((rc = d_pll_PQ2.alloc((size_t)S * max_grp2 * 56))) return rc;
       if ((rc = d_pll_dstart2.alloc((size_t)S * max_grp2 * 7))) return rc;
+      if ((rc = d_pll_pre.alloc((size_t)S * max_grp * 56))) return rc;
+      if ((rc = d_pll_sync.alloc((size_t)S))) return rc;               // zeroed here; the kernels leave it zeroed
+      if ((rc = d_pll_tick2.alloc((size_t)S * max_grp2))) return rc;
     }
     mask_words = (std::max(c_pll, 128) + 63) / 64;   // wrap bit masks: one word per 64 samples of a chunk
     if ((rc = d_ck_mask.alloc((size_t)S * max_ck * mask_words))) return rc;
@@ -1336,16 +1342,14 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
           for (int it = 0; it < pll_iters; it++) {
             // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
             // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
-            if (it < pll_jac_rounds)
-              hipLaunchKernelGGL(k_pll_shoot<true>, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p,
-                                 base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
-                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p,
-                                 d_pll_wgr.p);
-            else
-              hipLaunchKernelGGL(k_pll_shoot<false>, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p,
-                                 base_stride, H_b, ct, d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift,
-                                 d_pll_nodes.p, d_pll_G.p, d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p,
-                                 d_pll_wgr.p);
+            PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
+            auto shoot = [&](auto kern) {
+              hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p, base_stride, H_b, ct,
+                                 d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
+                                 d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
+                                 pll_rtol, (int)(it > 0));
+            };
+            if (it < pll_jac_rounds) shoot(k_pll_shoot<true>); else shoot(k_pll_shoot<false>);
             if (it == 0 && split_mono && agc_deferred) {
               // side2: [after the first integration pass] mono tail, then the AGC
               (void)hipEventRecord(ev_if, stream);
@@ -1355,9 +1359,19 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
               mono_enqueued = true;
             }
             if (it == 0 && agc_deferred) { agc_deferred = false; if (enqueue_agc()) return; }
-            hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
-                               (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
+            if (env.pll_v1)
+              hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
+                                 (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
             if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
+            if (!env.pll_v1) {
+              hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
+                                 d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p, d_flags.p, d_pll_sync.p,
+                                 d_pll_tick2.p);
+              hipLaunchKernelGGL(k_pll_down, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
+                                 d_pll_pre.p, d_pll_dstart2.p, ngrp2, d_flags.p, pllc.minfreq, pllc.maxfreq,
+                                 d_pll_sync.p);
+              continue;
+            }
             hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                                nck, d_pll_PQ.p, d_flags.p);
             hipLaunchKernelGGL(k_pll_nodes_a2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_PQ2.p,

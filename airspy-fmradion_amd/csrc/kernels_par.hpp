@@ -810,13 +810,76 @@ __device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc
   return wrapped;
 }
 
+// Round bookkeeping shared by the three-launch form of the Newton round (described at k_pll_up below)
+struct PllSync {
+  unsigned int tick_shoot, tick_up;
+  unsigned long long rslot[64];       // integration pass: scaled boundary mismatch maxima (bits of non-negative doubles)
+  unsigned long long dslot[64][8];    // node pass: scaled Newton step maxima per state component
+};
+
+// true for exactly one workgroup (of one wave) of a set of `total`: the one that arrives last.  No cache-wide fence:
+// a release / acquire pair at agent scope writes back and invalidates the whole L2 of the XCD on this part -- once per
+// workgroup that made every kernel on the GPU slower (measured: PLL group 0.33 -> 0.54 ms, k_stats beside it 0.18 ->
+// 0.31 ms).  Instead everything one workgroup hands to another inside a launch is stored and loaded with agent-scope
+// atomic accesses (write-through / L2-coherent), the producer waits for its stores to be acknowledged before it takes
+// its ticket, and the ticket itself is an agent-scope atomic.  The ticket is left at zero for the next launch.
+__device__ __forceinline__ void st_agent(double *p, double v) {
+  __hip_atomic_store((long long *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+  return __longlong_as_double(__hip_atomic_load((const long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ bool pll_last_arrival(unsigned int *ticket, unsigned int total) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this workgroup's stores and atomics are done
+  unsigned int t = 0;
+  if (threadIdx.x == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+  if (t != total - 1) return false;
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::: "memory");
+  return true;
+}
+__device__ __forceinline__ unsigned long long pll_max_bits(double v) {   // fmax semantics: a NaN never wins
+  return (v > 0.0) ? (unsigned long long)__double_as_longlong(v) : 0ull;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// k_pll_check's bookkeeping on one wave: same acceptance rule, same record in IterFlags
+__device__ __forceinline__ void pll_round_check(IterFlags &F, PllSync &Y, double tol, double rtol, int have_d) {
+  const int lane = threadIdx.x;
+  const double mr = wave_max_d(__longlong_as_double((long long)__hip_atomic_load(&Y.rslot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+  Y.rslot[lane] = 0ull;
+  double mc[7];
+#pragma unroll
+  for (int q = 0; q < 7; q++) {
+    mc[q] = wave_max_d(__longlong_as_double((long long)__hip_atomic_load(&Y.dslot[lane][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    Y.dslot[lane][q] = 0ull;
+  }
+  if (lane != 0) return;
+  double m = 0.0;
+#pragma unroll
+  for (int q = 0; q < 7; q++) { m = fmax(m, mc[q]); if (have_d) F.pll_comp[q] = mc[q]; }
+  const int it = F.pll_iters;                    // integration passes done before this one
+  if (it < 16) F.pll_rhist[it] = mr;
+  if (have_d && it >= 1 && it <= 16) F.pll_hist[it - 1] = m;
+  F.pll_iters = it + 1;
+  if (mr <= rtol) { F.pll_converged = 1; F.pll_r_accepted = 1; F.pll_resid = mr; }
+  else if (have_d && m <= tol) { F.pll_converged = 1; F.pll_resid = m; }
+  else F.pll_resid = have_d ? m : mr;
+}
+
 template <bool JAC>
 __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ base, long long base_stride, int base_off, ChunkTab ct,
                             double *__restrict__ raw, long long raw_stride, int raw_off,
                             const float *__restrict__ atan_tab, PllConst pc, int pilot_shift,
                             const double *__restrict__ nodes, double *__restrict__ G, double *__restrict__ M,
                             int *__restrict__ ck_wraps, unsigned long long *__restrict__ ck_mask, int mask_words,
-                            const IterFlags *__restrict__ fl, double *__restrict__ wg_r) {
+                            IterFlags *__restrict__ fl, double *__restrict__ wg_r,
+                            PllSync *__restrict__ sync, double tol, double rtol, int have_d) {
   __shared__ float tab[257];
   for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
   __syncthreads();
@@ -880,7 +943,14 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
   // mismatch alone, which skips this round's node pass
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, 64));
-  if (threadIdx.x == 0) wg_r[(long long)s * gridDim.x + blockIdx.x] = rmax;
+  if (!sync) {                               // seven-kernel form: k_pll_check is the next launch
+    if (threadIdx.x == 0) wg_r[(long long)s * gridDim.x + blockIdx.x] = rmax;
+    return;
+  }
+  // three-kernel form: maxima through 64 slots; the stream's last workgroup does the round's bookkeeping
+  PllSync &Y = sync[s];
+  if (threadIdx.x == 0) atomicMax(&Y.rslot[blockIdx.x & 63], pll_max_bits(rmax));
+  if (pll_last_arrival(&Y.tick_shoot, gridDim.x)) pll_round_check(fl[s], Y, tol, rtol, have_d);
 }
 
 // ---------------------------------------------------------------------------
@@ -973,12 +1043,16 @@ __global__ __launch_bounds__(64) void k_pll_nodes_a(const double *__restrict__ n
 // Phase A2: compose FMR_NODE_GRP2 consecutive level-1 group maps (already in [P|q] form)
 // into one level-2 map; same lane layout as phase A.
 // the [P|q] maps of one level-2 group (FMR_NODE_GRP2 x 56 doubles, contiguous) through LDS: one round of coalesced loads
-__device__ __forceinline__ void pll_stage_pq(const double *__restrict__ pq, int g0, int n, int lane, double *sp) {
+template <bool AGENT = false>   // AGENT: the maps were stored by other workgroups of this launch (st_agent)
+__device__ __forceinline__ void pll_stage_pq(const double *pq, int g0, int n, int lane, double *sp) {
   constexpr int NL = (FMR_NODE_GRP2 * 56 + 63) / 64;
   const double *pb = pq + (long long)g0 * 56;
   double tmp[NL];
 #pragma unroll
-  for (int u = 0; u < NL; u++) { const int idx = lane + 64 * u; tmp[u] = (idx < n * 56) ? pb[idx] : 0.0; }
+  for (int u = 0; u < NL; u++) {
+    const int idx = lane + 64 * u;
+    tmp[u] = (idx < n * 56) ? (AGENT ? ld_agent(pb + idx) : pb[idx]) : 0.0;
+  }
 #pragma unroll
   for (int u = 0; u < NL; u++) { const int idx = lane + 64 * u; if (idx < FMR_NODE_GRP2 * 56) sp[idx] = tmp[u]; }
 }
@@ -1196,6 +1270,165 @@ __global__ __launch_bounds__(1024) void k_pll_check(IterFlags *fl, int n_streams
       else F.pll_resid = have_d ? m : mr;
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// The same round in three launches instead of seven (integration pass + bookkeeping, up-sweep, down-sweep).
+// A launch that depends on the one before it costs ~5 us on this part whatever it does, and a call in lock accepts
+// its second pass: 14 of the 23 launches of the seven-kernel form found pll_converged set and left -- ~70 us of a
+// 0.8 ms step.  Kernels are merged with the last-arrival pattern: a workgroup publishes its result, fences, takes a
+// ticket; whoever draws the last ticket of its set does the next level's work (no workgroup ever waits for another).
+//   k_pll_shoot2:  integration pass; the last workgroup of a stream does k_pll_check's bookkeeping
+//   k_pll_up:      phase A; the last group of every level-2 set composes the set (A2) and stores the running prefix
+//                  composites on the way; the last set of a stream walks the level-2 maps (B)
+//   k_pll_down:    start delta of a group = its prefix composite applied to the set's start delta (replaces C2's
+//                  32-step chain by one 7x8 product), then phase C; residual maxima through 64 x 8 atomicMax slots
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes, const double *__restrict__ G,
+                                               const double *__restrict__ M, int nck, double *PQ,
+                                               double *__restrict__ PRE, double *PQ2, int ngrp2,
+                                               double *__restrict__ dstart2, const IterFlags *__restrict__ fl,
+                                               PllSync *__restrict__ sync, unsigned int *__restrict__ tick2) {
+  __shared__ double sm[FMR_NODE_GRP2 * 56];      // phase A uses FMR_NODE_GRP * 49 of it
+  __shared__ double sr[FMR_NODE_GRP * 8];
+  __shared__ double sh[64];
+  static_assert(FMR_NODE_GRP2 * 56 >= FMR_NODE_GRP * 49, "shared staging buffer");
+  const int s = blockIdx.y, grp = blockIdx.x, ngrp = gridDim.x;
+  if (fl[s].pll_converged) return;
+  const int lane = threadIdx.x, i = lane >> 3, k = lane & 7;
+  const bool act = i < 7;
+  const int ii = act ? i : 0;
+  {
+    const double *nd = nodes + (long long)s * (nck + 1) * 7;
+    const double *g = G + (long long)s * nck * 9;
+    const double *m = M + (long long)s * nck * 49;
+    const int c0 = grp * FMR_NODE_GRP, c1 = min(c0 + FMR_NODE_GRP, nck);
+    pll_stage_group(m, g, nd, c0, c1 - c0, lane, sm, sr, nullptr);
+    __syncthreads();
+    double val = (act && i == k) ? 1.0 : 0.0;   // P = I, q = 0
+    for (int t = 0; t < c1 - c0; t++) {
+      sh[lane] = val;
+      __syncthreads();                      // one wave per block: just orders the LDS write
+      double acc = (k == 7) ? sr[t * 8 + ii] : 0.0;
+      const double *row = sm + t * 49 + ii * 7;
+#pragma unroll
+      for (int j = 0; j < 7; j++) acc = fma(row[j], sh[j * 8 + k], acc);
+      __syncthreads();
+      val = acc;
+    }
+    if (act) st_agent(&PQ[(((long long)s * ngrp + grp) * 7 + i) * 8 + k], val);
+  }
+  // ---- level 2: the last group of the set composes the set
+  const int set = grp / FMR_NODE_GRP2;
+  const int g0 = set * FMR_NODE_GRP2, g1 = min(g0 + FMR_NODE_GRP2, ngrp);
+  if (!pll_last_arrival(tick2 + (long long)s * ngrp2 + set, (unsigned int)(g1 - g0))) return;
+  {
+    const double *pq = PQ + (long long)s * ngrp * 56;
+    double *pre = PRE + (long long)s * ngrp * 56;
+    pll_stage_pq<true>(pq, g0, g1 - g0, lane, sm);
+    __syncthreads();
+    double val = (act && i == k) ? 1.0 : 0.0;
+    for (int t = 0; t < g1 - g0; t++) {
+      if (act) pre[((long long)(g0 + t) * 7 + i) * 8 + k] = val;     // composite of the groups before g0 + t
+      const double *mr = sm + (t * 7 + ii) * 8;
+      sh[lane] = val;
+      __syncthreads();
+      double acc = (k == 7) ? mr[7] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 7; j++) acc = fma(mr[j], sh[j * 8 + k], acc);
+      __syncthreads();
+      val = acc;
+    }
+    if (act) st_agent(&PQ2[(((long long)s * ngrp2 + set) * 7 + i) * 8 + k], val);
+  }
+  // ---- level 3: the last set walks the level-2 maps (lane i = component i)
+  if (!pll_last_arrival(&sync[s].tick_up, (unsigned int)ngrp2)) return;
+  {
+    const double *pq2 = PQ2 + (long long)s * ngrp2 * 56;
+    double *ds = dstart2 + (long long)s * ngrp2 * 7;
+    const bool a7 = lane < 7;
+    const int l7 = a7 ? lane : 0;
+    double d = 0.0;
+    for (int q0 = 0; q0 < ngrp2; q0 += FMR_NODE_GRP2) {
+      const int n = min(FMR_NODE_GRP2, ngrp2 - q0);
+      __syncthreads();
+      pll_stage_pq<true>(pq2, q0, n, lane, sm);
+      __syncthreads();
+      for (int t = 0; t < n; t++) {
+        if (a7) ds[(long long)(q0 + t) * 7 + lane] = d;
+        const double *row = sm + (t * 7 + l7) * 8;
+        const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2 = readlane_d(d, 2), d3 = readlane_d(d, 3),
+                     d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
+        const double p0 = fma(row[0], d0, fma(row[1], d1, row[7]));
+        const double p1 = fma(row[2], d2, row[3] * d3);
+        const double p2 = fma(row[4], d4, fma(row[5], d5, row[6] * d6));
+        d = p0 + (p1 + p2);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_pll_down(double *__restrict__ nodes, const double *__restrict__ G,
+                                                 const double *__restrict__ M, int nck,
+                                                 const double *__restrict__ PRE, const double *__restrict__ dstart2,
+                                                 int ngrp2, const IterFlags *__restrict__ fl, double minfreq,
+                                                 double maxfreq, PllSync *__restrict__ sync) {
+  __shared__ double sm[FMR_NODE_GRP * 49];
+  __shared__ double sr[FMR_NODE_GRP * 8];
+  __shared__ double so[FMR_NODE_GRP * 8];
+  const int s = blockIdx.y, grp = blockIdx.x, ngrp = gridDim.x;
+  if (fl[s].pll_converged) return;
+  const int i = threadIdx.x;
+  const bool act = i < 7;
+  const int ii = act ? i : 0;
+  double *nd = nodes + (long long)s * (nck + 1) * 7;
+  const double *g = G + (long long)s * nck * 9;
+  const double *m = M + (long long)s * nck * 49;
+  const double two_pi = 2.0 * 3.14159265358979323846, inv_two_pi = 1.0 / two_pi;
+  const int c0 = grp * FMR_NODE_GRP, c1 = min(c0 + FMR_NODE_GRP, nck);
+  // start delta of the group: (P | q) of the groups before it in its set, applied to the set's start delta
+  const double *pre = PRE + (((long long)s * ngrp + grp) * 7 + ii) * 8;
+  const double *d2 = dstart2 + ((long long)s * ngrp2 + grp / FMR_NODE_GRP2) * 7;
+  double pr[8], dv[7];
+#pragma unroll
+  for (int q = 0; q < 8; q++) pr[q] = pre[q];
+#pragma unroll
+  for (int q = 0; q < 7; q++) dv[q] = d2[q];
+  // scale of the biquad delays: size of the (I,Q) delay pair at the group start
+  const double wm = fabs(g[(long long)c0 * 9 + 3]) + fabs(g[(long long)c0 * 9 + 5]);
+  double inv_scale = 1.0 / (1e-7 * (wm + 1.0));
+  if (i == 0) inv_scale = 1e7; else if (i == 1) inv_scale = 1e9; else if (i == 2) inv_scale = 1e5;
+  pll_stage_group(m, g, nd, c0, c1 - c0, i, sm, sr, so);
+  __syncthreads();
+  double d = fma(pr[0], dv[0], fma(pr[1], dv[1], pr[7])) + (fma(pr[2], dv[2], pr[3] * dv[3]) +
+             fma(pr[4], dv[4], fma(pr[5], dv[5], pr[6] * dv[6])));
+  double resid = 0.0;
+  for (int t = 0; t < c1 - c0; t++) {
+    const double *row = sm + t * 49 + ii * 7;
+    const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2v = readlane_d(d, 2), d3 = readlane_d(d, 3),
+                 d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
+    const double p0 = fma(row[0], d0, fma(row[1], d1, sr[t * 8 + ii]));
+    const double p1 = fma(row[2], d2v, row[3] * d3);
+    const double p2 = fma(row[4], d4, fma(row[5], d5, row[6] * d6));
+    d = p0 + (p1 + p2);                       // delta of node c+1
+    double nv = so[t * 8 + ii] + d;
+    if (i == 0) {                             // keep the phase inside (0, 2 pi] like the reference
+      nv -= two_pi * floor(nv * inv_two_pi);
+      if (nv <= 0.0) nv += two_pi;
+    }
+    if (i == 1) nv = fmax(minfreq, fmin(maxfreq, nv));   // the true freq never leaves the clamp range
+    if (act) {
+      so[t * 8 + i] = nv;                     // (each lane reads and writes only its own column)
+      resid = fmax(resid, fabs(d) * inv_scale);
+    }
+  }
+  __syncthreads();
+  for (int idx = i; idx < (c1 - c0) * 7; idx += 64) {
+    const int c = idx / 7, q = idx - 7 * c;
+    nd[(long long)(c0 + 1) * 7 + idx] = so[c * 8 + q];
+  }
+  // ~40 groups share a slot: same-address atomics from all the groups would serialise in L2
+  if (act) atomicMax(&sync[s].dslot[grp & 63][i], pll_max_bits(resid));
 }
 
 // initial node guess: nominal ramp from the carried state
