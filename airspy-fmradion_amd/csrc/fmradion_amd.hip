@@ -95,10 +95,12 @@ struct EnvKnobs {
   bool decim_v1 = false;        // FMR_DECIM_V1=1     round-1 first stage-A kernel
   bool poly_v1 = false, poly_v2 = false, poly_v3 = false;   // FMR_POLY_V1/V2/V3=1  older stage-B kernels
   bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end
-  bool agc_early = false;       // FMR_AGC_EARLY      side-stream AGC before the PLL's first pass
+  bool agc_late = false;        // FMR_AGC_LATE       side-stream AGC gated on k_stats (about the end of the PLL's first pass) instead of the front end
   bool mpf_v1 = false, mpf_v2 = false;   // FMR_MPF_V1 / V2   round-1 / one-wave equaliser kernels
-  bool no_split = false;        // FMR_NO_SPLIT       mono and L-R audio tails on one stream
+  bool split_mono = true;       // FMR_NO_SPLIT=1     mono and L-R audio tails on one stream (default: mono tail on the AGC's side stream)
   bool pll_v1 = false;          // FMR_PLL_V1         seven launches per Newton round of the PLL instead of three
+  bool agc_first = true;        // FMR_MONO_FIRST=1   side stream: mono audio tail before the AGC (default: after)
+  bool iter_v1 = false;         // FMR_ORDER_V1       round-2 enqueue order (flag reset / input history / markers on the main stream)
   bool am_serial_tail = false;  // FMR_AM_SERIAL_TAIL serial AM audio tail
   bool fmblock_v1 = false;      // FMR_FMBLOCK_V1     IF filter out of global memory (round-1 kernel)
   int decim_bl = 128;           // FMR_DECIM_BL=256   wider stage-A workgroups
@@ -112,7 +114,7 @@ struct EnvKnobs {
     serial = on("FMR_SERIAL"); pipeline = on("FMR_PIPELINE"); debug_taps = on("FMR_DEBUG_TAPS");
     host_prof = on("FMR_HOST_PROF"); decim_v1 = on("FMR_DECIM_V1"); poly_v1 = on("FMR_POLY_V1");
     poly_v2 = on("FMR_POLY_V2"); poly_v3 = on("FMR_POLY_V3"); no_fused = on("FMR_NO_FUSED");
-    agc_early = set("FMR_AGC_EARLY"); mpf_v1 = set("FMR_MPF_V1"); mpf_v2 = set("FMR_MPF_V2"); no_split = set("FMR_NO_SPLIT"); pll_v1 = set("FMR_PLL_V1");
+    agc_late = set("FMR_AGC_LATE"); mpf_v1 = set("FMR_MPF_V1"); mpf_v2 = set("FMR_MPF_V2"); split_mono = !set("FMR_NO_SPLIT"); pll_v1 = set("FMR_PLL_V1"); iter_v1 = set("FMR_ORDER_V1"); agc_first = !set("FMR_MONO_FIRST");
     am_serial_tail = set("FMR_AM_SERIAL_TAIL"); fmblock_v1 = set("FMR_FMBLOCK_V1");
     if (const char *e = getenv("FMR_DECIM_BL")) if (atoi(e) == 256) decim_bl = 256;
     if (const char *e = getenv("FMR_C_PLL")) c_pll = atoi(e);
@@ -157,6 +159,7 @@ struct fmr_chain {
   hipStream_t side = nullptr, side2 = nullptr;   // side2: the IF AGC when it is off the critical path
   hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr,
              ev_tab = nullptr, ev_mono = nullptr;
+  bool ev_agc_live = false;            // ev_agc has been recorded by an earlier call
   // designs + counters
   ResamplerDesign rs, ars;
   ResamplerCounter rsc, arsc;
@@ -1048,6 +1051,15 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                            pllc);
       });
   }
+  // FM without the equaliser: the round flags and the AGC's start nodes are reset here too, beside the front end (5-10 us
+  // of the critical path when launched between the front end and the PLL's first pass).  Their last readers of the previous
+  // call are the PLL kernels (ordered before this stream's k_pll_finish) and the side-stream AGC (ev_agc).
+  const bool iter_on_side = (mode == FMR_MODE_FM) && !serial_mode && !enable_mpf && !env.iter_v1;
+  if (iter_on_side) {
+    if (ev_agc_live) HIPCHK(hipStreamWaitEvent(side, ev_agc, 0));
+    const int nc = (int)((N_if + C_AGC - 1) / C_AGC);
+    hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, side, d_flags.p, d_agc_nodes.p, nc, d_state.p, S);
+  }
   HIPCHK(hipEventRecord(ev_tab, side));
   HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
   BlockTab bt{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
@@ -1097,9 +1109,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, stream, a, fused_taps);
     });
     fused_kb_ref = a.kb_ref;
-    timed("in_halo", [&] {
-      hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
-    });
+    if (env.iter_v1)
+      timed("in_halo", [&] {
+        hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
+      });
   }
   hp2 = std::chrono::steady_clock::now();
   // ------------------------------------------------------- decoder, IF-rate part
@@ -1137,11 +1150,12 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   // ---- IF AGC: Newton multiple shooting over chunks of C_AGC samples (kernels_par.hpp)
   const float *disc_gain = d_gain.p;      // gain sequence the discriminator multiplies in (nullptr = none)
   bool agc_on_side = false, agc_deferred = false;
-  std::function<int()> enqueue_agc;
+  std::function<int(hipEvent_t)> enqueue_agc;      // argument: event that gates the side stream (null: a new marker on the main stream)
   const int agc_nc = (int)((N_if + C_AGC - 1) / C_AGC);
-  hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, stream, d_flags.p,
-                     (serial_mode || enable_mpf) ? (float *)nullptr : d_agc_nodes.p,
-                     agc_nc, d_state.p, S);
+  if (!iter_on_side)
+    hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, stream, d_flags.p,
+                       (serial_mode || enable_mpf) ? (float *)nullptr : d_agc_nodes.p,
+                       agc_nc, d_state.p, S);
   // With the equaliser on, the AGC'd amplitude feeds the constant-modulus error, and
   // the equaliser kernel is the serial bottleneck anyway: use the exact serial AGC.
   if (serial_mode || enable_mpf) {
@@ -1161,11 +1175,15 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     hipStream_t as = agc_aside ? side2 : stream;
     // With the PLL on, the side-stream AGC starts only after the PLL's first (Jacobian) integration pass: that
     // pass runs one wave per SIMD and every co-resident AGC wave stretches it (measured 118 -> 160 us).
-    agc_deferred = agc_aside && stereo && !env.agc_early;
-    enqueue_agc = [=]() -> int {
+    agc_deferred = agc_aside && stereo;
+    enqueue_agc = [=](hipEvent_t gate) -> int {
     if (agc_aside) {
-      HIPCHK(hipEventRecord(ev_if, stream));
-      HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
+      if (gate) {
+        HIPCHK(hipStreamWaitEvent(side2, gate, 0));
+      } else {
+        HIPCHK(hipEventRecord(ev_if, stream));
+        HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
+      }
     }
     const int agc_nw = std::max(1, std::min(16, (agc_nc + 64 * FMR_AGC_PER_LANE - 1) / (64 * FMR_AGC_PER_LANE)));
     timed_on(as, "if_agc", [&] {
@@ -1179,11 +1197,11 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
       hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,
                          d_gain.p, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
     });
-    if (agc_aside) { HIPCHK(hipEventRecord(ev_agc, side2)); }
+    if (agc_aside) { HIPCHK(hipEventRecord(ev_agc, side2)); ev_agc_live = true; }
     return FMR_OK;
     };
     if (agc_aside) { disc_gain = nullptr; agc_on_side = true; }
-    if (!agc_deferred) { if (int rca = enqueue_agc()) return rca; }
+    if (!agc_deferred) { if (int rca = enqueue_agc(nullptr)) return rca; }
   }
   if (mode == FMR_MODE_FM) {
     if (any_mpf) {
@@ -1229,13 +1247,17 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     });
     HIPCHK(hipEventRecord(ev_disc, stream));
     HIPCHK(hipStreamWaitEvent(side, ev_disc, 0));
+    if (use_fused && !env.iter_v1)      // input history for the next call's front end: off the critical path (the next
+      timed_on(side, "in_halo", [&] {   // front end waits for this stream's table kernels anyway)
+        hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, side, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
+      });
     timed_on(side, "stats", [&] {     // (fused front end: the block values are summed from its partial sums on the fly)
       hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
                          d_bb_rms_blk.p, d_state.p, S, 1, use_fused ? d_fused_part.p : (const FusedPart *)nullptr,
                          fused_n_tiles, fused_kb_ref);
     });
     HIPCHK(hipEventRecord(ev_stats, side));
-    bool fin_on_side = false;
+    bool fin_on_side = false, fin_covers_all = false;
     const int nch = stereo ? 2 : 1;
     // ---------------------------------------------------- audio resampler + tail
     const int count_am = (int)(arsc.mA - amA_prev);
@@ -1325,7 +1347,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         });
     };
     const bool split_mono = stereo && !serial_mode && de_fused && (ars.LB == 3 && ars.MB == 8) &&
-                            n_pilotcut <= FMR_PCUT_MAXTAPS && !env.no_split;
+                            n_pilotcut <= FMR_PCUT_MAXTAPS && env.split_mono;
     bool mono_enqueued = false;
     if (stereo) {
       if (serial_mode) {
@@ -1350,15 +1372,24 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                                  pll_rtol, (int)(it > 0));
             };
             if (it < pll_jac_rounds) shoot(k_pll_shoot<true>); else shoot(k_pll_shoot<false>);
-            if (it == 0 && split_mono && agc_deferred) {
-              // side2: [after the first integration pass] mono tail, then the AGC
-              (void)hipEventRecord(ev_if, stream);
-              (void)hipStreamWaitEvent(side2, ev_if, 0);
-              enqueue_tail_channels(side2, 0, 1);
-              (void)hipEventRecord(ev_mono, side2);
-              mono_enqueued = true;
+            if (it == 0 && agc_deferred) {
+              // side2: the AGC and the mono audio tail beside the PLL.  Gated on an event that
+              // exists already -- the front end's (ev_disc) or k_stats', which fires about when the first pass ends
+              // (FMR_AGC_LATE=1) -- because a marker of its own on this stream costs ~10 us between the first pass
+              // and the node pass (FMR_ORDER_V1=1: that marker).
+              agc_deferred = false;
+              hipEvent_t gate = env.iter_v1 ? nullptr : (env.agc_late ? ev_stats : ev_disc);
+              if (!gate) { (void)hipEventRecord(ev_if, stream); gate = ev_if; }
+              auto mono_aside = [&] {
+                (void)hipStreamWaitEvent(side2, gate, 0);
+                enqueue_tail_channels(side2, 0, 1);
+                (void)hipEventRecord(ev_mono, side2);
+                mono_enqueued = true;
+              };
+              if (split_mono && !env.agc_first) mono_aside();
+              if (enqueue_agc(gate)) return;
+              if (split_mono && env.agc_first) mono_aside();
             }
-            if (it == 0 && agc_deferred) { agc_deferred = false; if (enqueue_agc()) return; }
             if (env.pll_v1)
               hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
                                  (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
@@ -1397,16 +1428,19 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                              pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
                              d_blk_wraps.p, d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
         });
+        // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
+        // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
+        if (agc_on_side && !agc_deferred && !env.iter_v1) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
         HIPCHK(hipEventRecord(ev_fin, side));
         fin_on_side = true;
       }
     }
-    if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc()) return rca; }   // PLL path not taken
+    if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr)) return rca; }   // PLL path not taken
     if (mono_enqueued) enqueue_tail_channels(stream, 1, 1);
     else enqueue_tail_channels(stream, 0, nch);
     if (mono_enqueued) HIPCHK(hipStreamWaitEvent(stream, ev_mono, 0));   // DC-block node pass needs both channels
     if (N_au > 0) {
-      if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
+      if (fin_on_side && (serial_mode || env.iter_v1)) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
       if (serial_mode) {
         timed("fm_out", [&] {
           hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
@@ -1419,6 +1453,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
           const int dc_nw = std::max(1, std::min(16, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
           hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
                              d_state.p, S, nch);
+          if (fin_on_side && !env.iter_v1) (void)hipStreamWaitEvent(stream, ev_fin, 0);   // only the mux needs the lock flags
           hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
                              (long long)max_au, bt, (int)N_au, dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,
                              d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
@@ -1434,9 +1469,11 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if (stereo) add_halo(d_am1.p, am_stride, H_am, count_am);
     add_halo(d_a10.p, a1_stride, H_pc, N_au);
     if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
-    HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
-    if (agc_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_agc, 0));
-    if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
+    if (!(fin_covers_all && N_au > 0)) {        // (otherwise the wait before the output mux covered all three)
+      HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
+      if (agc_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_agc, 0));
+      if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
+    }
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
   } else if (mode == FMR_MODE_NBFM) {
     // NbfmDecoder (NbfmDecode.cpp:47-96): discriminator on the AGC'd IF, statistics, 63-tap audio FIR (same

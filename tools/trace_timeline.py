@@ -8,7 +8,7 @@ import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "fmr::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-dec = [i for i, r in enumerate(rows) if "k_ifr_decim" in r["Kernel_Name"]]
+dec = [i for i, r in enumerate(rows) if "k_ifr_decim" in r["Kernel_Name"] or "k_ifr_fused" in r["Kernel_Name"]]
 print("decim us:", " ".join("%.0f" % ((int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3) for i in dec))
 starts = [int(rows[i]["Start_Timestamp"]) for i in dec]
 print("decim start-to-start us:", " ".join("%.0f" % ((b - a) / 1e3) for a, b in zip(starts, starts[1:])))
