@@ -241,6 +241,14 @@ struct fmr_chain {
   std::vector<KernelTime> ktimes;
 
   ~fmr_chain() {
+#ifdef FMR_PLL_TRACE
+    if (d_pll_wgr.p && getenv("FMR_PLL_TRACE_OUT")) {
+      (void)hipDeviceSynchronize();
+      std::vector<unsigned long long> h(d_pll_wgr.n);
+      (void)hipMemcpy(h.data(), d_pll_wgr.p, h.size() * 8, hipMemcpyDeviceToHost);
+      if (FILE *f = fopen(getenv("FMR_PLL_TRACE_OUT"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+#endif
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     for (auto &k : dom_times) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
@@ -627,7 +635,7 @@ int fmr_chain::init(const fmr_config *c) {
       if ((rc = d_pll_PQ.alloc((size_t)S * max_grp * 56))) return rc;
       if ((rc = d_pll_dstart.alloc((size_t)S * max_grp * 7))) return rc;
       if ((rc = d_pll_gres.alloc((size_t)S * max_grp * 8))) return rc;
-      if ((rc = d_pll_wgr.alloc((size_t)S * (max_ck / 64 + 2)))) return rc;
+      if ((rc = d_pll_wgr.alloc((size_t)S * (max_ck / 64 + 2) * 8))) return rc;      // (x 8: room for the FMR_PLL_TRACE records)
       const size_t max_grp2 = max_grp / FMR_NODE_GRP2 + 2;
       if ((rc = d_pll_PQ2.alloc((size_t)S * max_grp2 * 56))) return rc;
       if ((rc = d_pll_dstart2.alloc((size_t)S * max_grp2 * 7))) return rc;
@@ -1371,7 +1379,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                                  d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
                                  pll_rtol, (int)(it > 0));
             };
-            if (it < pll_jac_rounds) shoot(k_pll_shoot<true>); else shoot(k_pll_shoot<false>);
+            // the first round writes no L-R samples unless it can be the accepted one (a call of one or two chunks)
+            const bool wout = it > 0 || env.pll_v1 || nck <= 2;
+            if (it < pll_jac_rounds) { if (wout) shoot(k_pll_shoot<true, true>); else shoot(k_pll_shoot<true, false>); }
+            else shoot(k_pll_shoot<false, true>);
             if (it == 0 && agc_deferred) {
               // side2: the AGC and the mono audio tail beside the PLL.  Gated on an event that
               // exists already -- the front end's (ev_disc) or k_stats', which fires about when the first pass ends

@@ -93,6 +93,29 @@ __device__ __forceinline__ void serial_prefetch(const T *__restrict__ p, int i0,
   }
   for (; i < i1; i++) f(i, p[i]);
 }
+// The same with the loads of batch k+1 issued BEFORE the steps of batch k.  A body that stores to global memory makes
+// the difference: gfx9 counts loads and stores in one in-order counter (vmcnt), so waiting for loads issued after a
+// batch's stores waits for the stores' acknowledgements too -- a full memory round trip plus the load latency in
+// front of every batch.  Issued ahead of the stores, the loads are waited for with the stores still in flight.
+template <int U, class T, class F>
+__device__ __forceinline__ void serial_prefetch_ahead(const T *__restrict__ p, int i0, int i1, F &&f) {
+  int i = i0;
+  T cur[U], nxt[U];
+  if (i + U <= i1) {
+#pragma unroll
+    for (int u = 0; u < U; u++) cur[u] = p[i + u];
+  }
+  for (; i + U <= i1; i += U) {
+#pragma unroll
+    for (int u = 0; u < U; u++) nxt[u] = p[min(i + U + u, i1 - 1)];   // (clamped, not predicated: a branch around the
+                                                                      // loads makes the compiler wait with vmcnt(0))
+#pragma unroll
+    for (int u = 0; u < U; u++) f(i + u, cur[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) cur[u] = nxt[u];
+  }
+  for (; i < i1; i++) f(i, p[i]);
+}
 template <int U, class T, class T2, class F>
 __device__ __forceinline__ void serial_prefetch2(const T *__restrict__ p, const T2 *__restrict__ q, int i0, int i1, F &&f) {
   int i = i0;
@@ -1686,38 +1709,29 @@ __global__ __launch_bounds__(64) void k_stats(BlockTab bt, const float *__restri
 // (FmDecode.cpp:224-239).  Nonlinear feedback loop: strictly serial per
 // stream, one lane per stream; FP64 with the float table-driven fast_atan2f.
 // ---------------------------------------------------------------------------
+// Branch-free: the function sits on the loop-carried chain of every PLL sample step, and its eleven-way control flow
+// compiled to exec-mask branches around every arm.  Same comparisons, same float operations in the same order on the
+// arm that counts (one division, one table interpolation, one add / subtract from 0, pi or pi/2, one negation), so
+// the result is bit-identical to the branchy form: a - b == a + (-b) and b - a == -(a - b) exactly in IEEE arithmetic,
+// and 0 + b == b because b >= +0.
 __device__ __forceinline__ float fast_atan2f_dev(float y, float x, const float *tab) {
   const float y_abs = fabsf(y), x_abs = fabsf(x);
-  if (!((y_abs > 0.0f) || (x_abs > 0.0f))) return 0.0f;
-  float z = (y_abs < x_abs) ? (y_abs / x_abs) : (x_abs / y_abs);
-  float base_angle;
-  if ((double)z < 0.003921569) {
-    base_angle = z;
-  } else {
-    float alpha = z * 255.0f;
-    const int index = ((int)alpha) & 0xff;
-    alpha -= (float)index;
-    base_angle = tab[index];
-    base_angle += (tab[index + 1] - tab[index]) * alpha;
-  }
-  float angle;
-  if (x_abs > y_abs) {
-    if (x >= 0.0f) {
-      angle = (y >= 0.0f) ? base_angle : -base_angle;
-    } else {
-      angle = 3.14159265358979323846f;
-      if (y >= 0.0f) angle -= base_angle; else angle = base_angle - angle;
-    }
-  } else {
-    if (y >= 0.0f) {
-      angle = 1.57079632679489661923f;
-      if (x >= 0.0f) angle -= base_angle; else angle += base_angle;
-    } else {
-      angle = -1.57079632679489661923f;
-      if (x >= 0.0f) angle += base_angle; else angle -= base_angle;
-    }
-  }
-  return angle;
+  const bool any = (y_abs > 0.0f) || (x_abs > 0.0f);
+  const bool ylt = y_abs < x_abs;
+  const float z = (ylt ? y_abs : x_abs) / (ylt ? x_abs : y_abs);
+  float alpha = z * 255.0f;
+  const int index = ((int)alpha) & 0xff;
+  alpha -= (float)index;
+  const float t0 = tab[index], t1 = tab[index + 1];
+  float base_angle = t0;
+  base_angle += (t1 - t0) * alpha;
+  base_angle = ((double)z < 0.003921569) ? z : base_angle;
+  const bool xgt = x_abs > y_abs, xpos = x >= 0.0f, ypos = y >= 0.0f;
+  const float c = xgt ? (xpos ? 0.0f : 3.14159265358979323846f) : 1.57079632679489661923f;
+  const bool minus = xgt ? !xpos : xpos;
+  const float r = c + (minus ? -base_angle : base_angle);
+  const float angle = ypos ? r : -r;
+  return any ? angle : 0.0f;
 }
 
 __global__ __launch_bounds__(64) void k_pll(

@@ -784,12 +784,14 @@ __device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc
     const double eI = den > 0.0 ? -wq0 / den : 0.0, eQ = den > 0.0 ? wi0 / den : 0.0;
     const double cI = x * pcos, cQ = -x * psin;
     const double mask = (f_un >= pc.minfreq && f_un <= pc.maxfreq) ? 1.0 : 0.0;
+    const double na1 = -pc.bq_a1, na2 = -pc.bq_a2;
 #pragma unroll
     for (int k = 0; k < 7; k++) {
-      const double rwi = cI * Mx[0][k] - pc.bq_a1 * Mx[3][k] - pc.bq_a2 * Mx[4][k];
-      const double rwq = cQ * Mx[0][k] - pc.bq_a1 * Mx[5][k] - pc.bq_a2 * Mx[6][k];
-      const double re = eI * rwi + eQ * rwq;
-      const double rf = mask * (Mx[1][k] + pc.lf_b1 * Mx[2][k] + pc.lf_b0 * re);
+      // (explicit fma: the sensitivities are this implementation's own quantity, not reference arithmetic)
+      const double rwi = fma(cI, Mx[0][k], fma(na1, Mx[3][k], na2 * Mx[4][k]));
+      const double rwq = fma(cQ, Mx[0][k], fma(na1, Mx[5][k], na2 * Mx[6][k]));
+      const double re = fma(eI, rwi, eQ * rwq);
+      const double rf = mask * fma(pc.lf_b0, re, fma(pc.lf_b1, Mx[2][k], Mx[1][k]));
       Mx[0][k] = Mx[0][k] + rf;
       Mx[1][k] = rf;
       Mx[2][k] = re;
@@ -849,7 +851,8 @@ __device__ __forceinline__ double wave_max_d(double v) {
 }
 
 // k_pll_check's bookkeeping on one wave: same acceptance rule, same record in IterFlags
-__device__ __forceinline__ void pll_round_check(IterFlags &F, PllSync &Y, double tol, double rtol, int have_d) {
+__device__ __forceinline__ void pll_round_check(IterFlags &F, PllSync &Y, double tol, double rtol, int have_d,
+                                                bool may_accept) {
   const int lane = threadIdx.x;
   const double mr = wave_max_d(__longlong_as_double((long long)__hip_atomic_load(&Y.rslot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
   Y.rslot[lane] = 0ull;
@@ -867,12 +870,22 @@ __device__ __forceinline__ void pll_round_check(IterFlags &F, PllSync &Y, double
   if (it < 16) F.pll_rhist[it] = mr;
   if (have_d && it >= 1 && it <= 16) F.pll_hist[it - 1] = m;
   F.pll_iters = it + 1;
-  if (mr <= rtol) { F.pll_converged = 1; F.pll_r_accepted = 1; F.pll_resid = mr; }
-  else if (have_d && m <= tol) { F.pll_converged = 1; F.pll_resid = m; }
+  if (may_accept && mr <= rtol) { F.pll_converged = 1; F.pll_r_accepted = 1; F.pll_resid = mr; }
+  else if (may_accept && have_d && m <= tol) { F.pll_converged = 1; F.pll_resid = m; }
   else F.pll_resid = have_d ? m : mr;
 }
 
-template <bool JAC>
+// WOUT: store the demodulated L-R samples and the wrap masks.  The first round's trajectory is never the accepted one
+// (its start nodes are the nominal ramp), so it skips the 8 bytes per sample.
+//
+// One lane integrates one chunk, so lane l's sample i sits c_pll doubles away from lane l+1's: read or written straight
+// from the loop, every wave instruction touches 64 cache lines.  Measured (round 2, SQ / TA counters): the second pass
+// spent 14 us per SIMD in its VALU and the rest of its 80 us waiting for the acknowledgement of such stores (gfx9 has one
+// in-order counter for loads and stores, so the wait for the next samples is a wait for the last stores).  Samples
+// therefore cross between HBM and the lanes through an LDS tile: the wave loads T samples of each of its 64 chunks
+// with row-contiguous instructions (half a wave per chunk), every lane then walks its own row, the results overwrite
+// the inputs in place, and the tile leaves the same way.  No global access inside the sample loop.
+template <bool JAC, bool WOUT>
 __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ base, long long base_stride, int base_off, ChunkTab ct,
                             double *__restrict__ raw, long long raw_stride, int raw_off,
                             const float *__restrict__ atan_tab, PllConst pc, int pilot_shift,
@@ -880,53 +893,93 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
                             int *__restrict__ ck_wraps, unsigned long long *__restrict__ ck_mask, int mask_words,
                             IterFlags *__restrict__ fl, double *__restrict__ wg_r,
                             PllSync *__restrict__ sync, double tol, double rtol, int have_d) {
+  constexpr int T = 32, TP = T + 1;          // tile: 64 rows of T samples, one pad word pair per row
+#ifdef FMR_PLL_TRACE   // diagnostic build: where and when every workgroup ran (tools/pll_trace.py reads the dump)
+  const unsigned long long trace_t0 = __builtin_readcyclecounter(), trace_w0 = wall_clock64();
+#endif
   __shared__ float tab[257];
+  __shared__ double xs[64 * TP];
+  __shared__ int s_off[64], s_len[64];
+  static_assert(64 * TP >= 64 * 25, "the tile also carries the Jacobians out, 25 elements per lane at a time");
   for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
-  __syncthreads();
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x;
+  const int c = blockIdx.x * blockDim.x + lane;
   const int s = blockIdx.y;
   if (fl[s].pll_converged) return;          // uniform: every workgroup of the stream leaves
   const bool valid = c < ct.nck;
+  const int cc = valid ? c : ct.nck - 1;
+  const int n = valid ? ct.len[cc] : 0;
+  const int off = ct.off[cc];
+  s_off[lane] = off; s_len[lane] = n;
+  int nmax = n;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  const double *xb = base + (long long)s * base_stride + base_off;
+  double *ob = raw + (long long)s * raw_stride + raw_off;
   double rmax = 0.0;
-  if (valid) {
-    const double *xin = base + (long long)s * base_stride + base_off + ct.off[c];
-    double *out = raw + (long long)s * raw_stride + raw_off + ct.off[c];
-    const int n = ct.len[c];
-    PllRegs S;
-    const double *nd = nodes + ((long long)s * (ct.nck + 1) + c) * 7;
+  PllRegs S;
+  const double *nd = nodes + ((long long)s * (ct.nck + 1) + cc) * 7;
 #pragma unroll
-    for (int k = 0; k < 7; k++) S.v[k] = nd[k];
-    S.li = 0.0; S.lq = 0.0; S.freq_err = 0.0;
-    double Mx[7][7];
+  for (int k = 0; k < 7; k++) S.v[k] = nd[k];
+  S.li = 0.0; S.lq = 0.0; S.freq_err = 0.0;
+  double Mx[7][7];
 #pragma unroll
-    for (int r = 0; r < 7; r++)
+  for (int r = 0; r < 7; r++)
 #pragma unroll
-      for (int k = 0; k < 7; k++) Mx[r][k] = (r == k) ? 1.0 : 0.0;
-    int wraps = 0;
-    // positions of the phase wraps inside the chunk (bit i = sample i wrapped): lets the
-    // finish pass place a PPS event without re-integrating the chunk
-    unsigned long long *mk = ck_mask + ((long long)s * ct.nck + c) * mask_words;
-    unsigned long long word = 0;
-    serial_prefetch<4>(xin, 0, n, [&](int i, double xv) {
+    for (int k = 0; k < 7; k++) Mx[r][k] = (r == k) ? 1.0 : 0.0;
+  int wraps = 0;
+  // positions of the phase wraps inside the chunk (bit i = sample i wrapped): lets the
+  // finish pass place a PPS event without re-integrating the chunk
+  unsigned long long *mk = ck_mask + ((long long)s * ct.nck + cc) * mask_words;
+  unsigned long long word = 0;
+  const int half = lane >> 5, l5 = lane & 31;
+  for (int t0 = 0; t0 < nmax; t0 += T) {
+    __syncthreads();
+    // tile in: lanes 0-31 take chunk j, lanes 32-63 chunk j+1 (clamped addresses instead of predicates: loads under a
+    // branch make the compiler wait for each of them)
+    // (all loads of a tile in flight at once: one memory latency per tile; the Jacobian variant has no registers to spare)
+    constexpr int NLD = JAC ? 8 : 32;
+#pragma unroll 1
+    for (int j0 = 0; j0 < 64; j0 += 2 * NLD) {
+      double v[NLD];
+#pragma unroll
+      for (int u = 0; u < NLD; u++) {
+        const int jj = j0 + 2 * u + half;
+        const int o0 = s_off[jj], last = o0 + s_len[jj] - 1;
+        v[u] = xb[max(0, min(o0 + t0 + l5, last))];
+      }
+#pragma unroll
+      for (int u = 0; u < NLD; u++) xs[(j0 + 2 * u + half) * TP + l5] = v[u];
+    }
+    __syncthreads();
+    const int m = min(T, n - t0);
+    double *row = xs + lane * TP;
+    for (int i = 0; i < m; i++) {
       double o;
-      const int wflag = pll_step<JAC>(S, xv, pc, tab, pilot_shift, o, Mx);
+      const int wflag = pll_step<JAC>(S, row[i], pc, tab, pilot_shift, o, Mx);
       wraps += wflag;
-      word |= (unsigned long long)wflag << (i & 63);
-      if ((i & 63) == 63) { mk[i >> 6] = word; word = 0; }
-      out[i] = o;
-    });
-    if (n & 63) mk[n >> 6] = word;
+      if (WOUT) {
+        const int gi = t0 + i;
+        word |= (unsigned long long)wflag << (gi & 63);
+        if ((gi & 63) == 63) { mk[gi >> 6] = word; word = 0; }
+        row[i] = o;
+      }
+    }
+    if (WOUT) {
+      __syncthreads();
+#pragma unroll 8
+      for (int j = 0; j < 64; j += 2) {
+        const int jj = j + half;
+        if (l5 < s_len[jj] - t0) ob[s_off[jj] + t0 + l5] = xs[jj * TP + l5];
+      }
+    }
+  }
+  if (valid) {
+    if (WOUT && (n & 63)) mk[n >> 6] = word;
     double *g = G + ((long long)s * ct.nck + c) * 9;
 #pragma unroll
     for (int k = 0; k < 7; k++) g[k] = S.v[k];
     g[7] = pll_level(S); g[8] = S.freq_err;
-    if (JAC) {   // JAC == false: frozen-Jacobian round, the stored M of the last JAC round stands
-      double *m = M + ((long long)s * ct.nck + c) * 49;
-#pragma unroll
-      for (int r = 0; r < 7; r++)
-#pragma unroll
-        for (int k = 0; k < 7; k++) m[r * 7 + k] = Mx[r][k];
-    }
     ck_wraps[(long long)s * ct.nck + c] = wraps;
     // scaled mismatch against the start node of the next chunk (same scales as the node pass);
     // the call's end node has no consumer
@@ -939,6 +992,36 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
       for (int k = 3; k < 7; k++) rmax = fmax(rmax, fabs(S.v[k] - nd[7 + k]) * wsc);
     }
   }
+  if (JAC) {   // JAC == false: frozen-Jacobian round, the stored M of the last JAC round stands
+    // the wave's Jacobians are one contiguous block of 64 x 49 doubles: through the tile, 25 + 24 elements per lane, so
+    // that a store instruction covers two or three rows instead of 64 (row-per-lane stores are issue-bound in the TA)
+    double *mb = M + ((long long)s * ct.nck + (long long)blockIdx.x * 64) * 49;
+    const int rows = min(64, ct.nck - blockIdx.x * 64);
+    auto part = [&](auto e0c, auto nec) {
+      constexpr int E0 = decltype(e0c)::value, NE = decltype(nec)::value;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < NE; e++) xs[lane * 25 + e] = Mx[(E0 + e) / 7][(E0 + e) % 7];
+      __syncthreads();
+#pragma unroll 5
+      for (int it = 0; it < NE; it++) {
+        const int q = it * 64 + lane, r = q / NE, e = q - r * NE;
+        if (r < rows) mb[r * 49 + E0 + e] = xs[r * 25 + e];
+      }
+    };
+    part(std::integral_constant<int, 0>{}, std::integral_constant<int, 25>{});
+    part(std::integral_constant<int, 25>{}, std::integral_constant<int, 24>{});
+  }
+#ifdef FMR_PLL_TRACE
+  if (threadIdx.x == 0 && (JAC || WOUT)) {
+    unsigned int hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long *tr = (unsigned long long *)wg_r + (((long long)s * gridDim.x + blockIdx.x) * 2 + (JAC ? 0 : 1)) * 4;
+    tr[0] = trace_w0; tr[1] = __builtin_readcyclecounter() - trace_t0; tr[2] = ((unsigned long long)xcc << 32) | hw;
+    tr[3] = wall_clock64();
+  }
+#endif
   // per-workgroup maximum; k_pll_check (next launch) reduces them and may accept the round on the
   // mismatch alone, which skips this round's node pass
 #pragma unroll
@@ -950,7 +1033,7 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
   // three-kernel form: maxima through 64 slots; the stream's last workgroup does the round's bookkeeping
   PllSync &Y = sync[s];
   if (threadIdx.x == 0) atomicMax(&Y.rslot[blockIdx.x & 63], pll_max_bits(rmax));
-  if (pll_last_arrival(&Y.tick_shoot, gridDim.x)) pll_round_check(fl[s], Y, tol, rtol, have_d);
+  if (pll_last_arrival(&Y.tick_shoot, gridDim.x)) pll_round_check(fl[s], Y, tol, rtol, have_d, WOUT);
 }
 
 // ---------------------------------------------------------------------------
