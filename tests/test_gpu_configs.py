@@ -302,3 +302,44 @@ def test_fused_and_three_kernel_front_ends_agree_on_random_partitions(seed, monk
     assert al_a == al_b and lk_a == lk_b and pp_a == pp_b
     assert lk_a[-1] == (1, 1)
     assert rms(a0 - b0) < 1e-6 and rms(a1 - b1) < 1e-6
+
+
+@pytest.mark.parametrize("knobs", [
+    {"FMR_PLL_V1": "1"},                                   # seven launches per Newton round instead of three
+    {"FMR_ORDER_V1": "1", "FMR_MONO_FIRST": "1"},          # round-2 enqueue order (markers on the decoder stream)
+    {"FMR_NO_SPLIT": "1"},                                 # both audio tails on the decoder stream
+    {"FMR_AGC_LATE": "1"},                                 # side stream gated on the statistics kernel
+])
+def test_launch_structure_switches_do_not_change_the_result(knobs, monkeypatch):
+    """The three-launch PLL round (last-arrival tickets, prefix composites, atomicMax slots) and the marker-free stream
+    order must decode what the plain forms decode: same stream, ragged blocks, several calls (cold start, acquisition
+    with the serial fallback, lock, steady state), once by default and once with the ablation switch.  The node pass
+    composes its affine maps in a different order in the two PLL forms, so the start states of the accepted
+    trajectory may differ below the acceptance threshold (1e-6 rad): audio within 1e-7 RMS, everything discrete equal."""
+    rng = np.random.default_rng(5)
+    lens = [int(rng.integers(2000, 65537)) for _ in range(40)] + [65536] * 100
+    n = sum(lens)
+    x = siggen.fm_stereo_iq(n, 10e6, stream_id=3)[None, :]
+    calls = [lens[0:3], lens[3:40], lens[40:41], lens[41:90], lens[90:140]]
+
+    def run():
+        ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, n_streams=1,
+                       max_block_len=65536, max_blocks=50)
+        out, alens, st, pos = [], [], [], 0
+        for ll in calls:
+            m = sum(ll)
+            a, alen = ch.process_blocks(x[:, pos:pos + m], ll)
+            out.append(a[0]); alens += list(alen); pos += m
+            s = ch.status(0)
+            st.append((s.stereo_detected, s.pll_iterations, s.pll_fallback, s.agc_fallback,
+                       [(e[0], e[1], e[3]) for e in ch.pps_events(0)]))
+        ch.close()
+        return np.concatenate(out), alens, st
+
+    a, al_a, st_a = run()
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    b, al_b, st_b = run()
+    assert al_a == al_b and st_a == st_b
+    assert st_a[-1][0] == 1 and st_a[-1][2] == 0
+    assert rms(a - b) < 1e-7
