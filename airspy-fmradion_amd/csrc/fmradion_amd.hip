@@ -159,6 +159,7 @@ struct fmr_chain {
   hipStream_t side = nullptr, side2 = nullptr;   // side2: the IF AGC when it is off the critical path
   hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr,
              ev_tab = nullptr, ev_mono = nullptr;
+  int pll_tick2_per_stream = 0;
   bool ev_agc_live = false;            // ev_agc has been recorded by an earlier call
   // designs + counters
   ResamplerDesign rs, ars;
@@ -642,6 +643,7 @@ int fmr_chain::init(const fmr_config *c) {
       if ((rc = d_pll_pre.alloc((size_t)S * max_grp * 56))) return rc;
       if ((rc = d_pll_sync.alloc((size_t)S))) return rc;               // zeroed here; the kernels leave it zeroed
       if ((rc = d_pll_tick2.alloc((size_t)S * max_grp2))) return rc;
+      pll_tick2_per_stream = (int)max_grp2;
     }
     mask_words = (std::max(c_pll, 128) + 63) / 64;   // wrap bit masks: one word per 64 samples of a chunk
     if ((rc = d_ck_mask.alloc((size_t)S * max_ck * mask_words))) return rc;
@@ -1066,7 +1068,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   if (iter_on_side) {
     if (ev_agc_live) HIPCHK(hipStreamWaitEvent(side, ev_agc, 0));
     const int nc = (int)((N_if + C_AGC - 1) / C_AGC);
-    hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, side, d_flags.p, d_agc_nodes.p, nc, d_state.p, S);
+    hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, side, d_flags.p, d_agc_nodes.p, nc, d_state.p, S,
+                       (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p, pll_tick2_per_stream);
   }
   HIPCHK(hipEventRecord(ev_tab, side));
   HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
@@ -1163,7 +1166,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   if (!iter_on_side)
     hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, stream, d_flags.p,
                        (serial_mode || enable_mpf) ? (float *)nullptr : d_agc_nodes.p,
-                       agc_nc, d_state.p, S);
+                       agc_nc, d_state.p, S, (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p,
+                       pll_tick2_per_stream);
   // With the equaliser on, the AGC'd amplitude feeds the constant-modulus error, and
   // the equaliser kernel is the serial bottleneck anyway: use the exact serial AGC.
   if (serial_mode || enable_mpf) {

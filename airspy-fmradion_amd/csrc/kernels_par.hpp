@@ -505,12 +505,19 @@ __global__ __launch_bounds__(1024) void k_agc_nodes(float *__restrict__ nodes, c
 }
 
 __global__ void k_iter_begin(IterFlags *fl, float *__restrict__ agc_nodes, int agc_nc, const StreamState *st,
-                             int n_streams) {
+                             int n_streams, unsigned long long *__restrict__ pll_sync, int sync_words,
+                             unsigned int *__restrict__ pll_tick2, int n_tick2) {
   const int s = blockIdx.x;
   if (s >= n_streams) return;
   if (threadIdx.x == 0) {
     fl[s] = IterFlags{};
     if (agc_nodes) agc_nodes[(long long)s * (agc_nc + 1)] = st[s].agc_gain;
+  }
+  // the PLL rounds' tickets and maximum slots (PllSync) are left at zero by the kernels that use them; a call that
+  // starts from anything else (an aborted call before it) would mistake its last arrivals, so they are zeroed anyway
+  if (pll_sync) {
+    for (int i = threadIdx.x; i < sync_words; i += blockDim.x) pll_sync[(long long)s * sync_words + i] = 0ull;
+    for (int i = threadIdx.x; i < n_tick2; i += blockDim.x) pll_tick2[(long long)s * n_tick2 + i] = 0u;
   }
   // initial guess: the carried gain everywhere
   if (agc_nodes) {
