@@ -325,6 +325,62 @@ struct fmr_chain {
   int pps_block_base = 0;               // blocks of the call that ran before the part whose PPS events the state holds
   int run_cold_aware(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
                      size_t astride, uint32_t *audio_len);
+  // values one call's stages hand each other (run() fills the head, every stage adds its part)
+  struct FusedGeom { long long mA_prev, kB_prev, n_prev; int count_mid; };
+  struct CallCtx {
+    const float2 *d_iq = nullptr;
+    size_t stride{};
+    const uint32_t *block_len = nullptr;
+    int nb{};
+    double *d_aud = nullptr;
+    size_t astride{};
+    uint32_t *audio_len = nullptr;
+    long long N_in{};
+    int slot{};
+    int *h_tab = nullptr;
+    int *d_tab_slot = nullptr;
+    int *t_if_off = nullptr;
+    int *t_if_len = nullptr;
+    int *t_au_off = nullptr;
+    int *t_au_len = nullptr;
+    int *t_mpf = nullptr;
+    long long N_if{};
+    bool use_fused{};
+    FusedGeom fused_geom{};
+    int par{};
+    float2 *ifbuf = nullptr;
+    HaloTable ht{};
+    long long N_au{};
+    bool any_mpf{};
+    long long amA_prev{};
+    long long akB_prev{};
+    long long an_prev{};
+    int nck{};
+    int fused_n_tiles{};
+    int fused_kb_ref{};
+    ChunkTab ct{};
+    bool iter_on_side{};
+    BlockTab bt{};
+    long long if_stride{};
+    bool rms_in_disc{};
+    const float2 *xin = nullptr;
+    long long x_stride{};
+    int x_off{};
+    const float *disc_gain = nullptr;
+    bool agc_on_side{};
+    bool agc_deferred{};
+    std::function<int(hipEvent_t)> enqueue_agc{};
+    bool done = false;                 // the front end found nothing to decode
+    void add_halo(void *buf, long long stride_e, int H, long long N) {   // history to move to the buffer heads at the end of the call
+      if (H > 0 && N > 0) ht.d[ht.n++] = HaloDesc{(unsigned long long *)buf, stride_e, H, (int)N};
+    }
+  };
+  int run_front_end(CallCtx &k);
+  int run_tables(CallCtx &k);
+  int run_if_stage(CallCtx &k);
+  int run_fm(CallCtx &k);
+  int run_nbfm(CallCtx &k);
+  int run_am(CallCtx &k);
   int run(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
           size_t astride, uint32_t *audio_len);
 };
@@ -810,15 +866,44 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   int *d_tab_slot = d_tab.p + (size_t)slot * tab_ints;
   int *t_if_off = h_tab, *t_if_len = h_tab + max_blocks, *t_au_off = h_tab + 2 * max_blocks,
       *t_au_len = h_tab + 3 * max_blocks, *t_mpf = h_tab + 4 * max_blocks;
+  // ---- the stages of one call share their per-call values through CallCtx (run_front_end ... run_am below)
+  CallCtx k{};
+  k.d_iq = d_iq; k.stride = stride; k.block_len = block_len; k.nb = nb; k.d_aud = d_aud; k.astride = astride;
+  k.audio_len = audio_len; k.N_in = N_in; k.slot = slot; k.h_tab = h_tab; k.d_tab_slot = d_tab_slot;
+  k.t_if_off = t_if_off; k.t_if_len = t_if_len; k.t_au_off = t_au_off; k.t_au_len = t_au_len; k.t_mpf = t_mpf;
+  if (int rc = run_front_end(k)) return rc;
+  if (k.done) return FMR_OK;
+  hp1 = std::chrono::steady_clock::now();
+  if (int rc = run_tables(k)) return rc;
+  hp2 = std::chrono::steady_clock::now();
+  if (int rc = run_if_stage(k)) return rc;
+  if (int rc = (mode == FMR_MODE_FM) ? run_fm(k) : (mode == FMR_MODE_NBFM) ? run_nbfm(k) : run_am(k)) return rc;
+  HaloTable &ht = k.ht;
+  if (ht.n) {
+    timed("shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht); });
+  }
+  if (pipelined) hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, stream, &h_marks[1], pipe_seq);
+  HIPCHK(hipGetLastError());
+  return FMR_OK;
+}
+
+// IfResampler (or the pass-through copy): input -> IF buffer, input history, first halo entries
+int fmr_chain::run_front_end(CallCtx &k) {
+  auto &d_iq = k.d_iq; auto &stride = k.stride; auto &block_len = k.block_len; auto &nb = k.nb;
+  auto &audio_len = k.audio_len; auto &N_in = k.N_in; auto &slot = k.slot; auto &t_if_off = k.t_if_off;
+  auto &t_if_len = k.t_if_len; auto &N_if = k.N_if; auto &use_fused = k.use_fused; auto &fused_geom = k.fused_geom;
+  auto &par = k.par; auto &ifbuf = k.ifbuf; auto &ht = k.ht;
+  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
   // ------------------------------------------------------------------ front end
-  long long N_if = 0, count_mid_call = 0;
-  bool use_fused = false;
-  struct { long long mA_prev, kB_prev, n_prev; int count_mid; } fused_geom{};
+  long long count_mid_call = 0;
+  N_if = 0;
+  use_fused = false;
+  fused_geom = FusedGeom{};
   // Cross-call pipelining: the front end of call N+1 (its own stream, its own IF buffer) runs
   // beside the decoder of call N, whose recurrence kernels leave most of the chip idle.
-  const int par = pipelined ? (if_parity = (if_parity + 1) % kPipe) : 0;
+  par = pipelined ? (if_parity = (if_parity + 1) % kPipe) : 0;
   hipStream_t fes = pipelined ? fe : stream;
-  float2 *ifbuf = pipelined ? d_if_pp[par].p : d_if.p;
+  ifbuf = pipelined ? d_if_pp[par].p : d_if.p;
   last_if = ifbuf;
   // The decoder that last read this IF buffer (kPipe calls ago) must be done before the front end refills it.
   // The host polls a counter that a one-thread kernel at the end of every decoder writes into pinned host memory:
@@ -962,11 +1047,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   }
   abs_in += (unsigned long long)N_in;
   last_n_if = N_if; last_nb = nb; last_n_au = 0;
-  HaloTable ht{};
+  ht = HaloTable{};
   ht.n = 0;
-  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) {
-    if (H > 0 && N > 0) ht.d[ht.n++] = HaloDesc{(unsigned long long *)buf, stride_e, H, (int)N};
-  };
   if (has_rs && pipelined) {
     if (count_mid_call > 0) {
       HaloTable hm{};
@@ -986,13 +1068,26 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if (has_dec && fir_enable) add_halo(ifbuf, H_if + (long long)max_if, H_if, N_if);
     if (ht.n) hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht);
     HIPCHK(hipGetLastError());
+    k.done = true;                      // nothing to decode this call
     return FMR_OK;
   }
+  return FMR_OK;
+}
+
+// per-call block / chunk tables on the side stream, then the fused front end (it needs the block table)
+int fmr_chain::run_tables(CallCtx &k) {
+  auto &d_iq = k.d_iq; auto &stride = k.stride; auto &nb = k.nb; auto &N_in = k.N_in; auto &slot = k.slot;
+  auto &h_tab = k.h_tab; auto &d_tab_slot = k.d_tab_slot; auto &t_if_off = k.t_if_off; auto &t_if_len = k.t_if_len;
+  auto &t_au_off = k.t_au_off; auto &t_au_len = k.t_au_len; auto &t_mpf = k.t_mpf; auto &N_if = k.N_if;
+  auto &use_fused = k.use_fused; auto &fused_geom = k.fused_geom; auto &par = k.par; auto &ifbuf = k.ifbuf;
+  auto &N_au = k.N_au; auto &any_mpf = k.any_mpf; auto &amA_prev = k.amA_prev; auto &akB_prev = k.akB_prev;
+  auto &an_prev = k.an_prev; auto &nck = k.nck; auto &fused_n_tiles = k.fused_n_tiles;
+  auto &fused_kb_ref = k.fused_kb_ref; auto &ct = k.ct; auto &iter_on_side = k.iter_on_side; auto &bt = k.bt;
+  auto &if_stride = k.if_stride;
   // --------------------------------------------------------------- block tables
-  hp1 = std::chrono::steady_clock::now();
-  long long N_au = 0;
-  bool any_mpf = false;
-  const long long amA_prev = arsc.mA, akB_prev = arsc.kB, an_prev = arsc.n_in;
+  N_au = 0;
+  any_mpf = false;
+  amA_prev = arsc.mA; akB_prev = arsc.kB; an_prev = arsc.n_in;
   for (int b = 0; b < nb; b++) {
     t_mpf[b] = 0;
     t_au_off[b] = (int)N_au;
@@ -1014,7 +1109,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   // The per-chunk arrays (off, len, blk) are filled on the device from the block table; the
   // host only sends 6*max_blocks+1 ints per call.
   int *t_first = h_tab + 5 * (size_t)max_blocks;
-  int nck = 0;
+  nck = 0;
   for (int b = 0; b < nb; b++) {
     t_first[b] = nck;
     nck += (t_if_len[b] + c_pll - 1) / c_pll;
@@ -1026,7 +1121,8 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   // Table kernels and the PLL's initial node guess run on the side stream, beside the front end.
   hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((head_ints + 255) / 256)), dim3(256), 0, side,
                      (const int *)h_tab, d_tab_slot, (int)head_ints);
-  int fused_grid = 0, fused_tiles_per_wg = 0, fused_n_tiles = 0, fused_kb_ref = 0;
+  int fused_grid = 0, fused_tiles_per_wg = 0;
+  fused_n_tiles = 0; fused_kb_ref = 0;
   long long fused_T_first = 0;
   if (use_fused) {
     // one workgroup per CU: contiguous runs of macro tiles, the streams share the CUs.  The table's tail carries the
@@ -1050,7 +1146,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   }
   int *d_first = d_tab_slot + 5 * (size_t)max_blocks;
   int *d_ck = d_tab_slot + head_ints;
-  ChunkTab ct{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_first, nck};
+  ct = ChunkTab{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_first, nck};
   hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, side, &h_marks[0], call_seq);
   if (mode == FMR_MODE_FM && nck > 0) {
     hipLaunchKernelGGL(k_chunk_tab, dim3(nb), dim3(64), 0, side, d_tab_slot, d_tab_slot + max_blocks, d_first, c_pll,
@@ -1064,7 +1160,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   // FM without the equaliser: the round flags and the AGC's start nodes are reset here too, beside the front end (5-10 us
   // of the critical path when launched between the front end and the PLL's first pass).  Their last readers of the previous
   // call are the PLL kernels (ordered before this stream's k_pll_finish) and the side-stream AGC (ev_agc).
-  const bool iter_on_side = (mode == FMR_MODE_FM) && !serial_mode && !enable_mpf && !env.iter_v1;
+  iter_on_side = (mode == FMR_MODE_FM) && !serial_mode && !enable_mpf && !env.iter_v1;
   if (iter_on_side) {
     if (ev_agc_live) HIPCHK(hipStreamWaitEvent(side, ev_agc, 0));
     const int nc = (int)((N_if + C_AGC - 1) / C_AGC);
@@ -1073,9 +1169,9 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   }
   HIPCHK(hipEventRecord(ev_tab, side));
   HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
-  BlockTab bt{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
+  bt = BlockTab{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
               d_tab_slot + 4 * max_blocks, nb};
-  const long long if_stride = H_if + (long long)max_if;
+  if_stride = H_if + (long long)max_if;
   if (use_fused) {
     // ---- fused front end: needs the block table (per-block statistics), hence launched here, after the table copy
     constexpr int D = 10, NA = 151;
@@ -1125,7 +1221,15 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
         hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
       });
   }
-  hp2 = std::chrono::steady_clock::now();
+  return FMR_OK;
+}
+
+// IF-rate part common to all decoders: fine tuner, IF filter + level, IF AGC
+int fmr_chain::run_if_stage(CallCtx &k) {
+  auto &nb = k.nb; auto &N_if = k.N_if; auto &ifbuf = k.ifbuf; auto &iter_on_side = k.iter_on_side; auto &bt = k.bt;
+  auto &if_stride = k.if_stride; auto &rms_in_disc = k.rms_in_disc; auto &xin = k.xin; auto &x_stride = k.x_stride;
+  auto &x_off = k.x_off; auto &disc_gain = k.disc_gain; auto &agc_on_side = k.agc_on_side;
+  auto &agc_deferred = k.agc_deferred; auto &enqueue_agc = k.enqueue_agc;
   // ------------------------------------------------------- decoder, IF-rate part
   // SSB / WSPR: mix the new IF samples in place before the filter (the filter history in the halo is already mixed)
   if (ssb_like && d_ft_pre.p)
@@ -1134,7 +1238,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
                          480, ft_index, (float *)nullptr);
     });
   // FM without the IF FIR: the block RMS is taken inside the discriminator kernel (same samples, same lane order)
-  const bool rms_in_disc = (mode == FMR_MODE_FM) && !fir_enable && !serial_mode;
+  rms_in_disc = (mode == FMR_MODE_FM) && !fir_enable && !serial_mode;
   if (!rms_in_disc) {
     timed("fm_block", [&] {
       constexpr int TL = 1024;
@@ -1155,13 +1259,13 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     });
     ft_index = (unsigned)((ft_index + (unsigned long long)N_if) % 480u);
   }
-  const float2 *xin = fir_enable ? d_fir.p : ifbuf;
-  const long long x_stride = fir_enable ? (long long)max_if : if_stride;
-  const int x_off = fir_enable ? 0 : H_if;
+  xin = fir_enable ? d_fir.p : ifbuf;
+  x_stride = fir_enable ? (long long)max_if : if_stride;
+  x_off = fir_enable ? 0 : H_if;
   // ---- IF AGC: Newton multiple shooting over chunks of C_AGC samples (kernels_par.hpp)
-  const float *disc_gain = d_gain.p;      // gain sequence the discriminator multiplies in (nullptr = none)
-  bool agc_on_side = false, agc_deferred = false;
-  std::function<int(hipEvent_t)> enqueue_agc;      // argument: event that gates the side stream (null: a new marker on the main stream)
+  disc_gain = d_gain.p;      // gain sequence the discriminator multiplies in (nullptr = none)
+  agc_on_side = false; agc_deferred = false;
+  enqueue_agc = nullptr;      // argument: event that gates the side stream (null: a new marker on the main stream)
   const int agc_nc = (int)((N_if + C_AGC - 1) / C_AGC);
   if (!iter_on_side)
     hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, stream, d_flags.p,
@@ -1215,351 +1319,374 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
     if (agc_aside) { disc_gain = nullptr; agc_on_side = true; }
     if (!agc_deferred) { if (int rca = enqueue_agc(nullptr)) return rca; }
   }
-  if (mode == FMR_MODE_FM) {
-    if (any_mpf) {
-      const size_t lds = sizeof(float2) * ((size_t)2 * mpf_N + FMR_MPF_CH + 4);
-      const size_t lds3 = sizeof(float2) * ((size_t)mpf_N + FMR_MPF_CH + 8) + sizeof(float) * (FMR_MPF_CH / 4 + 2) +
-                          sizeof(float2) * (2 * 4 * 4 + FMR_MPF_CH);
-      timed("mpf", [&] {
-        auto go = [&](auto kern, int threads, size_t bytes) {
-          hipLaunchKernelGGL(kern, dim3(S), dim3(threads), bytes, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
-                             bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
-                             d_mpf_ok.p, d_state.p);
+  return FMR_OK;
+}
+
+// FmDecoder: equaliser, discriminator, statistics, pilot PLL, audio resampler + tail, DC block + mux
+int fmr_chain::run_fm(CallCtx &k) {
+  auto &d_iq = k.d_iq; auto &stride = k.stride; auto &nb = k.nb; auto &d_aud = k.d_aud; auto &astride = k.astride;
+  auto &audio_len = k.audio_len; auto &N_in = k.N_in; auto &t_au_len = k.t_au_len; auto &N_if = k.N_if;
+  auto &use_fused = k.use_fused; auto &ifbuf = k.ifbuf; auto &N_au = k.N_au; auto &any_mpf = k.any_mpf;
+  auto &amA_prev = k.amA_prev; auto &akB_prev = k.akB_prev; auto &an_prev = k.an_prev; auto &nck = k.nck;
+  auto &fused_n_tiles = k.fused_n_tiles; auto &fused_kb_ref = k.fused_kb_ref; auto &ct = k.ct; auto &bt = k.bt;
+  auto &if_stride = k.if_stride; auto &rms_in_disc = k.rms_in_disc; auto &xin = k.xin; auto &x_stride = k.x_stride;
+  auto &x_off = k.x_off; auto &disc_gain = k.disc_gain; auto &agc_on_side = k.agc_on_side;
+  auto &agc_deferred = k.agc_deferred; auto &enqueue_agc = k.enqueue_agc;
+  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
+  if (any_mpf) {
+    const size_t lds = sizeof(float2) * ((size_t)2 * mpf_N + FMR_MPF_CH + 4);
+    const size_t lds3 = sizeof(float2) * ((size_t)mpf_N + FMR_MPF_CH + 8) + sizeof(float) * (FMR_MPF_CH / 4 + 2) +
+                        sizeof(float2) * (2 * 4 * 4 + FMR_MPF_CH);
+    timed("mpf", [&] {
+      auto go = [&](auto kern, int threads, size_t bytes) {
+        hipLaunchKernelGGL(kern, dim3(S), dim3(threads), bytes, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
+                           bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
+                           d_mpf_ok.p, d_state.p);
+      };
+      // v3: four waves per stream (kernels.hpp); v2 (one wave, taps in registers) for FMR_MPF_V2=1, v1 for FMR_MPF_V1=1
+      if (env.mpf_v1) go(k_mpf, 64, lds);
+      else if (env.mpf_v2) {
+        if (mpf_N <= 64 * 5) go(k_mpf2<5>, 64, lds);
+        else if (mpf_N <= 64 * 10) go(k_mpf2<10>, 64, lds);
+        else go(k_mpf2<19>, 64, lds);
+      } else {
+        // FMR_MPF_NW = 1, 2, 4 waves per stream (4: product)
+        const int nw = env.mpf_nw;
+        auto pick = [&](auto nwc) {
+          constexpr int NWc = decltype(nwc)::value;
+          if (mpf_N <= 16 * NWc * (80 / NWc)) go(k_mpf3<NWc, 80 / NWc>, 64 * NWc, lds3);        // N <= 1280
+          else set_err("equaliser length out of range");
         };
-        // v3: four waves per stream (kernels.hpp); v2 (one wave, taps in registers) for FMR_MPF_V2=1, v1 for FMR_MPF_V1=1
-        if (env.mpf_v1) go(k_mpf, 64, lds);
-        else if (env.mpf_v2) {
-          if (mpf_N <= 64 * 5) go(k_mpf2<5>, 64, lds);
-          else if (mpf_N <= 64 * 10) go(k_mpf2<10>, 64, lds);
-          else go(k_mpf2<19>, 64, lds);
-        } else {
-          // FMR_MPF_NW = 1, 2, 4 waves per stream (4: product)
-          const int nw = env.mpf_nw;
-          auto pick = [&](auto nwc) {
-            constexpr int NWc = decltype(nwc)::value;
-            if (mpf_N <= 16 * NWc * (80 / NWc)) go(k_mpf3<NWc, 80 / NWc>, 64 * NWc, lds3);        // N <= 1280
-            else set_err("equaliser length out of range");
+        if (mpf_N <= 64 * 5 && nw == 4) go(k_mpf3<4, 5>, 256, lds3);
+        else if (mpf_N <= 64 * 5 && nw == 2) go(k_mpf3<2, 10>, 128, lds3);
+        else if (mpf_N <= 64 * 5 && nw == 1) go(k_mpf3<1, 20>, 64, lds3);
+        else if (mpf_N <= 64 * 10) go(k_mpf3<4, 10>, 256, lds3);
+        else pick(std::integral_constant<int, 4>{});
+      }
+    });
+  }
+  const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
+  const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
+  if (!use_fused)        // (the fused front end has already written the discriminator output and the block statistics)
+  timed("disc", [&] {
+    hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
+                       (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,
+                       disc_nf, disc_bound, d_dec.p, (long long)max_if, d_base.p, base_stride, H_b,
+                       d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p, rms_in_disc ? d_if_rms_blk.p : (float *)nullptr);
+  });
+  HIPCHK(hipEventRecord(ev_disc, stream));
+  HIPCHK(hipStreamWaitEvent(side, ev_disc, 0));
+  if (use_fused && !env.iter_v1)      // input history for the next call's front end: off the critical path (the next
+    timed_on(side, "in_halo", [&] {   // front end waits for this stream's table kernels anyway)
+      hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, side, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
+    });
+  timed_on(side, "stats", [&] {     // (fused front end: the block values are summed from its partial sums on the fly)
+    hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+                       d_bb_rms_blk.p, d_state.p, S, 1, use_fused ? d_fused_part.p : (const FusedPart *)nullptr,
+                       fused_n_tiles, fused_kb_ref);
+  });
+  HIPCHK(hipEventRecord(ev_stats, side));
+  bool fin_on_side = false, fin_covers_all = false;
+  const int nch = stereo ? 2 : 1;
+  // ---------------------------------------------------- audio resampler + tail
+  const int count_am = (int)(arsc.mA - amA_prev);
+  const long long am_stride = H_am + (long long)max_amid;
+  const long long a1_stride = H_pc + (long long)max_au;
+  if ((size_t)count_am > max_amid || (size_t)N_au > max_au) { set_err("internal audio capacity exceeded"); return FMR_ERR_CAPACITY; }
+  const long long a_top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
+  // fused de-emphasis + stage A: the tile (warm-up + (TOUT-1) D + NA samples) must fit BLOCK * LPL LDS slots
+  constexpr int DE_BLOCK = 256, DE_SLOTS = DE_BLOCK * FMR_DE_LPL;
+  // at most 4 * DE_BLOCK outputs per tile: every lane then owns exactly one run of 4 outputs in the FIR phase
+  const int de_tout = std::min(4 * DE_BLOCK, ((DE_SLOTS - FMR_DE_WARMUP - ars.NA - ars.D) / ars.D) & ~3);
+  const bool de_fused = !serial_mode && de_tout >= 64;
+  const int dc_nc = (int)((N_au + C_DC - 1) / C_DC);
+  DcCoef dk{};
+  dk.b0 = dcblock.b0; dk.b1 = dcblock.b1; dk.b2 = dcblock.b2; dk.a1 = dcblock.a1; dk.a2 = dcblock.a2;
+  for (int j = 0; j < 4; j++) dk.ac[j] = dc_ac[j];
+  for (int lv = 0; lv < 6; lv++) for (int j = 0; j < 4; j++) dk.agp[lv][j] = dc_agp[lv][j];
+  // Per-channel part of the audio tail (de-emphasis + audio resampler + pilot cut + DC-block pass 1) for channels
+  // ch_base .. ch_base + nch_l - 1.  Channel 0 (mono = L+R) does not depend on the PLL: with stereo on it runs on
+  // the AGC stream while the PLL iterates, and only L-R stays behind the PLL on the decoder stream.
+  auto enqueue_tail_channels = [&](hipStream_t st, int ch_base, int nch_l) {
+    if (de_fused) {
+      if (count_am > 0) {
+        timed_on(st, "deemph_decim", [&] {
+          const int tiles = (count_am + de_tout - 1) / de_tout;
+          const size_t lds = sizeof(double) * (size_t)(DE_SLOTS + DE_SLOTS / 16 + 1);
+          auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(tiles, S, nch_l), dim3(DE_BLOCK), lds, st, d_base.p, d_raw.p, base_stride, H_b,
+                               (int)N_if, deemph.b0, deemph.a1, de_scan, 1, (int)(stereo && !pilot_shift), d_ahA.p,
+                               ars.NA, ars.D, a_top0, count_am, de_tout, d_am0.p, d_am1.p, am_stride, H_am,
+                               debug_taps ? d_base_de.p : (double *)nullptr,
+                               debug_taps ? d_raw_de.p : (double *)nullptr, de_stride, H_a, ch_base);
           };
-          if (mpf_N <= 64 * 5 && nw == 4) go(k_mpf3<4, 5>, 256, lds3);
-          else if (mpf_N <= 64 * 5 && nw == 2) go(k_mpf3<2, 10>, 128, lds3);
-          else if (mpf_N <= 64 * 5 && nw == 1) go(k_mpf3<1, 20>, 64, lds3);
-          else if (mpf_N <= 64 * 10) go(k_mpf3<4, 10>, 256, lds3);
-          else pick(std::integral_constant<int, 4>{});
-        }
-      });
-    }
-    const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
-    const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
-    if (!use_fused)        // (the fused front end has already written the discriminator output and the block statistics)
-    timed("disc", [&] {
-      hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
-                         (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,
-                         disc_nf, disc_bound, d_dec.p, (long long)max_if, d_base.p, base_stride, H_b,
-                         d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p, rms_in_disc ? d_if_rms_blk.p : (float *)nullptr);
-    });
-    HIPCHK(hipEventRecord(ev_disc, stream));
-    HIPCHK(hipStreamWaitEvent(side, ev_disc, 0));
-    if (use_fused && !env.iter_v1)      // input history for the next call's front end: off the critical path (the next
-      timed_on(side, "in_halo", [&] {   // front end waits for this stream's table kernels anyway)
-        hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, side, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
-      });
-    timed_on(side, "stats", [&] {     // (fused front end: the block values are summed from its partial sums on the fly)
-      hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
-                         d_bb_rms_blk.p, d_state.p, S, 1, use_fused ? d_fused_part.p : (const FusedPart *)nullptr,
-                         fused_n_tiles, fused_kb_ref);
-    });
-    HIPCHK(hipEventRecord(ev_stats, side));
-    bool fin_on_side = false, fin_covers_all = false;
-    const int nch = stereo ? 2 : 1;
-    // ---------------------------------------------------- audio resampler + tail
-    const int count_am = (int)(arsc.mA - amA_prev);
-    const long long am_stride = H_am + (long long)max_amid;
-    const long long a1_stride = H_pc + (long long)max_au;
-    if ((size_t)count_am > max_amid || (size_t)N_au > max_au) { set_err("internal audio capacity exceeded"); return FMR_ERR_CAPACITY; }
-    const long long a_top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
-    // fused de-emphasis + stage A: the tile (warm-up + (TOUT-1) D + NA samples) must fit BLOCK * LPL LDS slots
-    constexpr int DE_BLOCK = 256, DE_SLOTS = DE_BLOCK * FMR_DE_LPL;
-    // at most 4 * DE_BLOCK outputs per tile: every lane then owns exactly one run of 4 outputs in the FIR phase
-    const int de_tout = std::min(4 * DE_BLOCK, ((DE_SLOTS - FMR_DE_WARMUP - ars.NA - ars.D) / ars.D) & ~3);
-    const bool de_fused = !serial_mode && de_tout >= 64;
-    const int dc_nc = (int)((N_au + C_DC - 1) / C_DC);
-    DcCoef dk{};
-    dk.b0 = dcblock.b0; dk.b1 = dcblock.b1; dk.b2 = dcblock.b2; dk.a1 = dcblock.a1; dk.a2 = dcblock.a2;
-    for (int j = 0; j < 4; j++) dk.ac[j] = dc_ac[j];
-    for (int lv = 0; lv < 6; lv++) for (int j = 0; j < 4; j++) dk.agp[lv][j] = dc_agp[lv][j];
-    // Per-channel part of the audio tail (de-emphasis + audio resampler + pilot cut + DC-block pass 1) for channels
-    // ch_base .. ch_base + nch_l - 1.  Channel 0 (mono = L+R) does not depend on the PLL: with stereo on it runs on
-    // the AGC stream while the PLL iterates, and only L-R stays behind the PLL on the decoder stream.
-    auto enqueue_tail_channels = [&](hipStream_t st, int ch_base, int nch_l) {
-      if (de_fused) {
-        if (count_am > 0) {
-          timed_on(st, "deemph_decim", [&] {
-            const int tiles = (count_am + de_tout - 1) / de_tout;
-            const size_t lds = sizeof(double) * (size_t)(DE_SLOTS + DE_SLOTS / 16 + 1);
-            auto go = [&](auto kern) {
-              hipLaunchKernelGGL(kern, dim3(tiles, S, nch_l), dim3(DE_BLOCK), lds, st, d_base.p, d_raw.p, base_stride, H_b,
-                                 (int)N_if, deemph.b0, deemph.a1, de_scan, 1, (int)(stereo && !pilot_shift), d_ahA.p,
-                                 ars.NA, ars.D, a_top0, count_am, de_tout, d_am0.p, d_am1.p, am_stride, H_am,
-                                 debug_taps ? d_base_de.p : (double *)nullptr,
-                                 debug_taps ? d_raw_de.p : (double *)nullptr, de_stride, H_a, ch_base);
-            };
-            if (ars.NA == 59 && ars.D == 3) go(k_deemph_decim<DE_BLOCK, 59, 3>);     // 384 kHz -> 48 kHz
-            else go(k_deemph_decim<DE_BLOCK, 0, 0>);
-          });
-        }
-      } else {
-        // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
-        timed_on(st, "deemph", [&] {
-          const int nt = (int)((N_if + C_DE - 1) / C_DE);
-          hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch_l), dim3(64), 0, st, d_base.p, d_raw.p,
-                             base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
-                             (int)(stereo && !pilot_shift));
-        });
-        if (count_am > 0) {
-          timed_on(st, "aud_decim", [&] {
-            hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch_l), dim3(128), 0, st, d_base_de.p,
-                               d_raw_de.p, de_stride, H_a, d_ahA.p, ars.NA, ars.D, a_top0, count_am, d_am0.p, d_am1.p,
-                               am_stride, H_am);
-          });
-        }
-      }
-      if (N_au > 0) {
-        timed_on(st, "aud_poly", [&] {
-          if (ars.LB == 3 && ars.MB == 8) {
-            // period form: one lane per period (3 outputs), taps through the scalar cache
-            constexpr int BLP = 256;
-            const long long P_first = akB_prev / 3, P_last = (akB_prev + N_au - 1) / 3;
-            const int tiles = (int)((P_last - P_first) / BLP + 1);
-            const int lx = (BLP - 1) * (int)ars.MB + (int)((2 * ars.MB) / 3) + ars.TB;
-            int ni_pad = (lx + (int)ars.MB - 1) / (int)ars.MB + 1;
-            if ((ni_pad & 1) == 0) ni_pad++;
-            hipLaunchKernelGGL((k_aud_poly2<BLP, 3, 8>), dim3(tiles, S, nch_l), dim3(BLP), sizeof(double) * (size_t)ars.MB * ni_pad,
-                               st, d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB,
-                               akB_prev, (int)N_au, d_a10.p, d_a11.p, a1_stride, H_pc, ni_pad, H_am + count_am, ch_base);
-          } else {
-            hipLaunchKernelGGL(k_aud_poly<128>, dim3((unsigned)((N_au + 127) / 128), S, nch_l), dim3(128), 0, st,
-                               d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB, (unsigned)ars.LB,
-                               (unsigned)ars.MB, (unsigned long long)akB_prev * ars.MB, (int)N_au, d_a10.p, d_a11.p,
-                               a1_stride, H_pc);
-          }
-        });
-        timed_on(st, "pilotcut", [&] {
-          if (n_pilotcut <= FMR_PCUT_MAXTAPS)
-            hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, nch_l), dim3(320), 0, st, d_a10.p, d_a11.p,
-                               a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au, 1.0, ch_base);
-          else
-            hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch_l), dim3(128), 0, st, d_a10.p, d_a11.p, a1_stride, H_pc,
-                               bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
+          if (ars.NA == 59 && ars.D == 3) go(k_deemph_decim<DE_BLOCK, 59, 3>);     // 384 kHz -> 48 kHz
+          else go(k_deemph_decim<DE_BLOCK, 0, 0>);
         });
       }
-      if (N_au > 0 && !serial_mode)
-        timed_on(st, "dc_pass1", [&] {
-          hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch_l), dim3(64), 0, st, d_pc0.p, d_pc1.p,
-                             (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc, ch_base);
+    } else {
+      // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
+      timed_on(st, "deemph", [&] {
+        const int nt = (int)((N_if + C_DE - 1) / C_DE);
+        hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch_l), dim3(64), 0, st, d_base.p, d_raw.p,
+                           base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
+                           (int)(stereo && !pilot_shift));
+      });
+      if (count_am > 0) {
+        timed_on(st, "aud_decim", [&] {
+          hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch_l), dim3(128), 0, st, d_base_de.p,
+                             d_raw_de.p, de_stride, H_a, d_ahA.p, ars.NA, ars.D, a_top0, count_am, d_am0.p, d_am1.p,
+                             am_stride, H_am);
         });
-    };
-    const bool split_mono = stereo && !serial_mode && de_fused && (ars.LB == 3 && ars.MB == 8) &&
-                            n_pilotcut <= FMR_PCUT_MAXTAPS && env.split_mono;
-    bool mono_enqueued = false;
-    if (stereo) {
-      if (serial_mode) {
-        timed("pll", [&] {
-          hipLaunchKernelGGL(k_pll, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt, d_raw.p,
-                             base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p, S);
-        });
-      } else {
-        // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
-        timed("pll", [&] {
-          const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
-          const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
-          const int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
-          for (int it = 0; it < pll_iters; it++) {
-            // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
-            // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
-            PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
-            auto shoot = [&](auto kern) {
-              hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p, base_stride, H_b, ct,
-                                 d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
-                                 d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
-                                 pll_rtol, (int)(it > 0));
-            };
-            // the first round writes no L-R samples unless it can be the accepted one (a call of one or two chunks)
-            const bool wout = it > 0 || env.pll_v1 || nck <= 2;
-            if (it < pll_jac_rounds) { if (wout) shoot(k_pll_shoot<true, true>); else shoot(k_pll_shoot<true, false>); }
-            else shoot(k_pll_shoot<false, true>);
-            if (it == 0 && agc_deferred) {
-              // side2: the AGC and the mono audio tail beside the PLL.  Gated on an event that
-              // exists already -- the front end's (ev_disc) or k_stats', which fires about when the first pass ends
-              // (FMR_AGC_LATE=1) -- because a marker of its own on this stream costs ~10 us between the first pass
-              // and the node pass (FMR_ORDER_V1=1: that marker).
-              agc_deferred = false;
-              hipEvent_t gate = env.iter_v1 ? nullptr : (env.agc_late ? ev_stats : ev_disc);
-              if (!gate) { (void)hipEventRecord(ev_if, stream); gate = ev_if; }
-              auto mono_aside = [&] {
-                (void)hipStreamWaitEvent(side2, gate, 0);
-                enqueue_tail_channels(side2, 0, 1);
-                (void)hipEventRecord(ev_mono, side2);
-                mono_enqueued = true;
-              };
-              if (split_mono && !env.agc_first) mono_aside();
-              if (enqueue_agc(gate)) return;
-              if (split_mono && env.agc_first) mono_aside();
-            }
-            if (env.pll_v1)
-              hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
-                                 (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
-            if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
-            if (!env.pll_v1) {
-              hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
-                                 d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p, d_flags.p, d_pll_sync.p,
-                                 d_pll_tick2.p);
-              hipLaunchKernelGGL(k_pll_down, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
-                                 d_pll_pre.p, d_pll_dstart2.p, ngrp2, d_flags.p, pllc.minfreq, pllc.maxfreq,
-                                 d_pll_sync.p);
-              continue;
-            }
-            hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
-                               nck, d_pll_PQ.p, d_flags.p);
-            hipLaunchKernelGGL(k_pll_nodes_a2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_PQ2.p,
-                               d_flags.p);
-            hipLaunchKernelGGL(k_pll_nodes_b, dim3(S), dim3(64), 0, stream, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p,
-                               d_flags.p);
-            hipLaunchKernelGGL(k_pll_nodes_c2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_dstart2.p,
-                               d_pll_dstart.p, d_flags.p);
-            hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
-                               nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
-          }
-          hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
-                             d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
-                             S, d_flags.p);
-        });
-        // lock logic / PPS / state commit beside the audio chain (needed again only by fm_out)
-        HIPCHK(hipEventRecord(ev_pll, stream));
-        HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
-        timed_on(side, "pll_finish", [&] {
-          hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, side, bt, ct, d_pll_G.p,
-                             d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
-          hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, side, d_base.p, base_stride, H_b, bt, ct, d_atan.p,
-                             pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
-                             d_blk_wraps.p, d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
-        });
-        // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
-        // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
-        if (agc_on_side && !agc_deferred && !env.iter_v1) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
-        HIPCHK(hipEventRecord(ev_fin, side));
-        fin_on_side = true;
       }
     }
-    if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr)) return rca; }   // PLL path not taken
-    if (mono_enqueued) enqueue_tail_channels(stream, 1, 1);
-    else enqueue_tail_channels(stream, 0, nch);
-    if (mono_enqueued) HIPCHK(hipStreamWaitEvent(stream, ev_mono, 0));   // DC-block node pass needs both channels
     if (N_au > 0) {
-      if (fin_on_side && (serial_mode || env.iter_v1)) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
-      if (serial_mode) {
-        timed("fm_out", [&] {
-          hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
-                             dcblock.b0, dcblock.b1, dcblock.b2, dcblock.a1, dcblock.a2, (int)stereo, (int)pilot_shift,
-                             d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
-        });
-      } else {
-        // ---- DC block by linear multiple shooting + output mux
-        timed("fm_out", [&] {
-          const int dc_nw = std::max(1, std::min(16, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
-          hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
-                             d_state.p, S, nch);
-          if (fin_on_side && !env.iter_v1) (void)hipStreamWaitEvent(stream, ev_fin, 0);   // only the mux needs the lock flags
-          hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
-                             (long long)max_au, bt, (int)N_au, dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,
-                             d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
-        });
-      }
-    }
-    if (fir_enable) add_halo(ifbuf, if_stride, H_if, N_if);
-    add_halo(d_base.p, base_stride, H_b, N_if);
-    if (stereo) add_halo(d_raw.p, base_stride, H_b, N_if);
-    add_halo(d_base_de.p, de_stride, H_a, N_if);
-    if (stereo) add_halo(d_raw_de.p, de_stride, H_a, N_if);
-    add_halo(d_am0.p, am_stride, H_am, count_am);
-    if (stereo) add_halo(d_am1.p, am_stride, H_am, count_am);
-    add_halo(d_a10.p, a1_stride, H_pc, N_au);
-    if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
-    if (!(fin_covers_all && N_au > 0)) {        // (otherwise the wait before the output mux covered all three)
-      HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
-      if (agc_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_agc, 0));
-      if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
-    }
-    if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
-  } else if (mode == FMR_MODE_NBFM) {
-    // NbfmDecoder (NbfmDecode.cpp:47-96): discriminator on the AGC'd IF, statistics, 63-tap audio FIR (same
-    // block-head path as the FM pilot cut: LowPassFilterFirAudio), -3 dB.  No resampling: audio block = IF block.
-    const long long base_stride = H_b + (long long)max_if;
-    timed("disc", [&] {
-      hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
-                         (long long)max_if, (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt, disc_nf, disc_bound,
-                         d_dec.p, (long long)max_if, d_base.p, base_stride, H_b, d_bb_mean_blk.p, d_bb_rms_blk.p,
-                         d_state.p, (float *)nullptr);
-    });
-    timed("stats", [&] {
-      hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
-                         d_bb_rms_blk.p, d_state.p, S, 1);
-    });
-    timed("nbfm_audio", [&] {
-      hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, 1), dim3(320), 0, stream, d_base.p, (double *)nullptr,
-                         base_stride, H_b, bt, d_pilotcut.p, n_pilotcut, d_aud, (double *)nullptr, (long long)astride,
-                         0.70794578438413791, 0);       // std::pow(10.0, -3.0 / 20.0), NbfmDecode.cpp:91
-    });
-    add_halo(ifbuf, if_stride, H_if, N_if);
-    add_halo(d_base.p, base_stride, H_b, N_if);
-    if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)t_au_len[b];
-  } else {
-    timed("am_demod", [&] {
-      hipLaunchKernelGGL(k_am_demod<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
-                         (long long)max_if, bt, (int)(mode != FMR_MODE_AM), d_dec.p, (long long)max_if, d_base.p,
-                         (long long)max_if, d_bb_mean_blk.p, d_bb_rms_blk.p);
-    });
-    timed("stats", [&] {
-      hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
-                         d_bb_rms_blk.p, d_state.p, S, 0);
-    });
-    timed("am_tail", [&] {
-      const bool par_tail = !serial_mode && !env.am_serial_tail;
-      if (par_tail) {
-        // DC block -> AfSimpleAgc -> de-emphasis in time-parallel form (kernels_par.hpp); the serial kernel below only
-        // runs for a stream whose Newton rounds did not converge
-        const int nc = (int)((N_if + C_AM - 1) / C_AM);
-        const AfAgcCoef af{1.0, 1.5, af_ref, af_rate};      // AfSimpleAgc(1.0, 1.5, reference, rate): AmDecode.cpp:54-66
-        hipLaunchKernelGGL(k_dc_pass1<C_AM>, dim3((nc + 63) / 64, S, 1), dim3(64), 0, stream, d_base.p, (const double *)nullptr,
-                           (long long)max_if, (int)N_if, am_dk, d_dc_G.p, nc, 0);
-        const int dc_nw = std::max(1, std::min(16, (nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
-        hipLaunchKernelGGL(k_dc_nodes, dim3(S), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, nc, am_dk, d_state.p, S, 0);
-        hipLaunchKernelGGL(k_af_begin, dim3(S), dim3(256), 0, stream, d_flags.p, d_af_nodes.p, nc, d_state.p);
-        for (int it = 0; it < K_AF_ITERS; it++) {
-          hipLaunchKernelGGL(k_af_shoot<C_AM>, dim3((nc + 63) / 64, S), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
-                             am_dk, d_dc_start.p, af, d_af_nodes.p, d_af_G.p, d_af_M.p, d_af_out.p, (long long)max_if, nc,
-                             d_state.p, d_flags.p);
-          hipLaunchKernelGGL(k_af_nodes, dim3(S), dim3(64), 0, stream, d_af_nodes.p, d_af_G.p, d_af_M.p, nc, d_state.p, d_flags.p);
+      timed_on(st, "aud_poly", [&] {
+        if (ars.LB == 3 && ars.MB == 8) {
+          // period form: one lane per period (3 outputs), taps through the scalar cache
+          constexpr int BLP = 256;
+          const long long P_first = akB_prev / 3, P_last = (akB_prev + N_au - 1) / 3;
+          const int tiles = (int)((P_last - P_first) / BLP + 1);
+          const int lx = (BLP - 1) * (int)ars.MB + (int)((2 * ars.MB) / 3) + ars.TB;
+          int ni_pad = (lx + (int)ars.MB - 1) / (int)ars.MB + 1;
+          if ((ni_pad & 1) == 0) ni_pad++;
+          hipLaunchKernelGGL((k_aud_poly2<BLP, 3, 8>), dim3(tiles, S, nch_l), dim3(BLP), sizeof(double) * (size_t)ars.MB * ni_pad,
+                             st, d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB,
+                             akB_prev, (int)N_au, d_a10.p, d_a11.p, a1_stride, H_pc, ni_pad, H_am + count_am, ch_base);
+        } else {
+          hipLaunchKernelGGL(k_aud_poly<128>, dim3((unsigned)((N_au + 127) / 128), S, nch_l), dim3(128), 0, st,
+                             d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB, (unsigned)ars.LB,
+                             (unsigned)ars.MB, (unsigned long long)akB_prev * ars.MB, (int)N_au, d_a10.p, d_a11.p,
+                             a1_stride, H_pc);
         }
-        const int ncd = (int)((N_if + C_AM_DE - 1) / C_AM_DE);
-        hipLaunchKernelGGL(k_am_deemph_out<C_AM_DE>, dim3((ncd + 63) / 64, S), dim3(64), 0, stream, d_af_out.p, (long long)max_if,
-                           (int)N_if, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
+      });
+      timed_on(st, "pilotcut", [&] {
+        if (n_pilotcut <= FMR_PCUT_MAXTAPS)
+          hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, nch_l), dim3(320), 0, st, d_a10.p, d_a11.p,
+                             a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au, 1.0, ch_base);
+        else
+          hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch_l), dim3(128), 0, st, d_a10.p, d_a11.p, a1_stride, H_pc,
+                             bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
+      });
+    }
+    if (N_au > 0 && !serial_mode)
+      timed_on(st, "dc_pass1", [&] {
+        hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch_l), dim3(64), 0, st, d_pc0.p, d_pc1.p,
+                           (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc, ch_base);
+      });
+  };
+  const bool split_mono = stereo && !serial_mode && de_fused && (ars.LB == 3 && ars.MB == 8) &&
+                          n_pilotcut <= FMR_PCUT_MAXTAPS && env.split_mono;
+  bool mono_enqueued = false;
+  if (stereo) {
+    if (serial_mode) {
+      timed("pll", [&] {
+        hipLaunchKernelGGL(k_pll, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt, d_raw.p,
+                           base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p, S);
+      });
+    } else {
+      // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
+      timed("pll", [&] {
+        const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
+        const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
+        const int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
+        for (int it = 0; it < pll_iters; it++) {
+          // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
+          // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
+          PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
+          auto shoot = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p, base_stride, H_b, ct,
+                               d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
+                               d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
+                               pll_rtol, (int)(it > 0));
+          };
+          // the first round writes no L-R samples unless it can be the accepted one (a call of one or two chunks)
+          const bool wout = it > 0 || env.pll_v1 || nck <= 2;
+          if (it < pll_jac_rounds) { if (wout) shoot(k_pll_shoot<true, true>); else shoot(k_pll_shoot<true, false>); }
+          else shoot(k_pll_shoot<false, true>);
+          if (it == 0 && agc_deferred) {
+            // side2: the AGC and the mono audio tail beside the PLL.  Gated on an event that
+            // exists already -- the front end's (ev_disc) or k_stats', which fires about when the first pass ends
+            // (FMR_AGC_LATE=1) -- because a marker of its own on this stream costs ~10 us between the first pass
+            // and the node pass (FMR_ORDER_V1=1: that marker).
+            agc_deferred = false;
+            hipEvent_t gate = env.iter_v1 ? nullptr : (env.agc_late ? ev_stats : ev_disc);
+            if (!gate) { (void)hipEventRecord(ev_if, stream); gate = ev_if; }
+            auto mono_aside = [&] {
+              (void)hipStreamWaitEvent(side2, gate, 0);
+              enqueue_tail_channels(side2, 0, 1);
+              (void)hipEventRecord(ev_mono, side2);
+              mono_enqueued = true;
+            };
+            if (split_mono && !env.agc_first) mono_aside();
+            if (enqueue_agc(gate)) return;
+            if (split_mono && env.agc_first) mono_aside();
+          }
+          if (env.pll_v1)
+            hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
+                               (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
+          if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
+          if (!env.pll_v1) {
+            hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
+                               d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p, d_flags.p, d_pll_sync.p,
+                               d_pll_tick2.p);
+            hipLaunchKernelGGL(k_pll_down, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
+                               d_pll_pre.p, d_pll_dstart2.p, ngrp2, d_flags.p, pllc.minfreq, pllc.maxfreq,
+                               d_pll_sync.p);
+            continue;
+          }
+          hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
+                             nck, d_pll_PQ.p, d_flags.p);
+          hipLaunchKernelGGL(k_pll_nodes_a2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_PQ2.p,
+                             d_flags.p);
+          hipLaunchKernelGGL(k_pll_nodes_b, dim3(S), dim3(64), 0, stream, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p,
+                             d_flags.p);
+          hipLaunchKernelGGL(k_pll_nodes_c2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_dstart2.p,
+                             d_pll_dstart.p, d_flags.p);
+          hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
+                             nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
+        }
+        hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
+                           d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
+                           S, d_flags.p);
+      });
+      // lock logic / PPS / state commit beside the audio chain (needed again only by fm_out)
+      HIPCHK(hipEventRecord(ev_pll, stream));
+      HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
+      timed_on(side, "pll_finish", [&] {
+        hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, side, bt, ct, d_pll_G.p,
+                           d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
+        hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, side, d_base.p, base_stride, H_b, bt, ct, d_atan.p,
+                           pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
+                           d_blk_wraps.p, d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
+      });
+      // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
+      // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
+      if (agc_on_side && !agc_deferred && !env.iter_v1) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
+      HIPCHK(hipEventRecord(ev_fin, side));
+      fin_on_side = true;
+    }
+  }
+  if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr)) return rca; }   // PLL path not taken
+  if (mono_enqueued) enqueue_tail_channels(stream, 1, 1);
+  else enqueue_tail_channels(stream, 0, nch);
+  if (mono_enqueued) HIPCHK(hipStreamWaitEvent(stream, ev_mono, 0));   // DC-block node pass needs both channels
+  if (N_au > 0) {
+    if (fin_on_side && (serial_mode || env.iter_v1)) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
+    if (serial_mode) {
+      timed("fm_out", [&] {
+        hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
+                           dcblock.b0, dcblock.b1, dcblock.b2, dcblock.a1, dcblock.a2, (int)stereo, (int)pilot_shift,
+                           d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
+      });
+    } else {
+      // ---- DC block by linear multiple shooting + output mux
+      timed("fm_out", [&] {
+        const int dc_nw = std::max(1, std::min(16, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
+        hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
+                           d_state.p, S, nch);
+        if (fin_on_side && !env.iter_v1) (void)hipStreamWaitEvent(stream, ev_fin, 0);   // only the mux needs the lock flags
+        hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
+                           (long long)max_au, bt, (int)N_au, dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,
+                           d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
+      });
+    }
+  }
+  if (fir_enable) add_halo(ifbuf, if_stride, H_if, N_if);
+  add_halo(d_base.p, base_stride, H_b, N_if);
+  if (stereo) add_halo(d_raw.p, base_stride, H_b, N_if);
+  add_halo(d_base_de.p, de_stride, H_a, N_if);
+  if (stereo) add_halo(d_raw_de.p, de_stride, H_a, N_if);
+  add_halo(d_am0.p, am_stride, H_am, count_am);
+  if (stereo) add_halo(d_am1.p, am_stride, H_am, count_am);
+  add_halo(d_a10.p, a1_stride, H_pc, N_au);
+  if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
+  if (!(fin_covers_all && N_au > 0)) {        // (otherwise the wait before the output mux covered all three)
+    HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
+    if (agc_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_agc, 0));
+    if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
+  }
+  if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
+  return FMR_OK;
+}
+
+// NbfmDecoder
+int fmr_chain::run_nbfm(CallCtx &k) {
+  auto &nb = k.nb; auto &d_aud = k.d_aud; auto &astride = k.astride; auto &audio_len = k.audio_len;
+  auto &t_au_len = k.t_au_len; auto &N_if = k.N_if; auto &ifbuf = k.ifbuf; auto &bt = k.bt;
+  auto &if_stride = k.if_stride; auto &xin = k.xin; auto &x_stride = k.x_stride; auto &x_off = k.x_off;
+  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
+  // NbfmDecoder (NbfmDecode.cpp:47-96): discriminator on the AGC'd IF, statistics, 63-tap audio FIR (same
+  // block-head path as the FM pilot cut: LowPassFilterFirAudio), -3 dB.  No resampling: audio block = IF block.
+  const long long base_stride = H_b + (long long)max_if;
+  timed("disc", [&] {
+    hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
+                       (long long)max_if, (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt, disc_nf, disc_bound,
+                       d_dec.p, (long long)max_if, d_base.p, base_stride, H_b, d_bb_mean_blk.p, d_bb_rms_blk.p,
+                       d_state.p, (float *)nullptr);
+  });
+  timed("stats", [&] {
+    hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+                       d_bb_rms_blk.p, d_state.p, S, 1);
+  });
+  timed("nbfm_audio", [&] {
+    hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, 1), dim3(320), 0, stream, d_base.p, (double *)nullptr,
+                       base_stride, H_b, bt, d_pilotcut.p, n_pilotcut, d_aud, (double *)nullptr, (long long)astride,
+                       0.70794578438413791, 0);       // std::pow(10.0, -3.0 / 20.0), NbfmDecode.cpp:91
+  });
+  add_halo(ifbuf, if_stride, H_if, N_if);
+  add_halo(d_base.p, base_stride, H_b, N_if);
+  if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)t_au_len[b];
+  return FMR_OK;
+}
+
+// AmDecoder (AM / DSB / USB / LSB / CW / WSPR)
+int fmr_chain::run_am(CallCtx &k) {
+  auto &nb = k.nb; auto &d_aud = k.d_aud; auto &astride = k.astride; auto &audio_len = k.audio_len;
+  auto &t_au_len = k.t_au_len; auto &N_if = k.N_if; auto &ifbuf = k.ifbuf; auto &bt = k.bt;
+  auto &if_stride = k.if_stride; auto &xin = k.xin; auto &x_stride = k.x_stride; auto &x_off = k.x_off;
+  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
+  timed("am_demod", [&] {
+    hipLaunchKernelGGL(k_am_demod<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
+                       (long long)max_if, bt, (int)(mode != FMR_MODE_AM), d_dec.p, (long long)max_if, d_base.p,
+                       (long long)max_if, d_bb_mean_blk.p, d_bb_rms_blk.p);
+  });
+  timed("stats", [&] {
+    hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+                       d_bb_rms_blk.p, d_state.p, S, 0);
+  });
+  timed("am_tail", [&] {
+    const bool par_tail = !serial_mode && !env.am_serial_tail;
+    if (par_tail) {
+      // DC block -> AfSimpleAgc -> de-emphasis in time-parallel form (kernels_par.hpp); the serial kernel below only
+      // runs for a stream whose Newton rounds did not converge
+      const int nc = (int)((N_if + C_AM - 1) / C_AM);
+      const AfAgcCoef af{1.0, 1.5, af_ref, af_rate};      // AfSimpleAgc(1.0, 1.5, reference, rate): AmDecode.cpp:54-66
+      hipLaunchKernelGGL(k_dc_pass1<C_AM>, dim3((nc + 63) / 64, S, 1), dim3(64), 0, stream, d_base.p, (const double *)nullptr,
+                         (long long)max_if, (int)N_if, am_dk, d_dc_G.p, nc, 0);
+      const int dc_nw = std::max(1, std::min(16, (nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
+      hipLaunchKernelGGL(k_dc_nodes, dim3(S), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, nc, am_dk, d_state.p, S, 0);
+      hipLaunchKernelGGL(k_af_begin, dim3(S), dim3(256), 0, stream, d_flags.p, d_af_nodes.p, nc, d_state.p);
+      for (int it = 0; it < K_AF_ITERS; it++) {
+        hipLaunchKernelGGL(k_af_shoot<C_AM>, dim3((nc + 63) / 64, S), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
+                           am_dk, d_dc_start.p, af, d_af_nodes.p, d_af_G.p, d_af_M.p, d_af_out.p, (long long)max_if, nc,
                            d_state.p, d_flags.p);
-        hipLaunchKernelGGL(k_am_commit, dim3((S + 63) / 64), dim3(64), 0, stream, d_state.p, d_flags.p, S);
+        hipLaunchKernelGGL(k_af_nodes, dim3(S), dim3(64), 0, stream, d_af_nodes.p, d_af_G.p, d_af_M.p, nc, d_state.p, d_flags.p);
       }
-      hipLaunchKernelGGL(k_am_tail, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
-                         am_dcblock.b0, am_dcblock.b1, am_dcblock.b2, am_dcblock.a1, am_dcblock.a2, 1.0, 1.5, af_ref,
-                         af_rate, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
-                         d_state.p, S, par_tail ? &d_flags.p->af_converged : (const int *)nullptr, (int)sizeof(IterFlags),
-                         par_tail ? &d_flags.p->af_fallback : (int *)nullptr);
-    });
-    add_halo(ifbuf, if_stride, H_if, N_if);
-    if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)t_au_len[b];
-  }
-  if (ht.n) {
-    timed("shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht); });
-  }
-  if (pipelined) hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, stream, &h_marks[1], pipe_seq);
-  HIPCHK(hipGetLastError());
+      const int ncd = (int)((N_if + C_AM_DE - 1) / C_AM_DE);
+      hipLaunchKernelGGL(k_am_deemph_out<C_AM_DE>, dim3((ncd + 63) / 64, S), dim3(64), 0, stream, d_af_out.p, (long long)max_if,
+                         (int)N_if, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
+                         d_state.p, d_flags.p);
+      hipLaunchKernelGGL(k_am_commit, dim3((S + 63) / 64), dim3(64), 0, stream, d_state.p, d_flags.p, S);
+    }
+    hipLaunchKernelGGL(k_am_tail, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
+                       am_dcblock.b0, am_dcblock.b1, am_dcblock.b2, am_dcblock.a1, am_dcblock.a2, 1.0, 1.5, af_ref,
+                       af_rate, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,
+                       d_state.p, S, par_tail ? &d_flags.p->af_converged : (const int *)nullptr, (int)sizeof(IterFlags),
+                       par_tail ? &d_flags.p->af_fallback : (int *)nullptr);
+  });
+  add_halo(ifbuf, if_stride, H_if, N_if);
+  if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)t_au_len[b];
   return FMR_OK;
 }
 
