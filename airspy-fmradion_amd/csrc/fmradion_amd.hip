@@ -379,6 +379,9 @@ struct fmr_chain {
   int run_tables(CallCtx &k);
   int run_if_stage(CallCtx &k);
   int run_fm(CallCtx &k);
+  int run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
+                 const std::function<void(hipStream_t, int, int)> &enqueue_tail_channels, bool &mono_enqueued,
+                 bool &fin_on_side, bool &fin_covers_all);
   int run_nbfm(CallCtx &k);
   int run_am(CallCtx &k);
   int run(const float2 *d_iq, size_t stride, const uint32_t *block_len, int nb, double *d_aud,
@@ -1322,6 +1325,102 @@ int fmr_chain::run_if_stage(CallCtx &k) {
   return FMR_OK;
 }
 
+// PilotPhaseLock: Newton multiple shooting over chunks (kernels_par.hpp); beside it, on side2, the IF AGC and the mono
+// audio tail; after it, on side, the lock logic.  tail(stream, first channel, channels) enqueues the per-channel audio tail.
+int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
+                          const std::function<void(hipStream_t, int, int)> &enqueue_tail_channels, bool &mono_enqueued,
+                          bool &fin_on_side, bool &fin_covers_all) {
+  auto &nb = k.nb; auto &N_if = k.N_if; auto &nck = k.nck; auto &ct = k.ct; auto &bt = k.bt; auto &agc_on_side = k.agc_on_side; auto &agc_deferred = k.agc_deferred; auto &enqueue_agc = k.enqueue_agc;
+  if (serial_mode) {
+    timed("pll", [&] {
+      hipLaunchKernelGGL(k_pll, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt, d_raw.p,
+                         base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p, S);
+    });
+  } else {
+    // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
+    timed("pll", [&] {
+      const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
+      const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
+      const int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
+      for (int it = 0; it < pll_iters; it++) {
+        // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
+        // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
+        PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
+        auto shoot = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p, base_stride, H_b, ct,
+                             d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
+                             d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
+                             pll_rtol, (int)(it > 0));
+        };
+        // the first round writes no L-R samples unless it can be the accepted one (a call of one or two chunks)
+        const bool wout = it > 0 || env.pll_v1 || nck <= 2;
+        if (it < pll_jac_rounds) { if (wout) shoot(k_pll_shoot<true, true>); else shoot(k_pll_shoot<true, false>); }
+        else shoot(k_pll_shoot<false, true>);
+        if (it == 0 && agc_deferred) {
+          // side2: the AGC and the mono audio tail beside the PLL.  Gated on an event that
+          // exists already -- the front end's (ev_disc) or k_stats', which fires about when the first pass ends
+          // (FMR_AGC_LATE=1) -- because a marker of its own on this stream costs ~10 us between the first pass
+          // and the node pass (FMR_ORDER_V1=1: that marker).
+          agc_deferred = false;
+          hipEvent_t gate = env.iter_v1 ? nullptr : (env.agc_late ? ev_stats : ev_disc);
+          if (!gate) { (void)hipEventRecord(ev_if, stream); gate = ev_if; }
+          auto mono_aside = [&] {
+            (void)hipStreamWaitEvent(side2, gate, 0);
+            enqueue_tail_channels(side2, 0, 1);
+            (void)hipEventRecord(ev_mono, side2);
+            mono_enqueued = true;
+          };
+          if (split_mono && !env.agc_first) mono_aside();
+          if (enqueue_agc(gate)) return;
+          if (split_mono && env.agc_first) mono_aside();
+        }
+        if (env.pll_v1)
+          hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
+                             (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
+        if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
+        if (!env.pll_v1) {
+          hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
+                             d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p, d_flags.p, d_pll_sync.p,
+                             d_pll_tick2.p);
+          hipLaunchKernelGGL(k_pll_down, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
+                             d_pll_pre.p, d_pll_dstart2.p, ngrp2, d_flags.p, pllc.minfreq, pllc.maxfreq,
+                             d_pll_sync.p);
+          continue;
+        }
+        hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
+                           nck, d_pll_PQ.p, d_flags.p);
+        hipLaunchKernelGGL(k_pll_nodes_a2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_PQ2.p,
+                           d_flags.p);
+        hipLaunchKernelGGL(k_pll_nodes_b, dim3(S), dim3(64), 0, stream, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p,
+                           d_flags.p);
+        hipLaunchKernelGGL(k_pll_nodes_c2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_dstart2.p,
+                           d_pll_dstart.p, d_flags.p);
+        hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
+                           nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
+      }
+      hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
+                         d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
+                         S, d_flags.p);
+    });
+    // lock logic / PPS / state commit beside the audio chain (needed again only by fm_out)
+    HIPCHK(hipEventRecord(ev_pll, stream));
+    HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
+    timed_on(side, "pll_finish", [&] {
+      hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, side, bt, ct, d_pll_G.p,
+                         d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
+      hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, side, d_base.p, base_stride, H_b, bt, ct, d_atan.p,
+                         pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
+                         d_blk_wraps.p, d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
+    });
+    // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
+    // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
+    if (agc_on_side && !agc_deferred && !env.iter_v1) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
+    HIPCHK(hipEventRecord(ev_fin, side));
+    fin_on_side = true;
+  }
+  return FMR_OK;
+}
+
 // FmDecoder: equaliser, discriminator, statistics, pilot PLL, audio resampler + tail, DC block + mux
 int fmr_chain::run_fm(CallCtx &k) {
   auto &d_iq = k.d_iq; auto &stride = k.stride; auto &nb = k.nb; auto &d_aud = k.d_aud; auto &astride = k.astride;
@@ -1479,93 +1578,7 @@ int fmr_chain::run_fm(CallCtx &k) {
                           n_pilotcut <= FMR_PCUT_MAXTAPS && env.split_mono;
   bool mono_enqueued = false;
   if (stereo) {
-    if (serial_mode) {
-      timed("pll", [&] {
-        hipLaunchKernelGGL(k_pll, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt, d_raw.p,
-                           base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p, S);
-      });
-    } else {
-      // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
-      timed("pll", [&] {
-        const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
-        const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
-        const int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
-        for (int it = 0; it < pll_iters; it++) {
-          // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
-          // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
-          PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
-          auto shoot = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p, base_stride, H_b, ct,
-                               d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
-                               d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
-                               pll_rtol, (int)(it > 0));
-          };
-          // the first round writes no L-R samples unless it can be the accepted one (a call of one or two chunks)
-          const bool wout = it > 0 || env.pll_v1 || nck <= 2;
-          if (it < pll_jac_rounds) { if (wout) shoot(k_pll_shoot<true, true>); else shoot(k_pll_shoot<true, false>); }
-          else shoot(k_pll_shoot<false, true>);
-          if (it == 0 && agc_deferred) {
-            // side2: the AGC and the mono audio tail beside the PLL.  Gated on an event that
-            // exists already -- the front end's (ev_disc) or k_stats', which fires about when the first pass ends
-            // (FMR_AGC_LATE=1) -- because a marker of its own on this stream costs ~10 us between the first pass
-            // and the node pass (FMR_ORDER_V1=1: that marker).
-            agc_deferred = false;
-            hipEvent_t gate = env.iter_v1 ? nullptr : (env.agc_late ? ev_stats : ev_disc);
-            if (!gate) { (void)hipEventRecord(ev_if, stream); gate = ev_if; }
-            auto mono_aside = [&] {
-              (void)hipStreamWaitEvent(side2, gate, 0);
-              enqueue_tail_channels(side2, 0, 1);
-              (void)hipEventRecord(ev_mono, side2);
-              mono_enqueued = true;
-            };
-            if (split_mono && !env.agc_first) mono_aside();
-            if (enqueue_agc(gate)) return;
-            if (split_mono && env.agc_first) mono_aside();
-          }
-          if (env.pll_v1)
-            hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
-                               (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
-          if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
-          if (!env.pll_v1) {
-            hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
-                               d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p, d_flags.p, d_pll_sync.p,
-                               d_pll_tick2.p);
-            hipLaunchKernelGGL(k_pll_down, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
-                               d_pll_pre.p, d_pll_dstart2.p, ngrp2, d_flags.p, pllc.minfreq, pllc.maxfreq,
-                               d_pll_sync.p);
-            continue;
-          }
-          hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
-                             nck, d_pll_PQ.p, d_flags.p);
-          hipLaunchKernelGGL(k_pll_nodes_a2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_PQ2.p,
-                             d_flags.p);
-          hipLaunchKernelGGL(k_pll_nodes_b, dim3(S), dim3(64), 0, stream, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p,
-                             d_flags.p);
-          hipLaunchKernelGGL(k_pll_nodes_c2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_dstart2.p,
-                             d_pll_dstart.p, d_flags.p);
-          hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
-                             nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
-        }
-        hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
-                           d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
-                           S, d_flags.p);
-      });
-      // lock logic / PPS / state commit beside the audio chain (needed again only by fm_out)
-      HIPCHK(hipEventRecord(ev_pll, stream));
-      HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
-      timed_on(side, "pll_finish", [&] {
-        hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, side, bt, ct, d_pll_G.p,
-                           d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
-        hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, side, d_base.p, base_stride, H_b, bt, ct, d_atan.p,
-                           pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
-                           d_blk_wraps.p, d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
-      });
-      // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
-      // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
-      if (agc_on_side && !agc_deferred && !env.iter_v1) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
-      HIPCHK(hipEventRecord(ev_fin, side));
-      fin_on_side = true;
-    }
+    if (int rcp = run_fm_pll(k, base_stride, split_mono, enqueue_tail_channels, mono_enqueued, fin_on_side, fin_covers_all)) return rcp;
   }
   if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr)) return rca; }   // PLL path not taken
   if (mono_enqueued) enqueue_tail_channels(stream, 1, 1);
