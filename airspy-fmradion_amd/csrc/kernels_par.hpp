@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(1024) void k_pll_check(IterFlags *fl, int n_streams
 // its second pass: 14 of the 23 launches of the seven-kernel form found pll_converged set and left -- ~70 us of a
 // 0.8 ms step.  Kernels are merged with the last-arrival pattern: a workgroup publishes its result, fences, takes a
 // ticket; whoever draws the last ticket of its set does the next level's work (no workgroup ever waits for another).
-//   k_pll_shoot2:  integration pass; the last workgroup of a stream does k_pll_check's bookkeeping
+//   k_pll_shoot:   integration pass; the last workgroup of a stream does k_pll_check's bookkeeping
 //   k_pll_up:      phase A; the last group of every level-2 set composes the set (A2) and stores the running prefix
 //                  composites on the way; the last set of a stream walks the level-2 maps (B)
 //   k_pll_down:    start delta of a group = its prefix composite applied to the set's start delta (replaces C2's
