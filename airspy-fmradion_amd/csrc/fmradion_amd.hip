@@ -1595,7 +1595,7 @@ int fmr_chain::run_fm(CallCtx &k) {
     } else {
       // ---- DC block by linear multiple shooting + output mux
       timed("fm_out", [&] {
-        const int dc_nw = std::max(1, std::min(16, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
+        const int dc_nw = std::max(1, std::min(FMR_DC_MAXW, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
         hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
                            d_state.p, S, nch);
         if (fin_on_side && !env.iter_v1) (void)hipStreamWaitEvent(stream, ev_fin, 0);   // only the mux needs the lock flags
@@ -1677,7 +1677,7 @@ int fmr_chain::run_am(CallCtx &k) {
       const AfAgcCoef af{1.0, 1.5, af_ref, af_rate};      // AfSimpleAgc(1.0, 1.5, reference, rate): AmDecode.cpp:54-66
       hipLaunchKernelGGL(k_dc_pass1<C_AM>, dim3((nc + 63) / 64, S, 1), dim3(64), 0, stream, d_base.p, (const double *)nullptr,
                          (long long)max_if, (int)N_if, am_dk, d_dc_G.p, nc, 0);
-      const int dc_nw = std::max(1, std::min(16, (nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
+      const int dc_nw = std::max(1, std::min(FMR_DC_MAXW, (nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
       hipLaunchKernelGGL(k_dc_nodes, dim3(S), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, nc, am_dk, d_state.p, S, 0);
       hipLaunchKernelGGL(k_af_begin, dim3(S), dim3(256), 0, stream, d_flags.p, d_af_nodes.p, nc, d_state.p);
       for (int it = 0; it < K_AF_ITERS; it++) {

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(BLOCK) void k_deemph_decim(
 // (FmDecode.cpp:194-220,242-283).
 // ---------------------------------------------------------------------------
 #define FMR_DC_K 32   // chunks per lane in the node pass
+#define FMR_DC_MAXW 8  // waves per workgroup of the node pass (each lane keeps its 2 K chunk values in registers)
 struct DcCoef {
   double b0, b1, b2, a1, a2;
   double ac[4];        // A^C row-major: state transition over one chunk
@@ -232,7 +233,7 @@ __device__ __forceinline__ void mv2(const double *m, double x1, double x2, doubl
   y1 = m[0] * x1 + m[1] * x2;
   y2 = m[2] * x1 + m[3] * x2;
 }
-__global__ __launch_bounds__(1024) void k_dc_nodes(const double *__restrict__ G, double *__restrict__ start, int nc,
+__global__ __launch_bounds__(64 * FMR_DC_MAXW) void k_dc_nodes(const double *__restrict__ G, double *__restrict__ start, int nc,
                                                     DcCoef k, StreamState *st, int n_streams, int nch) {
   // blockDim.x = 64 * NW: the NW waves take consecutive 64*K-chunk segments of a pass, scan them with a zero
   // carry in parallel, chain the NW segment totals (A^(C K 64) per segment) and replay with the true carries.
@@ -257,14 +258,23 @@ __global__ __launch_bounds__(1024) void k_dc_nodes(const double *__restrict__ G,
   }
   for (int c0 = 0; c0 < nc; c0 += 64 * K * NW) {
     const int cb = c0 + (wv * 64 + lane) * K;
+    // my K chunks' end vectors into registers, all loads in flight at once (clamped, not predicated): fetched one by one
+    // inside the fold and again inside the replay they were 2 K dependent memory latencies, 87 % of this kernel's time
+    double g1[K], g2[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const double2 gv = *reinterpret_cast<const double2 *>(g + 2 * (long long)min(cb + j, nc - 1));
+      g1[j] = gv.x; g2[j] = gv.y;
+    }
     // fold my K chunks from zero state
     double q1 = 0.0, q2 = 0.0;
+#pragma unroll
     for (int j = 0; j < K; j++) {
       const int c = cb + j;
       if (c < nc) {
         double n1, n2;
         mv2(k.ac, q1, q2, n1, n2);
-        q1 = n1 + g[2 * c]; q2 = n2 + g[2 * c + 1];
+        q1 = n1 + g1[j]; q2 = n2 + g2[j];
       }
       // past the end: identity step would need A^-C; lanes past nc are never read back
     }
@@ -297,13 +307,14 @@ __global__ __launch_bounds__(1024) void k_dc_nodes(const double *__restrict__ G,
       if (lane & (1 << lv)) { double m1, m2; mv2(k.agp[lv], t1, t2, m1, m2); t1 = m1; t2 = m2; }
     }
     double x1 = t1 + e1, x2 = t2 + e2;
+#pragma unroll
     for (int j = 0; j < K; j++) {
       const int c = cb + j;
       if (c < nc) {
-        o[2 * c] = x1; o[2 * c + 1] = x2;
+        *reinterpret_cast<double2 *>(o + 2 * (long long)c) = make_double2(x1, x2);
         double n1, n2;
         mv2(k.ac, x1, x2, n1, n2);
-        x1 = n1 + g[2 * c]; x2 = n2 + g[2 * c + 1];
+        x1 = n1 + g1[j]; x2 = n2 + g2[j];
       }
     }
     // carry into the next pass = state after the last chunk of the last lane (only used when the pass was full)
