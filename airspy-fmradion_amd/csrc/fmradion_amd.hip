@@ -893,7 +893,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
 // IfResampler (or the pass-through copy): input -> IF buffer, input history, first halo entries
 int fmr_chain::run_front_end(CallCtx &k) {
   auto &d_iq = k.d_iq; auto &stride = k.stride; auto &block_len = k.block_len; auto &nb = k.nb;
-  auto &audio_len = k.audio_len; auto &N_in = k.N_in; auto &slot = k.slot; auto &t_if_off = k.t_if_off;
+  auto &audio_len = k.audio_len; auto &N_in = k.N_in; auto &t_if_off = k.t_if_off;
   auto &t_if_len = k.t_if_len; auto &N_if = k.N_if; auto &use_fused = k.use_fused; auto &fused_geom = k.fused_geom;
   auto &par = k.par; auto &ifbuf = k.ifbuf; auto &ht = k.ht;
   auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
@@ -1079,10 +1079,10 @@ int fmr_chain::run_front_end(CallCtx &k) {
 
 // per-call block / chunk tables on the side stream, then the fused front end (it needs the block table)
 int fmr_chain::run_tables(CallCtx &k) {
-  auto &d_iq = k.d_iq; auto &stride = k.stride; auto &nb = k.nb; auto &N_in = k.N_in; auto &slot = k.slot;
+  auto &d_iq = k.d_iq; auto &stride = k.stride; auto &nb = k.nb; auto &N_in = k.N_in;
   auto &h_tab = k.h_tab; auto &d_tab_slot = k.d_tab_slot; auto &t_if_off = k.t_if_off; auto &t_if_len = k.t_if_len;
   auto &t_au_off = k.t_au_off; auto &t_au_len = k.t_au_len; auto &t_mpf = k.t_mpf; auto &N_if = k.N_if;
-  auto &use_fused = k.use_fused; auto &fused_geom = k.fused_geom; auto &par = k.par; auto &ifbuf = k.ifbuf;
+  auto &use_fused = k.use_fused; auto &fused_geom = k.fused_geom; auto &ifbuf = k.ifbuf;
   auto &N_au = k.N_au; auto &any_mpf = k.any_mpf; auto &amA_prev = k.amA_prev; auto &akB_prev = k.akB_prev;
   auto &an_prev = k.an_prev; auto &nck = k.nck; auto &fused_n_tiles = k.fused_n_tiles;
   auto &fused_kb_ref = k.fused_kb_ref; auto &ct = k.ct; auto &iter_on_side = k.iter_on_side; auto &bt = k.bt;
@@ -1426,8 +1426,8 @@ int fmr_chain::run_fm(CallCtx &k) {
   auto &d_iq = k.d_iq; auto &stride = k.stride; auto &nb = k.nb; auto &d_aud = k.d_aud; auto &astride = k.astride;
   auto &audio_len = k.audio_len; auto &N_in = k.N_in; auto &t_au_len = k.t_au_len; auto &N_if = k.N_if;
   auto &use_fused = k.use_fused; auto &ifbuf = k.ifbuf; auto &N_au = k.N_au; auto &any_mpf = k.any_mpf;
-  auto &amA_prev = k.amA_prev; auto &akB_prev = k.akB_prev; auto &an_prev = k.an_prev; auto &nck = k.nck;
-  auto &fused_n_tiles = k.fused_n_tiles; auto &fused_kb_ref = k.fused_kb_ref; auto &ct = k.ct; auto &bt = k.bt;
+  auto &amA_prev = k.amA_prev; auto &akB_prev = k.akB_prev; auto &an_prev = k.an_prev;
+  auto &fused_n_tiles = k.fused_n_tiles; auto &fused_kb_ref = k.fused_kb_ref; auto &bt = k.bt;
   auto &if_stride = k.if_stride; auto &rms_in_disc = k.rms_in_disc; auto &xin = k.xin; auto &x_stride = k.x_stride;
   auto &x_off = k.x_off; auto &disc_gain = k.disc_gain; auto &agc_on_side = k.agc_on_side;
   auto &agc_deferred = k.agc_deferred; auto &enqueue_agc = k.enqueue_agc;
