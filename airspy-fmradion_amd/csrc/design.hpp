@@ -43,6 +43,113 @@ inline long long gcd_ll(long long a, long long b) {
   return a < 0 ? -a : a;
 }
 
+// Parks-McClellan exchange for a type-I (odd length, symmetric) multiband FIR: the equiripple stage A of the IF-class
+// resampler ("Resampler specification").  Grid: band b contributes round((hi - lo) / delf) points from lo in
+// steps of delf = 0.5 / (16 (M + 1)), the last one moved onto hi; barycentric Lagrange interpolation in
+// x = cos(2 pi f); the exchange stops when the extremal errors agree to 1e-4 relative.  Band edges in cycles per sample.
+class ParksMcClellan {
+ public:
+  // returns false if the exchange did not settle within 100 steps
+  bool design(int N, const std::vector<double> &edges, const std::vector<double> &desired, const std::vector<double> &weight,
+              std::vector<double> &h) {
+    const int M = (N - 1) / 2;
+    r_ = M + 1;
+    const double delf = 0.5 / (16.0 * r_);
+    grid_.clear(); D_.clear(); W_.clear();
+    for (size_t b = 0; b < desired.size(); b++) {
+      const int k = (int)((edges[2 * b + 1] - edges[2 * b]) / delf + 0.5);
+      double f = edges[2 * b];
+      for (int i = 0; i < k; i++) { grid_.push_back(f); D_.push_back(desired[b]); W_.push_back(weight[b]); f += delf; }
+      if (k > 0) grid_.back() = edges[2 * b + 1];
+    }
+    const int gs = (int)grid_.size();
+    if (gs < r_ + 2) return false;
+    E_.assign(gs, 0.0);
+    ext_.resize(r_ + 1);
+    for (int i = 0; i <= r_; i++) ext_[i] = i * (gs - 1) / r_;
+    x_.resize(r_ + 1); y_.resize(r_ + 1); ad_.resize(r_ + 1);
+    bool settled = false;
+    for (int it = 0; it < 100 && !settled; it++) {
+      interpolant();
+      for (int i = 0; i < gs; i++) E_[i] = W_[i] * (D_[i] - response(grid_[i]));
+      exchange();
+      double mn = std::fabs(E_[ext_[0]]), mx = mn;
+      for (int i = 1; i <= r_; i++) { const double c = std::fabs(E_[ext_[i]]); mn = std::fmin(mn, c); mx = std::fmax(mx, c); }
+      settled = (mx - mn) / mx < 0.0001;
+    }
+    interpolant();
+    // frequency sampling: the response at i / N, i = 0 .. M, then the inverse cosine sum
+    std::vector<double> A(M + 1);
+    for (int i = 0; i <= M; i++) A[i] = response(double(i) / N);
+    h.assign(N, 0.0);
+    for (int n = 0; n <= M; n++) {
+      double val = A[0];
+      const double xx = 2.0 * M_PI * (n - M) / N;
+      for (int k = 1; k <= M; k++) val += 2.0 * A[k] * std::cos(xx * k);
+      h[n] = h[N - 1 - n] = val / N;
+    }
+    return settled;
+  }
+
+ private:
+  int r_ = 0;
+  std::vector<double> grid_, D_, W_, E_, x_, y_, ad_;
+  std::vector<int> ext_;
+
+  void interpolant() {
+    for (int i = 0; i <= r_; i++) x_[i] = std::cos(2.0 * M_PI * grid_[ext_[i]]);
+    const int ld = (r_ - 1) / 15 + 1;          // strided products keep the barycentric weights in range
+    for (int i = 0; i <= r_; i++) {
+      double denom = 1.0;
+      for (int j = 0; j < ld; j++)
+        for (int k = j; k <= r_; k += ld)
+          if (k != i) denom *= 2.0 * (x_[i] - x_[k]);
+      if (std::fabs(denom) < 1e-5) denom = 1e-5;
+      ad_[i] = 1.0 / denom;
+    }
+    double numer = 0.0, denom = 0.0, sign = 1.0;
+    for (int i = 0; i <= r_; i++) { numer += ad_[i] * D_[ext_[i]]; denom += sign * ad_[i] / W_[ext_[i]]; sign = -sign; }
+    const double delta = numer / denom;
+    sign = 1.0;
+    for (int i = 0; i <= r_; i++) { y_[i] = D_[ext_[i]] - sign * delta / W_[ext_[i]]; sign = -sign; }
+  }
+  double response(double f) const {
+    const double xc = std::cos(2.0 * M_PI * f);
+    double numer = 0.0, denom = 0.0;
+    for (int i = 0; i <= r_; i++) {
+      double c = xc - x_[i];
+      if (std::fabs(c) < 1.0e-7) return y_[i];
+      c = ad_[i] / c;
+      denom += c;
+      numer += c * y_[i];
+    }
+    return numer / denom;
+  }
+  void exchange() {
+    const int gs = (int)grid_.size();
+    std::vector<int> f;
+    const std::vector<double> &E = E_;
+    if ((E[0] > 0.0 && E[0] > E[1]) || (E[0] < 0.0 && E[0] < E[1])) f.push_back(0);
+    for (int i = 1; i < gs - 1; i++)
+      if ((E[i] >= E[i - 1] && E[i] > E[i + 1] && E[i] > 0.0) || (E[i] <= E[i - 1] && E[i] < E[i + 1] && E[i] < 0.0)) f.push_back(i);
+    if ((E[gs - 1] > 0.0 && E[gs - 1] > E[gs - 2]) || (E[gs - 1] < 0.0 && E[gs - 1] < E[gs - 2])) f.push_back(gs - 1);
+    while ((int)f.size() > r_ + 1) {
+      const int k = (int)f.size();
+      bool up = E[f[0]] > 0.0, alternating = true;
+      int l = 0;
+      for (int j = 1; j < k; j++) {
+        if (std::fabs(E[f[j]]) < std::fabs(E[f[l]])) l = j;
+        if (up && E[f[j]] < 0.0) up = false;
+        else if (!up && E[f[j]] > 0.0) up = true;
+        else { alternating = false; break; }      // two neighbours of one sign: drop the smaller seen so far
+      }
+      if (alternating && k - (r_ + 1) == 1) l = (std::fabs(E[f[k - 1]]) < std::fabs(E[f[0]])) ? k - 1 : 0;
+      f.erase(f.begin() + l);
+    }
+    for (int i = 0; i <= r_ && i < (int)f.size(); i++) ext_[i] = f[i];
+  }
+};
+
 struct ResamplerDesign {
   double in_rate = 0, out_rate = 0, atten = 0;
   long long L = 1, M = 1;
@@ -93,6 +200,29 @@ struct ResamplerDesign {
         sum += hA[k];
       }
       for (int k = 0; k < N; k++) hA[k] /= sum;
+      if (A <= 150.0 && D <= 78) {
+        // The IF class (float32 data, 140 dB): an equiripple stage A of 0.68 x the Kaiser length.  Pass band weight 1,
+        // stop bands k mid -+ fstop (k = 1 .. D / 2, cut at in / 2) weight 800, the bands between them free: what falls
+        // there is removed by stage B.  D = 2 .. 20: ripple <= 0.0010 dB peak to peak, aliases of the pass band
+        // <= -142 dB.  The Kaiser design stays if the exchange does not settle.
+        int NE = (int)std::ceil(0.68 * N);
+        if ((NE & 1) == 0) NE++;
+        std::vector<double> edges{0.0, fpass / in_rate}, des{1.0}, wt{1.0}, he;
+        for (int k = 1; k <= D / 2 && des.size() < 40; k++) {
+          const double lo = (k * mid - fstop) / in_rate;
+          double hi = (k * mid + fstop) / in_rate;
+          if (lo >= 0.5) break;
+          if (hi > 0.5) hi = 0.5;
+          edges.push_back(lo); edges.push_back(hi); des.push_back(0.0); wt.push_back(800.0);
+        }
+        ParksMcClellan pm;
+        if (pm.design(NE, edges, des, wt, he)) {
+          double se = 0;
+          for (double v : he) se += v;
+          for (double &v : he) v /= se;
+          hA = he; NA = NE;
+        }
+      }
     }
     const long long num = L * D, den = M;
     const long long g2 = gcd_ll(num, den);

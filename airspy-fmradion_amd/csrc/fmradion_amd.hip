@@ -520,9 +520,9 @@ int fmr_chain::init(const fmr_config *c) {
           poly4 = true;
           HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 125, 210>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-          // fused front end: the 10 MS/s shape (D = 10, NA = 151) with a symmetric stage-A filter; FM without IF FIR /
+          // fused front end: the 10 MS/s shape (D = 10, NA = 103) with a symmetric stage-A filter; FM without IF FIR /
           // equaliser (the discriminator then reads the IF directly), cf32 input, no Fs/4 shift
-          bool sym = rs.D == 10 && rs.NA == 151;
+          bool sym = rs.D == kFusedD && rs.NA == kFusedNA;
           for (int k = 0; sym && k < rs.NA / 2; k++) sym = (fa[k] == fa[rs.NA - 1 - k]);
           if (sym && mode == FMR_MODE_FM && !c->fmfilter_enable && c->multipath_stages == 0 && in_fmt == 0 &&
               !c->enable_fourth_down && !env.no_fused) {
@@ -530,9 +530,9 @@ int fmr_chain::init(const fmr_config *c) {
             for (int k = 0; k < rs.NA; k++) fused_taps.h[FUSED_TAP_PAD + k] = fa[k];
             if ((rc = upload(d_hB_last, fb.data() + (size_t)phi[47] * rs.TB, (size_t)rs.TB))) return rc;
             if ((rc = upload(d_fused_taps, fused_taps.h, (size_t)FUSED_TAP_LEN))) return rc;
-            constexpr int kL = FusedShape<10, 151>::LDS_BYTES;
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<10, 151, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<10, 151, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
+            constexpr int kL = FusedShape<kFusedD, kFusedNA>::LDS_BYTES;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
             fused_ok = true;
@@ -1177,7 +1177,7 @@ int fmr_chain::run_tables(CallCtx &k) {
   if_stride = H_if + (long long)max_if;
   if (use_fused) {
     // ---- fused front end: needs the block table (per-block statistics), hence launched here, after the table copy
-    constexpr int D = 10, NA = 151;
+    constexpr int D = kFusedD, NA = kFusedNA;
     FusedArgs a{};
     a.iq = d_iq; a.iq_stride = (long long)stride; a.n_valid = N_in;
     a.in_halo = d_in_halo.p; a.H_in = H_in; a.taps = d_fused_taps.p;
@@ -1185,7 +1185,7 @@ int fmr_chain::run_tables(CallCtx &k) {
     const long long lo0 = n0 + rs.ca() - (NA - 1);
     const int par = (int)(((lo0 % 2) + 2) % 2);
     a.nbase = lo0 - par;
-    constexpr int kME = FusedShape<10, 151>::ME, kEPT = FusedShape<10, 151>::EPT;
+    constexpr int kME = FusedShape<kFusedD, kFusedNA>::ME, kEPT = FusedShape<kFusedD, kFusedNA>::EPT;
     const long long T_first = fused_T_first, E_ref = kEPT * T_first - 1;
     a.j_ref = (int)(kME * E_ref + 104 - fused_geom.mA_prev);
     a.pos_ref = (int)((((kME * E_ref + 208) % 3000) + 3000) % 3000);

@@ -3,8 +3,8 @@
 // 384 kHz IF's second read) never goes through HBM.  Rows a1 + a7 (+ a3/a8 partial sums) of SURVEY.md 8a:
 // sfmbase/IfResampler.cpp:37-78, sfmbase/PhaseDiscriminator.cpp:33-46, sfmbase/FmDecode.cpp:95,141-150.
 //
-// Shape: the 10 MS/s class -- stage A D = 10, NA = 151 onto 1 MHz, followed by the LB/MB = 48/125, TB = 210
-// polyphase stage (the k_ifr_poly4 shape).
+// Shape: the 10 MS/s class -- stage A D = 10, NA = 103 (the equiripple design, design.hpp) onto 1 MHz, followed by the
+// LB/MB = 48/125, TB = 210 polyphase stage (the k_ifr_poly4 shape).
 //
 // One 768-lane workgroup per CU owns a CONTIGUOUS run of "macro tiles" (8 periods of stage B = 384 IF samples
 // = 1000 mid samples = 10 000 input samples) of one stream and walks it in EPOCHS of half a macro tile
@@ -65,6 +65,7 @@ struct FusedArgs {
 #endif
 // cycle counters only in the instrumented ablation builds (s_memtime costs ~100 cycles of latency per read)
 #define FUSED_CLK() (DBG ? __builtin_readcyclecounter() : 0ull)
+constexpr int kFusedD = 10, kFusedNA = 103;      // the shape the product instantiates (fmradion_amd.hip)
 #define FUSED_TAP_PAD 32
 #define FUSED_TAP_LEN 232
 // Stage-A taps travel in the kernel-argument segment (constant address space): every tap load is a scalar load.
@@ -355,8 +356,8 @@ __device__ __forceinline__ void fused_stage_a_half(const FusedArgs &a, const Fus
 }
 
 // ---- role: stage A, quad form (12-wave workgroup, FUSED_A_FORM = 2) ------------------------------------------
-// Four neighbouring lanes share four consecutive outputs: lane 4 g + q runs quarter q of the tap window (QS = 19 of
-// the 76 word steps) for outputs 4 g .. 4 g + 3, the quad adds its partial sums with two DPP steps and lane q stores
+// Four neighbouring lanes share four consecutive outputs: lane 4 g + q runs quarter q of the tap window (QS = 13 of
+// the 52 word steps for NA = 103; 19 of 76 for the 151-tap Kaiser design of round 2) for outputs 4 g .. 4 g + 3, the quad adds its partial sums with two DPP steps and lane q stores
 // output 4 g + q -- a wave stores 64 consecutive mid samples.  Why this shape (tools/bench_ldsread.hip,
 // tools/bench_pkfma.hip): a ds_read_b128 costs ~5.4 cycles of the CU's LDS pipe whether 16 or 64 lanes are active, and
 // one wave issues a packed FMA only every ~6 cycles.  Against three outputs on 42 lanes of a wave this form reads
@@ -369,7 +370,7 @@ struct FusedQuad {
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef float v4f __attribute__((ext_vector_type(4)));
   static constexpr int HD = D / 2, OQ = 4, NSTEP = (PAR + NA - 1) / 2 + 1, QS = NSTEP / 4, NW = QS + (OQ - 1) * HD;
-  static_assert(NSTEP % 4 == 0 && D == 10, "quarter windows of equal length; lane addresses 20 g + 19 q");
+  static_assert(NSTEP % 4 == 0 && D == 10 && (QS & 1) == 1, "quarter windows of equal length; lane addresses 20 g + QS q are distinct mod 16 over 16 lanes for odd QS");
   v2f tp[QS];                               // tap pair of step t of this lane's quarter: (even sample, odd sample) of the word
   __device__ __forceinline__ void load(const float *h, int q) {     // h = a.taps + FUSED_TAP_PAD (zero padded both sides)
 #pragma unroll
@@ -595,23 +596,30 @@ __device__ __forceinline__ float fused_atan2(float y, float x) {
   return r;
 }
 
-// The discriminator of one staged third (PhaseDiscriminator.cpp:33-46, FmDecode.cpp:141-150): lane l owns samples
-// idx0 + l and idx0 + 64 + l.  prev0 = normalised phase of the sample before idx0 (wave-uniform); save0 = the previous
-// call's last phase (m_save_value), which precedes the call's sample 0.
+// The discriminator of one staged third (PhaseDiscriminator.cpp:33-46, FmDecode.cpp:141-150): lane l owns the CONSECUTIVE
+// samples idx0 + 2 l and idx0 + 2 l + 1, so that the IF pair and the MPX pair leave as one 16-byte non-temporal store each
+// -- two store instructions per wave and third.  Under the input stream every store queues behind the loader's DMA in
+// the CU's memory pipeline: the stores, not the arithmetic, are what the epilogue costs (tools/bench_fused.hip, "no
+// global stores": 25 of 250 us; one sample per lane and store: 4 us more, plain instead of nt stores: 3 us more).
+// prev0 = normalised phase of the sample before idx0 (wave-uniform); save0 = the previous call's last phase
+// (m_save_value), which precedes the call's sample 0.
 template <int MT0, int ABL = 0>
 __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const float2 *stage, int kb, int tile_g, int &blk,
-                                               FusedBlkWin &win, float prev0, float save0, float2 *os, int lane) {
+                                                FusedBlkWin &win, float prev0, float save0, float2 *os, int lane) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  typedef v4f __attribute__((aligned(8))) v4f_u;
+  typedef v2d __attribute__((aligned(8))) v2d_u;
   const int idx0 = 128 * MT0, k0 = kb + idx0;
   if (k0 >= a.n_if || k0 + 128 <= 0) return;
-  const float2 x0 = stage[idx0 + lane], x1 = stage[idx0 + 64 + lane];
+  const v4f xx = reinterpret_cast<const v4f *>(stage + idx0)[lane];
+  const float2 x0 = make_float2(xx.x, xx.y), x1 = make_float2(xx.z, xx.w);
   const float inv_nf = 1.0f / a.nf;
   const float ph0 = (ABL & 64) ? x0.x : fused_atan2(x0.y, x0.x) * inv_nf, ph1 = (ABL & 64) ? x1.x : fused_atan2(x1.y, x1.x) * inv_nf;     // V4
-  auto shr1 = [](float v, float first) {       // lane l <- lane l - 1, lane 0 <- first   (DPP wave_shr:1, no LDS crossbar)
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xF, 0xF, false));
-  };
-  const float ph0_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ph0), 63));
-  float pv0 = shr1(ph0, prev0), pv1 = shr1(ph1, ph0_last);
-  const int ka = k0 + lane, kc = k0 + 64 + lane;
+  // phase of the sample before the lane's first one: lane l - 1's second sample (DPP wave_shr:1), lane 0 <- prev0
+  float pv0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(prev0), __float_as_int(ph1), 0x138, 0xF, 0xF, false));
+  float pv1 = ph0;
+  const int ka = k0 + 2 * lane, kc = ka + 1;
   if (ka == 0) pv0 = save0;
   if (kc == 0) pv1 = save0;
   auto diff = [&](float ph, float pv) {
@@ -624,8 +632,19 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
   const float d0 = diff(ph0, pv0), d1 = diff(ph1, pv1);
   const bool va = ka >= 0 && ka < a.n_if, vc = kc >= 0 && kc < a.n_if;
   double *bs = a.base + (long long)s * a.base_stride + a.base_off;
-  if (va && !((ABL & 128) && d0 != 12345.f)) { os[ka] = x0; bs[ka] = (double)d0; if (a.dec) a.dec[(long long)s * a.dec_stride + ka] = d0; }
-  if (vc && !((ABL & 128) && d1 != 12345.f)) { os[kc] = x1; bs[kc] = (double)d1; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
+  if (!((ABL & 128) && d0 != 12345.f)) {
+    if (va && vc) {
+      v4f_u *po = reinterpret_cast<v4f_u *>(os + ka);
+      v2d_u *pb = reinterpret_cast<v2d_u *>(bs + ka);
+      const v2d dd = {(double)d0, (double)d1};
+      __builtin_nontemporal_store(xx, po);
+      __builtin_nontemporal_store(dd, pb);
+      if (a.dec) { float *pd = a.dec + (long long)s * a.dec_stride + ka; pd[0] = d0; pd[1] = d1; }
+    } else {
+      if (va) { os[ka] = x0; bs[ka] = (double)d0; if (a.dec) a.dec[(long long)s * a.dec_stride + ka] = d0; }
+      if (vc) { os[kc] = x1; bs[kc] = (double)d1; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
+    }
+  }
   if (ka == a.n_if - 1) { a.st[s].disc_save_next = ph0; a.st[s].disc_save_valid = 1; }
   if (kc == a.n_if - 1) { a.st[s].disc_save_next = ph1; a.st[s].disc_save_valid = 1; }
   if ((ABL & 256) || k0 + 128 <= a.part_from) return;

@@ -3,6 +3,9 @@
 1. Taps.  Oracle (oracle/fmradion_oracle.c rs_design) and product (csrc/design.hpp, through fmr_design_taps -- host
    arithmetic, no GPU) implement the same formulas; here both are checked against scipy.signal (kaiserord / firwin /
    numpy.kaiser): an independent implementation of "Kaiser-windowed sinc, unit DC gain".  Tolerance 1e-12 relative.
+   Round 3: stage A of the IF class (140 dB) is an equiripple filter of 0.68 x the Kaiser length; both Parks-McClellan
+   implementations (C in the oracle, C++ in design.hpp) are checked against scipy.signal.remez on the same bands and
+   weights -- the Chebyshev optimum is unique, so independent exchanges agree to their stopping tolerance (1e-7 relative).
 2. Frequency response of the cascade: pass band flat to 0.885 x Nyquist, every frequency that can alias into the pass
    band rejected by the design attenuation.
 3. Specification gap (VERDICT r1 item 3): the reference's r8b::CDSPResampler24 (IfResampler.cpp:26-29) passes 98 % of
@@ -25,7 +28,8 @@ from conftest import ROOT
 
 fmr = importlib.import_module("airspy-fmradion_amd")
 
-CASES = [(10e6, 384e3, 140.0), (1e6, 384e3, 140.0), (384e3, 48e3, 180.0), (6e6, 384e3, 140.0)]
+CASES = [(10e6, 384e3, 140.0), (1e6, 384e3, 140.0), (384e3, 48e3, 180.0), (6e6, 384e3, 140.0), (384e3, 48e3, 140.0),
+         (2.4e6, 384e3, 140.0), (20e6, 384e3, 140.0)]
 
 
 def _scipy_stage_a(in_rate, out_rate, atten, D):
@@ -36,6 +40,19 @@ def _scipy_stage_a(in_rate, out_rate, atten, D):
     n, beta = signal.kaiserord(atten, (f2 - f1) / (0.5 * in_rate))
     if n % 2 == 0:
         n += 1
+    if atten <= 150.0:
+        # the IF class: equiripple, 0.68 x the Kaiser length, stop bands k mid -+ fstop (weight 800), free in between
+        ne = int(np.ceil(0.68 * n))
+        ne += ne % 2 == 0
+        bands, des, wt = [0.0, fpass], [1.0], [1.0]
+        for k in range(1, D // 2 + 1):
+            lo, hi = k * mid - fstop, min(k * mid + fstop, in_rate / 2)
+            if lo >= in_rate / 2:
+                break
+            bands += [lo, hi]
+            des.append(0.0)
+            wt.append(800.0)
+        return signal.remez(ne, bands, des, weight=wt, fs=in_rate, maxiter=100), beta
     return signal.firwin(n, 0.5 * (f1 + f2), window=("kaiser", beta), fs=in_rate, scale=False), beta
 
 
@@ -54,8 +71,10 @@ def test_taps_match_scipy_construction(in_rate, out_rate, atten):
         assert len(h) == info["NA"]
         assert beta == pytest.approx(0.1102 * (atten - 8.7), rel=1e-12)
         h = h / h.sum()
+        assert np.array_equal(ha_o, ha_p)            # the two Parks-McClellan implementations run the same arithmetic
         for got in (ha_o, ha_p):
-            assert np.max(np.abs(got - h)) < 1e-12 * np.max(np.abs(h))
+            assert np.array_equal(got, got[::-1])
+            assert np.max(np.abs(got - h)) < (1e-7 if atten <= 150.0 else 1e-12) * np.max(np.abs(h))
     # stage B: rows of the polyphase table are the samples of ONE Kaiser-windowed sinc prototype at rate LB * mid
     n = TB * LB + 1
     beta = signal.kaiser_beta(atten)
@@ -70,7 +89,7 @@ def test_taps_match_scipy_construction(in_rate, out_rate, atten):
         assert np.max(np.abs(got - tab)) < 1e-11 * np.max(np.abs(tab))
 
 
-@pytest.mark.parametrize("in_rate,out_rate,atten", CASES[:3])
+@pytest.mark.parametrize("in_rate,out_rate,atten", CASES[:7])
 def test_cascade_frequency_response(in_rate, out_rate, atten):
     """|H(f)| of stage A x stage B on a dense grid: flat pass band, aliases of the pass band rejected."""
     ha, d = fmr.design_taps(in_rate, out_rate, atten, 0)
@@ -88,7 +107,7 @@ def test_cascade_frequency_response(in_rate, out_rate, atten):
     Hb = np.abs(np.fft.fft(proto, LB * nb))[np.arange(len(f)) % (LB * nb)] / LB
     H = Ha * Hb
     pb = f <= fpass
-    assert np.max(np.abs(20 * np.log10(H[pb]))) < 1e-3                       # ripple < 0.001 dB
+    assert np.max(np.abs(20 * np.log10(H[pb]))) < 1.2e-3                     # within 0.0015 dB of unity (equiripple stage A: 0.0010 dB peak to peak)
     # images of the pass band: anything within +-fpass of a multiple of out_rate (k >= 1)
     k = np.round(f / out_rate)
     alias = (k >= 1) & (np.abs(f - k * out_rate) <= fpass)
@@ -209,6 +228,13 @@ def test_fractional_phase_resampling_of_an_analytic_signal(in_rate, out_rate):
     cuts = [0, 1, 17, 4096, 4097, n // 3 + 11, n // 2, n]
     y = np.concatenate([rs.process(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
     assert abs(len(y) - n * out_rate / in_rate) < 300
-    ref = sig(np.arange(len(y)) / out_rate)
+    # stage A of the IF class is equiripple: a tone leaves with the filter's (zero-phase) gain at its frequency, within
+    # +-6e-5 of unity; the fractional-phase stage itself is held to 3e-7
+    ha = rs.taps_a()
+    gain = lambda f: float(np.sum(ha * np.cos(2 * np.pi * f * (np.arange(len(ha)) - (len(ha) - 1) / 2) / in_rate))) if len(ha) else 1.0
+    g0, g1 = gain(f0), gain(0.31 * f0)
+    assert abs(g0 - 1) < 6e-5 and abs(g1 - 1) < 6e-5
+    tt = np.arange(len(y)) / out_rate
+    ref = g0 * np.cos(2 * np.pi * f0 * tt) + 0.3 * g1 * np.cos(2 * np.pi * 0.31 * f0 * tt + 1.0)
     err = (y - ref)[3000:]
     assert np.sqrt(np.mean(err ** 2)) < 3e-7

@@ -60,7 +60,8 @@ def test_passband_tone_amplitude_and_alignment(fin, fout, att):
     k = np.arange(len(y))
     ref = np.cos(2 * np.pi * f0 * k / fout)
     s = 400
-    assert np.max(np.abs(y[s:] - ref[s:])) < 2e-6
+    # IF class (140 dB): the equiripple stage A holds the pass band to +-0.0005 dB (+-6e-5); the Kaiser designs to 2e-6
+    assert np.max(np.abs(y[s:] - ref[s:])) < (6e-5 if att <= 150.0 else 2e-6)
 
 
 @pytest.mark.parametrize("fin,fout,att,floor_db", [(10e6, 384e3, 140.0, -135.0), (384e3, 48e3, 180.0, -170.0)])

@@ -33,7 +33,7 @@ struct Ctx {
   unsigned long long *d_dbg = nullptr; float *d_taps = nullptr;
   long long wg_key = -1;
   double *d_base = nullptr; float *d_dec = nullptr, *d_hBlast = nullptr, *d_stats = nullptr; StreamState *d_st = nullptr; FusedPart *d_part = nullptr; int *d_tab = nullptr;
-  bool epi = false; int nb = 0; std::vector<int> h_off, h_len; int *d_wgblk = nullptr;
+  bool epi = false, lean = false; int h_off_dev400 = 0; int nb = 0; std::vector<int> h_off, h_len; int *d_wgblk = nullptr;
   int poly2_tile;
 };
 
@@ -68,8 +68,8 @@ static void setup(Ctx &c, size_t max_in) {
   CK(hipMalloc(&c.d_mid, (c.H_mid + c.max_mid) * 8)); CK(hipMemset(c.d_mid, 0, (c.H_mid + c.max_mid) * 8));
   CK(hipMalloc(&c.d_if_old, (c.H_if + c.max_if) * 8)); CK(hipMalloc(&c.d_if_new, (c.H_if + c.max_if) * 8));
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 125, 210>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-  constexpr int kL = FusedShape<10, 151>::LDS_BYTES;
-#define SETATTR(P, A) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<10, 151, P, A>), hipFuncAttributeMaxDynamicSharedMemorySize, kL))
+  constexpr int kL = FusedShape<kFusedD, kFusedNA>::LDS_BYTES;
+#define SETATTR(P, A) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, P, A>), hipFuncAttributeMaxDynamicSharedMemorySize, kL))
   SETATTR(0, 0); SETATTR(1, 0); SETATTR(0, 1); SETATTR(1, 1); SETATTR(0, 2); SETATTR(1, 2); SETATTR(0, 3); SETATTR(1, 3);
   SETATTR(0, 4); SETATTR(1, 4); SETATTR(0, 7); SETATTR(1, 7); SETATTR(0, 5); SETATTR(1, 5); SETATTR(0, 6); SETATTR(1, 6);
   SETATTR(0, 14); SETATTR(1, 14); SETATTR(0, 22); SETATTR(1, 22); SETATTR(0, 32); SETATTR(1, 32); SETATTR(0, 36); SETATTR(1, 36); SETATTR(0, 38); SETATTR(1, 38); SETATTR(0, 37); SETATTR(1, 37); SETATTR(0, 35); SETATTR(1, 35);
@@ -117,7 +117,7 @@ static void launch_old(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
 template <int ABL = 0>
 static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *ifbuf, int n_wg) {
   const auto &rs = c.rs;
-  constexpr int D = 10, NA = 151;
+  constexpr int D = kFusedD, NA = kFusedNA;
   FusedArgs a{};
   a.iq = d_iq; a.iq_stride = (long long)c.max_in; a.n_valid = g.N_in;
   a.in_halo = c.d_in_halo; a.H_in = c.H_in; a.taps = c.d_taps;
@@ -126,7 +126,7 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
   const int par = (int)(((lo0 % 2) + 2) % 2);
   a.nbase = lo0 - par;
   const long long P_first = g.kB_prev / 48, P_last = (g.kB_prev + g.N_if - 1) / 48;
-  constexpr int kME = FusedShape<10, 151>::ME, kEPT = FusedShape<10, 151>::EPT;
+  constexpr int kME = FusedShape<kFusedD, kFusedNA>::ME, kEPT = FusedShape<kFusedD, kFusedNA>::EPT;
   const long long T_first = P_first / 8, E_ref = kEPT * T_first - 1;
   a.j_ref = (int)(kME * E_ref + 104 - g.mA_prev);
   a.pos_ref = (int)((((kME * E_ref + 208) % 3000) + 3000) % 3000);
@@ -138,7 +138,8 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
   a.out = ifbuf; a.out_stride = (long long)(c.H_if + c.max_if); a.out_off = c.H_if;
   a.dbg = c.d_dbg;
   if (c.epi) {
-    a.base = c.d_base; a.base_stride = (long long)c.max_if; a.base_off = 0; a.dec = c.d_dec; a.dec_stride = (long long)c.max_if;
+    a.base = c.d_base; a.base_stride = (long long)c.max_if; a.base_off = 0; a.dec = c.lean ? nullptr : c.d_dec; a.dec_stride = (long long)c.max_if;
+    if (c.lean && c.nb > 400) a.part_from = c.h_off_dev400;     // as in the chain: no debug copy, block sums only where k_stats reads them
     a.nf = (float)((75000.0 / 384000.0) * 2.0 * M_PI); a.bound = (float)(1.0 / ((75000.0 / 384000.0) * 2.0));
     a.st = c.d_st; a.hB_last = c.d_hBlast; a.part = c.d_part; a.if_off = c.d_tab; a.if_len = c.d_tab + 4096; a.nb = c.nb;
   }
@@ -334,10 +335,15 @@ int main(int argc, char **argv) {
     std::vector<int> tab(2 * 4096, 0);
     long long acc_if = 0, left = (long long)N; int nb = 0;
     while (left > 0 && nb < 4096) { const long long bl = std::min<long long>(65536, left); const long long k = rc2.advance(c.rs, bl); tab[nb] = (int)acc_if; tab[4096 + nb] = (int)k; acc_if += k; left -= bl; nb++; }
-    c.nb = nb; c.wg_key = -1;
+    c.nb = nb; c.wg_key = -1; c.h_off_dev400 = nb > 400 ? tab[nb - 400] : 0;
     CK(hipMemcpy(c.d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
   }
   c.epi = true;
+  c.lean = true;
+  time_it("fused A+B+discriminator AS IN THE CHAIN (lean)", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
+  time_it("lean, no global stores", bytes, [&] { launch_new<128>(c, g, d_iq, c.d_if_new, 256); });
+  time_it("lean, no atan2", bytes, [&] { launch_new<64>(c, g, d_iq, c.d_if_new, 256); });
+  c.lean = false;
   time_it("fused A+B+discriminator, 256 workgroups", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
   time_it("fused A+B+discriminator, 248 workgroups", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 248); });
   time_it("epilogue ablation: no atan2", bytes, [&] { launch_new<64>(c, g, d_iq, c.d_if_new, 256); });
@@ -372,6 +378,22 @@ int main(int argc, char **argv) {
   launch_new<35>(c, g, d_iq, c.d_if_new, 256); dump("DMA only");
   launch_new<46>(c, g, d_iq, c.d_if_new, 256); dump("A FMAs only");
   launch_new<54>(c, g, d_iq, c.d_if_new, 256); dump("A LDS reads only");
+  launch_new<39>(c, g, d_iq, c.d_if_new, 256); dump("nothing");
+  {
+    // fixed cost of a launch vs cost per epoch: the same geometry at half and a quarter of the length
+    for (int sh = 1; sh <= 2; sh++) {
+      c.rsc.reset(); advance(c, 12345678);
+      CallGeom gh = advance(c, (long long)(N >> sh));
+      char nm[96];
+      snprintf(nm, sizeof nm, "1/%d length: fused A+B", 1 << sh);
+      time_it(nm, bytes / (1 << sh), [&] { launch_new(c, gh, d_iq, c.d_if_new, 256); });
+      snprintf(nm, sizeof nm, "1/%d length: nothing (barriers)", 1 << sh);
+      time_it(nm, bytes / (1 << sh), [&] { launch_new<7>(c, gh, d_iq, c.d_if_new, 256); });
+      snprintf(nm, sizeof nm, "1/%d length: DMA only", 1 << sh);
+      time_it(nm, bytes / (1 << sh), [&] { launch_new<3>(c, gh, d_iq, c.d_if_new, 256); });
+    }
+    c.rsc.reset(); advance(c, 12345678); advance(c, (long long)N);
+  }
   CK(hipDeviceSynchronize());
   CK(hipGetLastError());
   launch_new(c, g, d_iq, c.d_if_new, 256);
