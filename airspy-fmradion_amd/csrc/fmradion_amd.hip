@@ -62,7 +62,7 @@ constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 512, K_A
 #ifndef FMR_C_PLL_MIN
 #define FMR_C_PLL_MIN 64
 #endif
-constexpr int C_PLL_MIN = FMR_C_PLL_MIN;   // smallest PLL chunk (capacity); the actual length is c_pll (env FMR_C_PLL)
+constexpr int C_PLL_MIN = FMR_C_PLL_MIN;   // smallest PLL chunk (capacity); the actual length is c_pll
 constexpr long long kSmallCall = 8192;   // IF samples: calls up to this size enqueue fewer spare Newton rounds
 constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 4;   // PLL: 2 rounds in lock, 2 spare (an unused round is three launches that return at once: ~6 us measured)
 
@@ -88,38 +88,21 @@ using namespace fmr;
 // Diagnostic switches from the environment, read ONCE when a chain is created (INTEGRATION.md section 4 lists them);
 // nothing on the call path touches the environment.
 struct EnvKnobs {
+  // Run-time switches (environment).  Everything else that rounds 1 and 2 compared side by side has been decided and
+  // removed; what is left selects a MODE of the product or the slower form a test compares the product with.
   bool serial = false;          // FMR_SERIAL=1       serial recurrence kernels (reference loop order on one lane)
   bool pipeline = false;        // FMR_PIPELINE=1     front end of call N+1 beside the decoder of call N
   bool debug_taps = false;      // FMR_DEBUG_TAPS=1   keep intermediate signals readable through fmr_debug_read
   bool host_prof = false;       // FMR_HOST_PROF=1    host enqueue time per call on stderr
-  bool decim_v1 = false;        // FMR_DECIM_V1=1     round-1 first stage-A kernel
-  bool poly_v1 = false, poly_v2 = false, poly_v3 = false;   // FMR_POLY_V1/V2/V3=1  older stage-B kernels
-  bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end
-  bool agc_late = false;        // FMR_AGC_LATE       side-stream AGC gated on k_stats (about the end of the PLL's first pass) instead of the front end
-  bool mpf_v1 = false, mpf_v2 = false;   // FMR_MPF_V1 / V2   round-1 / one-wave equaliser kernels
-  bool split_mono = true;       // FMR_NO_SPLIT=1     mono and L-R audio tails on one stream (default: mono tail on the AGC's side stream)
-  bool pll_v1 = false;          // FMR_PLL_V1         seven launches per Newton round of the PLL instead of three
-  bool agc_first = true;        // FMR_MONO_FIRST=1   side stream: mono audio tail before the AGC (default: after)
-  bool iter_v1 = false;         // FMR_ORDER_V1       round-2 enqueue order (flag reset / input history / markers on the main stream)
-  bool am_serial_tail = false;  // FMR_AM_SERIAL_TAIL serial AM audio tail
-  bool fmblock_v1 = false;      // FMR_FMBLOCK_V1     IF filter out of global memory (round-1 kernel)
-  int decim_bl = 128;           // FMR_DECIM_BL=256   wider stage-A workgroups
-  int mpf_nw = 4;               // FMR_MPF_NW=1|2|4   waves per stream in the equaliser kernel
-  int c_pll = 0;                // FMR_C_PLL          PLL chunk length (0 = default)
-  int pll_jac = 0;              // FMR_PLL_JAC        rounds that re-integrate the sensitivities (0 = default)
+  bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end (tests: fused vs three-kernel property test)
+  bool pll_v1 = false;          // FMR_PLL_V1         seven launches per Newton round of the PLL instead of three: no hand-off
+                                //                    between workgroups inside a launch (tests: bit-equality stress test)
   double pll_rtol = -1.0;       // FMR_PLL_RTOL       PLL acceptance threshold (< 0 = default)
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
   void load() {
     serial = on("FMR_SERIAL"); pipeline = on("FMR_PIPELINE"); debug_taps = on("FMR_DEBUG_TAPS");
-    host_prof = on("FMR_HOST_PROF"); decim_v1 = on("FMR_DECIM_V1"); poly_v1 = on("FMR_POLY_V1");
-    poly_v2 = on("FMR_POLY_V2"); poly_v3 = on("FMR_POLY_V3"); no_fused = on("FMR_NO_FUSED");
-    agc_late = set("FMR_AGC_LATE"); mpf_v1 = set("FMR_MPF_V1"); mpf_v2 = set("FMR_MPF_V2"); split_mono = !set("FMR_NO_SPLIT"); pll_v1 = set("FMR_PLL_V1"); iter_v1 = set("FMR_ORDER_V1"); agc_first = !set("FMR_MONO_FIRST");
-    am_serial_tail = set("FMR_AM_SERIAL_TAIL"); fmblock_v1 = set("FMR_FMBLOCK_V1");
-    if (const char *e = getenv("FMR_DECIM_BL")) if (atoi(e) == 256) decim_bl = 256;
-    if (const char *e = getenv("FMR_C_PLL")) c_pll = atoi(e);
-    if (const char *e = getenv("FMR_MPF_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) mpf_nw = v; }
-    if (const char *e = getenv("FMR_PLL_JAC")) if (e[0] >= '1' && e[0] <= '9') pll_jac = e[0] - '0';
+    host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED"); pll_v1 = set("FMR_PLL_V1");
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
   }
 };
@@ -146,7 +129,7 @@ struct fmr_chain {
   DevBuf<double> d_pll_wgr, d_pll_pre;
   DevBuf<PllSync> d_pll_sync;
   DevBuf<unsigned int> d_pll_tick2;
-  int pll_jac_rounds = 1;                // rounds that re-integrate the sensitivities (env FMR_PLL_JAC)
+  int pll_jac_rounds = 1;                // rounds that re-integrate the sensitivities
   double hp_fe = 0, hp_tab = 0, hp_dec = 0; long long hp_calls = 0; bool host_prof = false;   // FMR_HOST_PROF=1
   hipStream_t fe = nullptr;              // front-end stream (cross-call pipelining)
   bool pipelined = false;
@@ -182,7 +165,6 @@ struct fmr_chain {
   unsigned ft_index = 0;                 // FineTuner::m_index, the same for every tuner of the chain
   double af_ref = 0.6, af_rate = 0.001;  // AfSimpleAgc reference / rate (AmDecode.cpp:54-66)
   int in_fmt = 0, in_bps = 8;          // source sample format (fmr_config.input_format) and its bytes per IQ sample
-  int decim_bl = 128;
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
   DevBuf<float> d_afrag;               // v4: constant A fragments
@@ -203,7 +185,7 @@ struct fmr_chain {
   DevBuf<StreamState> d_state;
   // time-parallel recurrences
   bool serial_mode = false;            // FMR_SERIAL=1: plain serial kernels (A/B, debugging)
-  int c_pll = 64;                      // PLL chunk length (env FMR_C_PLL, >= C_PLL_MIN)
+  int c_pll = 64;                      // PLL chunk length (>= C_PLL_MIN; 32: 0.40 ms, 48: 0.345, 64: 0.33, 96 / 128: 0.47 per 2^27-sample call)
   int H_b = 0;                         // halo of the pre-de-emphasis buffers (>= warm-up)
   size_t max_ck = 0, max_agc_nc = 0, max_dc_nc = 0;
   DevBuf<double> d_base_de, d_raw_de, d_pll_nodes, d_pll_G, d_pll_M, d_pll_PQ, d_pll_dstart, d_pll_PQ2, d_pll_dstart2, d_pll_gres,
@@ -467,7 +449,6 @@ int fmr_chain::init(const fmr_config *c) {
         if ((rc = upload(d_hpA, hp.data(), hp.size()))) return rc;
       }
     }
-    if (env.decim_v1) qa = 0;
     if (in_fmt != 0) {
       // the fused sample conversion lives in the v2 front-end kernel only: refuse the chain now, not on every call
       constexpr int BL2 = 128, T2 = 2 * BL2;
@@ -485,7 +466,7 @@ int fmr_chain::init(const fmr_config *c) {
       std::vector<int> phi((size_t)rs.LB), off((size_t)rs.LB);
       for (long long q = 0; q < rs.LB; q++) { phi[q] = (int)((q * rs.MB) % rs.LB); off[q] = (int)((q * rs.MB) / rs.LB); }
       const long long tl = 64 * rs.MB + off[rs.LB - 1] + rs.TB;
-      if (tl * 8 <= 98304 && rs.LB <= 4096 && !env.poly_v1) {
+      if (tl * 8 <= 98304 && rs.LB <= 4096) {
         poly2_tile = (int)tl;
         if ((rc = upload(d_bphi, phi.data(), phi.size()))) return rc;
         if ((rc = upload(d_boff, off.data(), off.size()))) return rc;
@@ -496,7 +477,7 @@ int fmr_chain::init(const fmr_config *c) {
         int dmax = 0;
         for (long long g = 0; g * Q3 < rs.LB; g++)
           dmax = std::max(dmax, off[std::min<long long>(g * Q3 + Q3 - 1, rs.LB - 1)] - off[g * Q3]);
-        if (dmax <= FMR_POLY_PADZ - 8 && (tl + 64) * 8 <= 98304 && !env.poly_v2) {
+        if (dmax <= FMR_POLY_PADZ - 8 && (tl + 64) * 8 <= 98304) {
           const int TBP = rs.TB + 2 * FMR_POLY_PADZ;
           std::vector<float> hp((size_t)rs.LB * TBP, 0.f);
           for (long long r = 0; r < rs.LB; r++)
@@ -507,7 +488,7 @@ int fmr_chain::init(const fmr_config *c) {
           HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly3<384, Q3>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
         }
-        if (poly3 && rs.LB == 48 && rs.MB == 125 && rs.TB == 210 && !env.poly_v3) {
+        if (poly3 && rs.LB == 48 && rs.MB == 125 && rs.TB == 210) {
           using SH = Poly4Shape<48, 125, 210>;
           std::vector<float> af((size_t)SH::MT * SH::NK * 64, 0.f);
           for (int mt = 0; mt < SH::MT; mt++)
@@ -559,9 +540,8 @@ int fmr_chain::init(const fmr_config *c) {
   H_if = has_dec ? (ntaps > 1 ? ntaps - 1 : 1) : 1;
   if ((rc = d_if.alloc((size_t)S * (H_if + max_if)))) return rc;
   last_if = d_if.p;
-  host_prof = env.host_prof; decim_bl = env.decim_bl; debug_taps = env.debug_taps;
+  host_prof = env.host_prof; debug_taps = env.debug_taps;
   if (env.pll_rtol >= 0.0) pll_rtol = env.pll_rtol;
-  if (env.pll_jac) pll_jac_rounds = env.pll_jac;
   {
     // Opt-in (FMR_PIPELINE=1): +5 % whole-job rate on config 2, but the front-end kernel then shares HBM
     // with the decoder's tail and its own launch takes 0.28 ms instead of 0.20 ms.
@@ -595,7 +575,6 @@ int fmr_chain::init(const fmr_config *c) {
   if ((rc = d_flags.alloc((size_t)S))) return rc;
   {
     serial_mode = env.serial;
-    if (env.c_pll >= C_PLL_MIN) c_pll = env.c_pll;
   }
   max_agc_nc = max_if / C_AGC + 2;
   if (has_dec) {
@@ -976,8 +955,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
         });
         v2_done = true;
       };
-      if (decim_bl == 256) launch_decim2(std::integral_constant<int, 256>{});
-      if (!v2_done) launch_decim2(std::integral_constant<int, 128>{});
+      launch_decim2(std::integral_constant<int, 128>{});
       if (v2_done) {
       } else if (in_fmt != 0) {
         set_err("input_format != cf32 needs the v2 front-end kernel (decimation ratio out of its range)");
@@ -1163,7 +1141,7 @@ int fmr_chain::run_tables(CallCtx &k) {
   // FM without the equaliser: the round flags and the AGC's start nodes are reset here too, beside the front end (5-10 us
   // of the critical path when launched between the front end and the PLL's first pass).  Their last readers of the previous
   // call are the PLL kernels (ordered before this stream's k_pll_finish) and the side-stream AGC (ev_agc).
-  iter_on_side = (mode == FMR_MODE_FM) && !serial_mode && !enable_mpf && !env.iter_v1;
+  iter_on_side = (mode == FMR_MODE_FM) && !serial_mode && !enable_mpf;
   if (iter_on_side) {
     if (ev_agc_live) HIPCHK(hipStreamWaitEvent(side, ev_agc, 0));
     const int nc = (int)((N_if + C_AGC - 1) / C_AGC);
@@ -1215,14 +1193,10 @@ int fmr_chain::run_tables(CallCtx &k) {
     if ((size_t)a.n_tiles * 3 * S > d_fused_part.n) { set_err("internal capacity exceeded (fused tiles)"); return FMR_ERR_CAPACITY; }
     constexpr size_t kLds = FusedShape<D, NA>::LDS_BYTES;
     timed("ifr_fused", [&] {
-      if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, stream, a, fused_taps);
-      else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, stream, a, fused_taps);
+      if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, stream, a);
+      else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, stream, a);
     });
     fused_kb_ref = a.kb_ref;
-    if (env.iter_v1)
-      timed("in_halo", [&] {
-        hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
-      });
   }
   return FMR_OK;
 }
@@ -1246,7 +1220,7 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     timed("fm_block", [&] {
       constexpr int TL = 1024;
       const size_t lds_fb = sizeof(float2) * ((size_t)(ntaps - 1) + TL) + sizeof(float) * (size_t)ntaps;
-      if (fir_enable && ntaps >= 2 && lds_fb <= 60000 && !env.fmblock_v1)
+      if (fir_enable && ntaps >= 2 && lds_fb <= 60000)
         hipLaunchKernelGGL((k_fm_block2<256, TL>), dim3(nb, S), dim3(256), lds_fb, stream, ifbuf, if_stride, H_if, bt,
                            d_coeff.p, ntaps, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if, d_if_rms_blk.p);
       else
@@ -1338,6 +1312,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
     });
   } else {
     // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
+    int rc_agc = FMR_OK;          // a failure inside the lambda must leave run_fm_pll, not only the lambda
     timed("pll", [&] {
       const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
       const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
@@ -1362,7 +1337,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
           // (FMR_AGC_LATE=1) -- because a marker of its own on this stream costs ~10 us between the first pass
           // and the node pass (FMR_ORDER_V1=1: that marker).
           agc_deferred = false;
-          hipEvent_t gate = env.iter_v1 ? nullptr : (env.agc_late ? ev_stats : ev_disc);
+          hipEvent_t gate = ev_disc;
           if (!gate) { (void)hipEventRecord(ev_if, stream); gate = ev_if; }
           auto mono_aside = [&] {
             (void)hipStreamWaitEvent(side2, gate, 0);
@@ -1370,9 +1345,8 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
             (void)hipEventRecord(ev_mono, side2);
             mono_enqueued = true;
           };
-          if (split_mono && !env.agc_first) mono_aside();
-          if (enqueue_agc(gate)) return;
-          if (split_mono && env.agc_first) mono_aside();
+          if ((rc_agc = enqueue_agc(gate))) return;
+          if (split_mono) mono_aside();
         }
         if (env.pll_v1)
           hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
@@ -1402,6 +1376,8 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
                          d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
                          S, d_flags.p);
     });
+    if (rc_agc) return rc_agc;
+    HIPCHK(hipGetLastError());    // a launch of the rounds above that could not be enqueued
     // lock logic / PPS / state commit beside the audio chain (needed again only by fm_out)
     HIPCHK(hipEventRecord(ev_pll, stream));
     HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
@@ -1414,7 +1390,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
     });
     // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
     // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
-    if (agc_on_side && !agc_deferred && !env.iter_v1) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
+    if (agc_on_side && !agc_deferred) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
     HIPCHK(hipEventRecord(ev_fin, side));
     fin_on_side = true;
   }
@@ -1433,7 +1409,6 @@ int fmr_chain::run_fm(CallCtx &k) {
   auto &agc_deferred = k.agc_deferred; auto &enqueue_agc = k.enqueue_agc;
   auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
   if (any_mpf) {
-    const size_t lds = sizeof(float2) * ((size_t)2 * mpf_N + FMR_MPF_CH + 4);
     const size_t lds3 = sizeof(float2) * ((size_t)mpf_N + FMR_MPF_CH + 8) + sizeof(float) * (FMR_MPF_CH / 4 + 2) +
                         sizeof(float2) * (2 * 4 * 4 + FMR_MPF_CH);
     timed("mpf", [&] {
@@ -1442,26 +1417,11 @@ int fmr_chain::run_fm(CallCtx &k) {
                            bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
                            d_mpf_ok.p, d_state.p);
       };
-      // v3: four waves per stream (kernels.hpp); v2 (one wave, taps in registers) for FMR_MPF_V2=1, v1 for FMR_MPF_V1=1
-      if (env.mpf_v1) go(k_mpf, 64, lds);
-      else if (env.mpf_v2) {
-        if (mpf_N <= 64 * 5) go(k_mpf2<5>, 64, lds);
-        else if (mpf_N <= 64 * 10) go(k_mpf2<10>, 64, lds);
-        else go(k_mpf2<19>, 64, lds);
-      } else {
-        // FMR_MPF_NW = 1, 2, 4 waves per stream (4: product)
-        const int nw = env.mpf_nw;
-        auto pick = [&](auto nwc) {
-          constexpr int NWc = decltype(nwc)::value;
-          if (mpf_N <= 16 * NWc * (80 / NWc)) go(k_mpf3<NWc, 80 / NWc>, 64 * NWc, lds3);        // N <= 1280
-          else set_err("equaliser length out of range");
-        };
-        if (mpf_N <= 64 * 5 && nw == 4) go(k_mpf3<4, 5>, 256, lds3);
-        else if (mpf_N <= 64 * 5 && nw == 2) go(k_mpf3<2, 10>, 128, lds3);
-        else if (mpf_N <= 64 * 5 && nw == 1) go(k_mpf3<1, 20>, 64, lds3);
-        else if (mpf_N <= 64 * 10) go(k_mpf3<4, 10>, 256, lds3);
-        else pick(std::integral_constant<int, 4>{});
-      }
+      // four waves per stream (kernels.hpp), taps per lane and row by equaliser length
+      if (mpf_N <= 64 * 5) go(k_mpf3<4, 5>, 256, lds3);
+      else if (mpf_N <= 64 * 10) go(k_mpf3<4, 10>, 256, lds3);
+      else if (mpf_N <= 64 * 20) go(k_mpf3<4, 20>, 256, lds3);                                   // N <= 1280
+      else set_err("equaliser length out of range");
     });
   }
   const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
@@ -1475,7 +1435,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   });
   HIPCHK(hipEventRecord(ev_disc, stream));
   HIPCHK(hipStreamWaitEvent(side, ev_disc, 0));
-  if (use_fused && !env.iter_v1)      // input history for the next call's front end: off the critical path (the next
+  if (use_fused)      // input history for the next call's front end: off the critical path (the next
     timed_on(side, "in_halo", [&] {   // front end waits for this stream's table kernels anyway)
       hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, side, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
     });
@@ -1575,7 +1535,7 @@ int fmr_chain::run_fm(CallCtx &k) {
       });
   };
   const bool split_mono = stereo && !serial_mode && de_fused && (ars.LB == 3 && ars.MB == 8) &&
-                          n_pilotcut <= FMR_PCUT_MAXTAPS && env.split_mono;
+                          n_pilotcut <= FMR_PCUT_MAXTAPS;
   bool mono_enqueued = false;
   if (stereo) {
     if (int rcp = run_fm_pll(k, base_stride, split_mono, enqueue_tail_channels, mono_enqueued, fin_on_side, fin_covers_all)) return rcp;
@@ -1585,7 +1545,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   else enqueue_tail_channels(stream, 0, nch);
   if (mono_enqueued) HIPCHK(hipStreamWaitEvent(stream, ev_mono, 0));   // DC-block node pass needs both channels
   if (N_au > 0) {
-    if (fin_on_side && (serial_mode || env.iter_v1)) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
+    if (fin_on_side && serial_mode) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
     if (serial_mode) {
       timed("fm_out", [&] {
         hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
@@ -1598,7 +1558,7 @@ int fmr_chain::run_fm(CallCtx &k) {
         const int dc_nw = std::max(1, std::min(FMR_DC_MAXW, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
         hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
                            d_state.p, S, nch);
-        if (fin_on_side && !env.iter_v1) (void)hipStreamWaitEvent(stream, ev_fin, 0);   // only the mux needs the lock flags
+        if (fin_on_side) (void)hipStreamWaitEvent(stream, ev_fin, 0);   // only the mux needs the lock flags
         hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
                            (long long)max_au, bt, (int)N_au, dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,
                            d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
@@ -1669,7 +1629,7 @@ int fmr_chain::run_am(CallCtx &k) {
                        d_bb_rms_blk.p, d_state.p, S, 0);
   });
   timed("am_tail", [&] {
-    const bool par_tail = !serial_mode && !env.am_serial_tail;
+    const bool par_tail = !serial_mode;
     if (par_tail) {
       // DC block -> AfSimpleAgc -> de-emphasis in time-parallel form (kernels_par.hpp); the serial kernel below only
       // runs for a stream whose Newton rounds did not converge

@@ -1036,23 +1036,12 @@ __global__ void k_if_agc(const float2 *__restrict__ x, long long x_stride, int x
 }
 
 // ---------------------------------------------------------------------------
-// K_mpf : MultipathFilter (MultipathFilter.cpp:92-197), constant-modulus NLMS.
-// One wave per stream; taps spread over the 64 lanes (tap i on lane i & 63),
-// coefficients and the sliding state window in LDS, cross-lane reduction with
-// shuffles.  Serial over samples (taps depend on previous outputs); the update
-// cadence restarts in every block (hazard H2).
-// LDS: coeff[N] | xw[N + CH]  (float2)
+// K_mpf : MultipathFilter (MultipathFilter.cpp:92-197), constant-modulus NLMS.  Serial over samples (taps depend on
+// previous outputs); the update cadence restarts in every block (hazard H2).  The product form is k_mpf3 below
+// (four waves per stream); rounds 1 and 2 also carried a one-wave form with the taps in LDS (74 ms per 161 k IF samples)
+// and one with the taps in registers (65.7 ms) -- removed in round 3, the measurements are in DESIGN.md.
 // ---------------------------------------------------------------------------
 #define FMR_MPF_CH 2048
-__device__ __forceinline__ float2 wave_sum2(float2 v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    v.x += __shfl_xor(v.x, o, 64);
-    v.y += __shfl_xor(v.y, o, 64);
-  }
-  return v;
-}
-
 // Wave sum without the LDS crossbar: four DPP steps sum each row of 16 lanes (quad_perm xor 1, xor 2, then the
 // row_half_mirror / row_mirror pairings), four v_readlane add the rows.  Every lane returns the total.
 __device__ __forceinline__ float wave_sum_dpp(float v) {
@@ -1069,264 +1058,9 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
-__global__ __launch_bounds__(64) void k_mpf(
-    const float2 *__restrict__ xin, long long x_stride, int x_off,
-    const float *__restrict__ gain, long long g_stride, BlockTab bt,
-    float2 *__restrict__ out, long long out_stride, float2 *__restrict__ coeff_g,
-    float2 *__restrict__ state_g, int N, int ref, int *__restrict__ mpf_ok, StreamState *st) {
-  extern __shared__ float2 lds_m[];
-  float2 *c = lds_m;
-  float2 *xw = lds_m + N;
-  const int s = blockIdx.x;
-  const int lane = threadIdx.x;
-  const float2 *xs = xin + (long long)s * x_stride + x_off;
-  const float *gs = gain + (long long)s * g_stride;
-  float2 *os = out + (long long)s * out_stride;
-  float2 *cg = coeff_g + (long long)s * N;
-  float2 *sg = state_g + (long long)s * N;
-  for (int i = lane; i < N; i += 64) c[i] = cg[i];
-  double err_last = st[s].mpf_error;
-  unsigned resets = st[s].mpf_resets;
-  __syncthreads();
-  for (int b = 0; b < bt.nb; b++) {
-    const int n = bt.if_len[b];
-    int ok = 1;
-    if (n == 0 || !bt.mpf_active[b]) {
-      if (lane == 0) mpf_ok[(long long)s * bt.nb + b] = 0;
-      continue;
-    }
-    const int off = bt.if_off[b];
-    for (int i = lane; i < N; i += 64) xw[i] = sg[i];
-    __syncthreads();
-    for (int c0 = 0; c0 < n && ok; c0 += FMR_MPF_CH) {
-      const int cn = min(FMR_MPF_CH, n - c0);
-      for (int i = lane; i < cn; i += 64) {
-        const float2 v = xs[off + c0 + i];
-        const float g = gs[off + c0 + i];
-        xw[N + i] = make_float2(v.x * g, v.y * g);
-      }
-      if (lane < 4) xw[N + cn + lane] = make_float2(0.f, 0.f);      // slack read by the last (partial) group
-      __syncthreads();
-      int pushed = 0;
-      // The taps only change after every fourth sample of a block (MultipathFilter.cpp:176,186), so the outputs
-      // idx+1 .. idx+4 behind an update at idx share their coefficients: their dot products and wave reductions run
-      // together (one reduction latency per four samples), then the update at idx+4 follows.
-      int q = 0;
-      while (q < cn) {
-        const int jg = c0 + q;                                  // index inside the block
-        const int glen = min(((jg + 3) & ~3) - jg + 1, cn - q);  // up to and including the next update sample
-        float2 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = make_float2(0.f, 0.f);
-        // state after the push of sample q+t = xw[q+t+1 .. q+t+N]; y = sum state[i]*coeff[i] (V9)
-        for (int i = lane; i < N; i += 64) {
-          const float2 cv = c[i];
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const float2 sv = xw[q + 1 + t + i];                // beyond the group: staged samples or the zeroed slack, unused
-            acc[t].x = fmaf(sv.x, cv.x, acc[t].x); acc[t].x = fmaf(-sv.y, cv.y, acc[t].x);
-            acc[t].y = fmaf(sv.x, cv.y, acc[t].y); acc[t].y = fmaf(sv.y, cv.x, acc[t].y);
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) { acc[t].x = wave_sum_dpp(acc[t].x); acc[t].y = wave_sum_dpp(acc[t].y); }
-        int bad = -1;
-#pragma unroll
-        for (int t = 3; t >= 0; t--)
-          if (t < glen && (!isfinite(acc[t].x) || !isfinite(acc[t].y))) bad = t;   // first non-finite output
-        if (bad >= 0) { pushed = q + bad + 1; ok = 0; break; }                      // :182-184
-        pushed = q + glen;
-        if (lane < glen) {
-          const float2 yv = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
-          os[off + c0 + q + lane] = yv;
-        }
-        const int qlast = q + glen - 1;
-        if ((((c0 + qlast) & 3) == 0)) {                        // :176,186
-          const float2 y = glen == 1 ? acc[0] : glen == 2 ? acc[1] : glen == 3 ? acc[2] : acc[3];
-          const double env = (double)(y.x * y.x + y.y * y.y);
-          const double error = 1.0 - env;
-          float ms = 0.f;
-          for (int i = lane; i < N; i += 64) {
-            const float2 sv = xw[qlast + 1 + i];
-            ms += sv.x * sv.x + sv.y * sv.y;
-          }
-          const float sum = wave_sum_dpp(ms);
-          const float mu = (float)(0.1 / ((double)sum + 1e-10));   // :130
-          const float factor = (float)(error * (double)mu);         // :133
-          const float fr = factor * y.x, fi = factor * y.y;
-          for (int i = lane; i < N; i += 64) {                       // V10: lane i only ever touches its own taps
-            const float2 sv = xw[qlast + 1 + i];
-            float2 cv = c[i];
-            cv.x += sv.x * fr + sv.y * fi;
-            cv.y += sv.x * fi - sv.y * fr;
-            if (i == ref) cv = make_float2(1.f, 0.f);                // :158
-            c[i] = cv;
-          }
-          err_last = error;
-          if (!isfinite(error)) { ok = 0; break; }                   // :190-192
-        }
-        q += glen;
-      }
-      // new state = last N entries pushed so far
-      __syncthreads();
-      float2 tmp[20];
-      int cnt = 0;
-      for (int i = lane; i < N; i += 64) tmp[cnt++] = xw[pushed + i];
-      __syncthreads();
-      cnt = 0;
-      for (int i = lane; i < N; i += 64) xw[i] = tmp[cnt++];
-      __syncthreads();
-    }
-    for (int i = lane; i < N; i += 64) sg[i] = xw[i];
-    if (!ok) {
-      // FmDecode.cpp:117-123: re-initialise the taps, block falls back to the AGC output
-      for (int i = lane; i < N; i += 64) c[i] = make_float2(i == ref ? 1.f : 0.f, 0.f);
-      resets++;
-    }
-    if (lane == 0) mpf_ok[(long long)s * bt.nb + b] = ok;
-    __syncthreads();
-  }
-  for (int i = lane; i < N; i += 64) cg[i] = c[i];
-  if (lane == 0) { st[s].mpf_error = err_last; st[s].mpf_resets = resets; }
-}
 
-// ---------------------------------------------------------------------------
-// K_mpf v2 : the same recurrence with the latency taken out of the per-group chain.  Still one wave per stream (the
-// taps depend on the previous outputs), but
-//  * the taps live in registers (lane l owns taps l, l+64, ...: TPL per lane), not in LDS;
-//  * the state window stays in LDS and is read once per group: the five values a lane needs for the four outputs of a
-//    group at one tap (xw[q+1+i .. q+4+i]) are loaded together, and sum |state|^2 of the update (MultipathFilter.cpp:130)
-//    is taken from the same registers as the last output's dot product instead of a second pass;
-//  * the 8 + 1 wave reductions of a group are issued together (independent DPP chains);
-//  * the tap update reuses the state values of the last output, still in registers.
-// Arithmetic per tap and per output is unchanged (same fmaf chains in the same order as k_mpf, same float / double
-// mix as MultipathFilter.cpp:92-161), so the two kernels agree bit for bit.
-// ---------------------------------------------------------------------------
-template <int TPL>
-__global__ __launch_bounds__(64) void k_mpf2(
-    const float2 *__restrict__ xin, long long x_stride, int x_off,
-    const float *__restrict__ gain, long long g_stride, BlockTab bt,
-    float2 *__restrict__ out, long long out_stride, float2 *__restrict__ coeff_g,
-    float2 *__restrict__ state_g, int N, int ref, int *__restrict__ mpf_ok, StreamState *st) {
-  extern __shared__ float2 lds_m[];
-  float2 *xw = lds_m;                       // [N + CH + 4]
-  const int s = blockIdx.x;
-  const int lane = threadIdx.x;
-  const float2 *xs = xin + (long long)s * x_stride + x_off;
-  const float *gs = gain + (long long)s * g_stride;
-  float2 *os = out + (long long)s * out_stride;
-  float2 *cg = coeff_g + (long long)s * N;
-  float2 *sg = state_g + (long long)s * N;
-  float2 c[TPL];
-#pragma unroll
-  for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; c[j] = (i < N) ? cg[i] : make_float2(0.f, 0.f); }
-  double err_last = st[s].mpf_error;
-  unsigned resets = st[s].mpf_resets;
-  for (int b = 0; b < bt.nb; b++) {
-    const int n = bt.if_len[b];
-    int ok = 1;
-    if (n == 0 || !bt.mpf_active[b]) {
-      if (lane == 0) mpf_ok[(long long)s * bt.nb + b] = 0;
-      continue;
-    }
-    const int off = bt.if_off[b];
-    for (int i = lane; i < N; i += 64) xw[i] = sg[i];
-    __syncthreads();
-    for (int c0 = 0; c0 < n && ok; c0 += FMR_MPF_CH) {
-      const int cn = min(FMR_MPF_CH, n - c0);
-      for (int i = lane; i < cn; i += 64) {
-        const float2 v = xs[off + c0 + i];
-        const float g = gs[off + c0 + i];
-        xw[N + i] = make_float2(v.x * g, v.y * g);
-      }
-      if (lane < 4) xw[N + cn + lane] = make_float2(0.f, 0.f);      // slack read by the last (partial) group
-      __syncthreads();
-      int pushed = 0, q = 0;
-      while (q < cn) {
-        const int jg = c0 + q;                                  // index inside the block
-        const int glen = min(((jg + 3) & ~3) - jg + 1, cn - q);  // up to and including the next update sample
-        float2 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = make_float2(0.f, 0.f);
-        float2 sl[TPL];                                         // state values of the group's LAST output (update operand)
-        float ms = 0.f;
-        // state after the push of sample q+t = xw[q+t+1 .. q+t+N]; y = sum state[i]*coeff[i] (V9)
-#pragma unroll
-        for (int j = 0; j < TPL; j++) {
-          const int i = lane + 64 * j;
-          float2 sv[4];
-#pragma unroll
-          for (int t = 0; t < 4; t++) sv[t] = (i < N) ? xw[q + 1 + t + i] : make_float2(0.f, 0.f);   // lanes past the last tap add exact zeros
-          const float2 cv = c[j];
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            acc[t].x = fmaf(sv[t].x, cv.x, acc[t].x); acc[t].x = fmaf(-sv[t].y, cv.y, acc[t].x);
-            acc[t].y = fmaf(sv[t].x, cv.y, acc[t].y); acc[t].y = fmaf(sv[t].y, cv.x, acc[t].y);
-          }
-          const float2 last = glen == 4 ? sv[3] : glen == 3 ? sv[2] : glen == 2 ? sv[1] : sv[0];
-          sl[j] = last;
-          if (i < N) ms += last.x * last.x + last.y * last.y;
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) { acc[t].x = wave_sum_dpp(acc[t].x); acc[t].y = wave_sum_dpp(acc[t].y); }
-        const float sum = wave_sum_dpp(ms);
-        int bad = -1;
-#pragma unroll
-        for (int t = 3; t >= 0; t--)
-          if (t < glen && (!isfinite(acc[t].x) || !isfinite(acc[t].y))) bad = t;   // first non-finite output
-        if (bad >= 0) { pushed = q + bad + 1; ok = 0; break; }                      // :182-184
-        pushed = q + glen;
-        if (lane < glen) {
-          const float2 yv = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
-          os[off + c0 + q + lane] = yv;
-        }
-        const int qlast = q + glen - 1;
-        if ((((c0 + qlast) & 3) == 0)) {                        // :176,186
-          const float2 y = glen == 1 ? acc[0] : glen == 2 ? acc[1] : glen == 3 ? acc[2] : acc[3];
-          const double env = (double)(y.x * y.x + y.y * y.y);
-          const double error = 1.0 - env;
-          const float mu = (float)(0.1 / ((double)sum + 1e-10));   // :130
-          const float factor = (float)(error * (double)mu);         // :133
-          const float fr = factor * y.x, fi = factor * y.y;
-#pragma unroll
-          for (int j = 0; j < TPL; j++) {                            // V10: lane l only ever touches its own taps
-            const int i = lane + 64 * j;
-            const float2 sv = sl[j];
-            float2 cv = c[j];
-            cv.x += sv.x * fr + sv.y * fi;
-            cv.y += sv.x * fi - sv.y * fr;
-            if (i == ref) cv = make_float2(1.f, 0.f);                // :158
-            if (i < N) c[j] = cv;
-          }
-          err_last = error;
-          if (!isfinite(error)) { ok = 0; break; }                   // :190-192
-        }
-        q += glen;
-      }
-      // new state = last N entries pushed so far
-      __syncthreads();
-      float2 tmp[TPL];
-#pragma unroll
-      for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; tmp[j] = (i < N) ? xw[pushed + i] : make_float2(0.f, 0.f); }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; if (i < N) xw[i] = tmp[j]; }
-      __syncthreads();
-    }
-    for (int i = lane; i < N; i += 64) sg[i] = xw[i];
-    if (!ok) {
-      // FmDecode.cpp:117-123: re-initialise the taps, block falls back to the AGC output
-#pragma unroll
-      for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; c[j] = make_float2(i == ref ? 1.f : 0.f, 0.f); }
-      resets++;
-    }
-    if (lane == 0) mpf_ok[(long long)s * bt.nb + b] = ok;
-    __syncthreads();
-  }
-#pragma unroll
-  for (int j = 0; j < TPL; j++) { const int i = lane + 64 * j; if (i < N) cg[i] = c[j]; }
-  if (lane == 0) { st[s].mpf_error = err_last; st[s].mpf_resets = resets; }
-}
+
+
 
 // ---------------------------------------------------------------------------
 // K_mpf v3: FOUR waves per stream.  The recurrence is a chain of ~N_if / 4 dependent steps (dot products -> error ->
@@ -1816,27 +1550,7 @@ __global__ __launch_bounds__(64) void k_pll(
   S.stereo_detected = (lock_cnt >= pc.lock_delay);
 }
 
-// ---------------------------------------------------------------------------
-// K_deemph : LowPassFilterRC::process_inplace (Filter.cpp:214-221) on the mono
-// and the L-R signals at 384 kHz.  Linear first-order recurrence, one lane per
-// (stream, channel).
-// ---------------------------------------------------------------------------
-__global__ void k_deemph(double *__restrict__ base, long long base_stride, int base_off,
-                         double *__restrict__ raw, long long raw_stride, int raw_off, int n,
-                         double b0, double a1, int do_mono, int do_stereo, StreamState *st, int n_streams) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int s = t >> 1, ch = t & 1;
-  if (s >= n_streams) return;
-  if ((ch == 0 && !do_mono) || (ch == 1 && !do_stereo)) return;
-  double *p = ch ? raw + (long long)s * raw_stride + raw_off : base + (long long)s * base_stride + base_off;
-  double x1 = ch ? st[s].de_stereo_x1 : st[s].de_mono_x1;
-  for (int i = 0; i < n; i++) {
-    const double x0 = p[i] - a1 * x1;
-    p[i] = b0 * x0;                  // b1 == 0
-    x1 = x0;
-  }
-  if (ch) st[s].de_stereo_x1 = x1; else st[s].de_mono_x1 = x1;
-}
+
 
 // ---------------------------------------------------------------------------
 // Audio resampler (AudioResampler.cpp:37-61 stand-in), FP64, two channels:

@@ -19,7 +19,6 @@
 //                          spread over the two epochs that follow its last input; then a third each of the
 //                          EPILOGUE: IF samples of the finished macro tile -> atan2 / wrapped difference (the
 //                          discriminator), float -> double widening, per-block partial sums, coalesced stores
-// (FUSED_A_FORM selects two older stage-A layouts for tools/bench_fused.hip.)
 // Arithmetic: every stage-A output is fp32 FMAs in a fixed order (quarter of the window, word, even / odd sample, then
 // the quad's reduction tree); stage B is bit-identical to k_ifr_poly4 (an f32 MFMA is a k-ordered fmaf chain).
 #pragma once
@@ -68,57 +67,24 @@ struct FusedArgs {
 constexpr int kFusedD = 10, kFusedNA = 103;      // the shape the product instantiates (fmradion_amd.hip)
 #define FUSED_TAP_PAD 32
 #define FUSED_TAP_LEN 232
-// Stage-A taps travel in the kernel-argument segment (constant address space): every tap load is a scalar load.
-// h[FUSED_TAP_PAD + k] = hA[k], zeros elsewhere.
+// Stage-A taps as the quad form reads them (FusedArgs::taps points at a device copy): h[FUSED_TAP_PAD + k] = hA[k], zeros elsewhere.
 struct FusedTaps { float h[FUSED_TAP_LEN]; };
 
-#ifndef FUSED_OPL
-#define FUSED_OPL 3          // stage-A outputs per lane: 3 (epochs of 500 mid samples, 3-slot ring) or 1 (250, 5 slots)
-#endif
 template <int D, int NA>
 struct FusedShape {
-  static constexpr int OPL = FUSED_OPL;
-  static constexpr int ME = (OPL == 3) ? 500 : 250;   // mid samples per epoch
+  static constexpr int ME = 500;                 // mid samples per epoch
   static constexpr int EPT = 1000 / ME;          // epochs per macro tile
-  static constexpr int LPW = (ME + 4 * OPL - 1) / (4 * OPL);   // active lanes of each of the four stage-A waves
   static constexpr int RS = D * ME + 144;        // input samples per ring slot (pre-roll NA - D + parity + slack), even
   static constexpr int NPIECE = RS / 2;          // 16-byte pieces per slot
   static constexpr int PRE = (RS - D * ME) / 2;  // pieces a region shares with the one before it
   static_assert(PRE > 64 && PRE <= 128, "fused_fill / fused_copy_preroll handle the shared pieces in DMA instructions 0 and 1");
   static constexpr int NDMA = (NPIECE + 63) / 64;
-  static constexpr int NSLOT = (OPL == 3) ? 3 : 5, AHEAD = NSLOT - 1;   // ring slots; the loader runs AHEAD epochs in front of stage A
-  static constexpr int NWORDS = ((OPL - 1) * D + NA + 2) / 2;           // 16-byte words a stage-A lane reads
+  static constexpr int NSLOT = 3, AHEAD = NSLOT - 1;   // ring slots; the loader runs AHEAD epochs in front of stage A
   static constexpr int MIDR = 3000, MIDM = 207;  // mid ring: three macro-tile windows + mirror of the first 207
-  static constexpr int SIDE = 2 * ME;            // k-split form: partial sums of the second half-wave, double buffered (float2)
-  static constexpr int LDS_BYTES = NSLOT * RS * 8 + (MIDR + MIDM + 1) * 8 + 384 * 8 + SIDE * 8 + 64;
-  static constexpr int NT = (NA + 1) / 2;        // distinct taps of the symmetric filter
-  static_assert((OPL * D) % 2 == 0 && ((OPL * D / 2) & 1) == 1, "lane stride must be an odd number of 16-byte words");
+  static constexpr int LDS_BYTES = NSLOT * RS * 8 + (MIDR + MIDM + 1) * 8 + 384 * 8 + 64;
   static_assert(NA - D + 1 + D * ME <= RS, "slot too small");
   static_assert((NA & 1) == 1 && NA + 2 * FUSED_TAP_PAD <= FUSED_TAP_LEN, "tap table");
   static_assert((AHEAD - 1) * NDMA <= 63, "vmcnt is a 6-bit counter");
-  static_assert(LPW <= 64 && 4 * LPW * OPL >= ME, "four stage-A waves cover an epoch");
-};
-
-// The distinct taps, two per 64-bit VGPR pair.  A packed FMA broadcasts either half of the pair through op_sel, so
-// a tap costs half a register pair and is never copied; the compiler does not form this operand by itself (it
-// materialises {h, h}), hence the two one-instruction asm statements.
-template <int NT>
-struct FusedTapRegs {
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  v2f p[(NT + 1) / 2];
-  __device__ __forceinline__ void load_sym(const float *h) {      // h[k] = hA[k]: the first NT taps of the symmetric filter
-#pragma unroll
-    for (int j = 0; j < (NT + 1) / 2; j++) {
-      p[j] = (v2f){h[2 * j], (2 * j + 1 < NT) ? h[2 * j + 1] : 0.f};
-      asm volatile("" : "+v"(p[j]));
-    }
-  }
-  // acc += tap[k] * x   (x = (re, im) of one sample)
-  template <int K>
-  __device__ __forceinline__ void fma(v2f &acc, v2f x) const {
-    if (K & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p[K >> 1]), "v"(x));
-    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(p[K >> 1]), "v"(x));
-  }
 };
 
 // one barrier per epoch.  LDS traffic only: no wave waits here for its global stores, and the loader's DMA stays
@@ -184,178 +150,7 @@ __device__ __forceinline__ void fused_wait_dma(int young) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// One group of G steps of the stage-A loop (compile-time recursion: the tap index of every FMA is a template constant).
-// Output o of the lane reads word I + (D/2) o at step I, so all OPL outputs use the SAME tap pair in the same step.
-// Accumulator chains: (output, even / odd sample of the word), and for OPL = 1 also word index mod 3 -- a dependent
-// v_pk_fma_f32 issues only every ~27 cycles, an independent one every ~6 (tools/bench_pkfma.hip): six chains.
-template <int D, int NA, int PAR, int I, int IEND>
-__device__ __forceinline__ void fused_a_steps(const FusedTapRegs<FusedShape<D, NA>::NT> &tv, const float __attribute__((ext_vector_type(4))) *x,
-                                              float __attribute__((ext_vector_type(2))) (&acc)[6]) {
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  if constexpr (I < IEND) {
-    constexpr int NT = FusedShape<D, NA>::NT, OPL = FusedShape<D, NA>::OPL, HD = D / 2;
-    constexpr int k0 = PAR + NA - 1 - 2 * I, k1 = k0 - 1;        // taps of the even / odd sample of word I
-#pragma unroll
-    for (int o = 0; o < OPL; o++) {
-      const int c = (OPL == 1) ? 2 * (I % 3) : 2 * o;
-      if constexpr (k0 >= 0 && k0 < NA) tv.template fma<(k0 < NT ? k0 : NA - 1 - k0)>(acc[c], (v2f){x[I + HD * o].x, x[I + HD * o].y});
-      if constexpr (k1 >= 0 && k1 < NA) tv.template fma<(k1 < NT ? k1 : NA - 1 - k1)>(acc[c + 1], (v2f){x[I + HD * o].z, x[I + HD * o].w});
-    }
-    fused_a_steps<D, NA, PAR, I + 1, IEND>(tv, x, acc);
-  }
-}
-template <int D, int NA, int PAR, int G, int PF, int GI>
-__device__ __forceinline__ void fused_a_groups(const FusedTapRegs<FusedShape<D, NA>::NT> &tv, const float __attribute__((ext_vector_type(4))) *w,
-                                               float __attribute__((ext_vector_type(4))) *x,
-                                               float __attribute__((ext_vector_type(2))) (&acc)[6]) {
-  constexpr int NSTEP = (PAR + NA - 1) / 2 + 1, NGRP = (NSTEP + G - 1) / G, NW = FusedShape<D, NA>::NWORDS;
-  if constexpr (GI < NGRP) {
-#pragma unroll
-    for (int t = 0; t < G; t++) {              // words first used PF / G groups from now
-      const int i = PF + G * GI + t;
-      if (i < NW) x[i] = w[i];
-    }
-    fused_a_steps<D, NA, PAR, G * GI, (G * GI + G < NSTEP ? G * GI + G : NSTEP)>(tv, x, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    fused_a_groups<D, NA, PAR, G, PF, GI + 1>(tv, w, x, acc);
-  }
-}
-
-// ---- role: stage A --------------------------------------------------------------------------------------
-// Lane L (LPW per wave) owns outputs OPL L .. OPL L + OPL - 1 of the epoch.  Sample q = OPL D L + 2 i + e of the slot
-// meets tap k = PAR + NA - 1 - 2 i - e of output 0 (PAR: parity of the region start); lane stride OPL D / 2 words,
-// odd => conflict-free ds_read_b128.  Loads run PF words ahead of the FMAs; the loop has no scalar loads, so LDS
-// data return in order and the waits are partial.
-template <int D, int NA, int PAR>
-__device__ __forceinline__ void fused_stage_a(const FusedArgs &a, const FusedTapRegs<FusedShape<D, NA>::NT> &tv, int s, int jE,
-                                              int pos0, const unsigned char *slot, float2 *midr, int aw, int lane,
-                                              bool no_math, int abl = 0) {
-  using SH = FusedShape<D, NA>;
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  if (lane >= SH::LPW) return;
-  const int L = SH::LPW * aw + lane;
-  if (SH::OPL * L >= SH::ME) return;
-  const v4f *w = reinterpret_cast<const v4f *>(__builtin_assume_aligned(slot, 16)) + (SH::OPL * D / 2) * L;
-  constexpr int NSTEP = (PAR + NA - 1) / 2 + 1, G = (SH::OPL == 3) ? 4 : 8, PF = (SH::OPL == 3) ? (D + 12) : 16;
-  static_assert(NSTEP + (SH::OPL - 1) * (D / 2) <= SH::NWORDS, "word window");
-  v2f acc[6];
-#pragma unroll
-  for (int c = 0; c < 6; c++) acc[c] = (v2f){0.f, 0.f};
-  if (!no_math) {
-    v4f x[SH::NWORDS + G + PF];
-    if (abl & 16) {       // ablation: the LDS reads alone
-      v4f sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < SH::NWORDS; i++) { const v4f t = w[i]; sum += t; }
-      acc[0] = (v2f){sum.x + sum.z, sum.y + sum.w};
-    } else {
-#pragma unroll
-      for (int i = 0; i < PF && i < SH::NWORDS; i++) x[i] = w[i];
-      fused_a_groups<D, NA, PAR, G, PF, 0>(tv, w, x, acc);
-    }
-  }
-  float2 y[3];
-  if (SH::OPL == 1) {
-    const v2f ys = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + (acc[4] + acc[5]);
-    y[0] = make_float2(ys.x, ys.y);
-  } else {
-#pragma unroll
-    for (int o = 0; o < 3; o++) { const v2f ys = acc[2 * o] + acc[2 * o + 1]; y[o] = make_float2(ys.x, ys.y); }
-  }
-#pragma unroll
-  for (int o = 0; o < SH::OPL; o++) {
-    const int jl = SH::OPL * L + o;
-    if (jl >= SH::ME) continue;
-    float2 yo = y[o];
-    const int j = jE + jl;
-    if (j < 0) {                     // produced by an earlier call: its tail is the prefix halo of d_mid, older samples are never used
-      const int h = j + a.H_mid;
-      yo = (h >= 0) ? a.mid[(long long)s * a.mid_stride + h] : make_float2(0.f, 0.f);
-    }
-    int pos = pos0 + jl;
-    if (pos >= SH::MIDR) pos -= SH::MIDR;
-    midr[pos] = yo;
-    if (pos < SH::MIDM) midr[pos + SH::MIDR] = yo;
-    // the next call's stage-B history: the last H_mid mid samples of this call, at their d_mid positions (k_shift_halo re-seats them)
-    if (j >= a.count_mid - a.H_mid && j < a.count_mid && j >= 0) a.mid[(long long)s * a.mid_stride + a.H_mid + j] = yo;
-  }
-}
-
-// ---- role: stage A, k-split form (12-wave workgroup) --------------------------------------------------------
-// Two waves on the same SIMD share each group of 42 x 3 outputs: wave HALF = 0 runs the first half of the window
-// (steps 0 .. NH-1) and stores into the mid ring, HALF = 1 the second and stores into a side buffer; the first wave
-// adds the two one epoch later (fused_a_fixup; LDS float atomics cost microseconds).  One wave alone issues a packed
-// FMA only every ~6 cycles; two co-resident waves fill the SIMD.  Taps are wave-uniform scalar loads (one group ahead).
-template <int D, int NA, int PAR, int HALF>
-__device__ __forceinline__ void fused_stage_a_half(const FusedArgs &a, const FusedTaps &taps, int s, int jE, int pos0,
-                                                   const unsigned char *slot, float2 *midr, float2 *side, int aw, int lane, bool no_math) {
-  using SH = FusedShape<D, NA>;
-  static_assert(SH::OPL == 3, "k-split form: three outputs per lane");
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  if (lane >= SH::LPW) return;
-  const int L = SH::LPW * aw + lane;
-  constexpr int HD = D / 2, NSTEP = (PAR + NA - 1) / 2 + 1, NH = (NSTEP + 1) / 2;
-  constexpr int I0 = HALF ? NH : 0, I1 = HALF ? NSTEP : NH, G = 4, PF = 8, NGRP = (I1 - I0 + G - 1) / G;
-  // tap pair of step i: hq[-2 i], hq[-2 i - 1]; the table sits in the kernarg segment (constant address space => s_load)
-  typedef const __attribute__((address_space(4))) float *cptr;
-  cptr hq = (cptr)(uintptr_t)(a.taps + FUSED_TAP_PAD + PAR + (NA - 1));
-  asm volatile("" : "+s"(hq));
-  const v4f *w = reinterpret_cast<const v4f *>(__builtin_assume_aligned(slot, 16)) + (3 * HD) * L;
-  v2f acc[3][2];
-#pragma unroll
-  for (int o = 0; o < 3; o++) acc[o][0] = acc[o][1] = (v2f){0.f, 0.f};
-  if (!no_math) {
-    v4f x[SH::NWORDS + G + PF];
-#pragma unroll
-    for (int i = I0; i < I0 + 2 * HD + PF && i < SH::NWORDS; i++) x[i] = w[i];
-    float hk[2][2 * G];
-#pragma unroll
-    for (int t = 0; t < 2 * G; t++) hk[0][t] = hq[-2 * I0 - t];
-#pragma unroll
-    for (int g = 0; g < NGRP; g++) {
-#pragma unroll
-      for (int t = 0; t < G; t++) {            // words first used two groups from now
-        const int i = I0 + 2 * HD + PF + G * g + t;
-        if (i < SH::NWORDS && i < I1 + 2 * HD) x[i] = w[i];
-      }
-      // taps of the next group (the table is zero padded).  The pointer is laundered per group: with a compile-time
-      // address the compiler loads all taps up front and spills them through v_writelane / v_readlane
-      asm volatile("" : "+s"(hq));
-#pragma unroll
-      for (int t = 0; t < 2 * G; t++) hk[(g + 1) & 1][t] = hq[-2 * (I0 + G * (g + 1)) - t];
-#pragma unroll
-      for (int t = 0; t < G; t++) {
-        const int i = I0 + G * g + t;
-        if (i < I1) {
-          const float h0 = hk[g & 1][2 * t], h1 = hk[g & 1][2 * t + 1];
-#pragma unroll
-          for (int o = 0; o < 3; o++) {
-            const v4f xx = x[i + HD * o];
-            acc[o][0] = __builtin_elementwise_fma((v2f){h0, h0}, (v2f){xx.x, xx.y}, acc[o][0]);
-            acc[o][1] = __builtin_elementwise_fma((v2f){h1, h1}, (v2f){xx.z, xx.w}, acc[o][1]);
-          }
-        }
-      }
-      // pin this group's FMAs here: without it instruction selection sinks every FMA below the last load
-      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#pragma unroll
-  for (int o = 0; o < 3; o++) {
-    const int jl = 3 * L + o;
-    if (jl >= SH::ME) continue;
-    float2 y = make_float2(acc[o][0].x + acc[o][1].x, acc[o][0].y + acc[o][1].y);
-    if (HALF) { side[jl] = y; continue; }           // added to the ring by the first-half wave one epoch later
-    int pos = pos0 + jl;
-    if (pos >= SH::MIDR) pos -= SH::MIDR;
-    midr[pos] = y;
-  }
-}
-
-// ---- role: stage A, quad form (12-wave workgroup, FUSED_A_FORM = 2) ------------------------------------------
+// ---- role: stage A, quad form (waves 4 .. 11) -----------------------------------------------------------------
 // Four neighbouring lanes share four consecutive outputs: lane 4 g + q runs quarter q of the tap window (QS = 13 of
 // the 52 word steps for NA = 103; 19 of 76 for the 151-tap Kaiser design of round 2) for outputs 4 g .. 4 g + 3, the quad adds its partial sums with two DPP steps and lane q stores
 // output 4 g + q -- a wave stores 64 consecutive mid samples.  Why this shape (tools/bench_ldsread.hip,
@@ -478,32 +273,6 @@ struct FusedQuad {
       if (j >= a.count_mid - a.H_mid && j < a.count_mid && j >= 0) a.mid[(long long)s * a.mid_stride + a.H_mid + j] = yo;
   }
 };
-
-// One epoch later: ring += second half's partial sum (the sum of two operands does not depend on the order), the
-// overrides for samples of earlier calls, the mirror of the ring's first positions and the next call's history.
-template <int D, int NA>
-__device__ __forceinline__ void fused_a_fixup(const FusedArgs &a, int s, int jE, int pos0, float2 *midr, const float2 *side, int aw, int lane) {
-  using SH = FusedShape<D, NA>;
-  if (lane >= SH::LPW) return;
-  const int L = SH::LPW * aw + lane;
-#pragma unroll
-  for (int o = 0; o < 3; o++) {
-    const int jl = 3 * L + o, j = jE + jl;
-    if (jl >= SH::ME) continue;
-    int pos = pos0 + jl;
-    if (pos >= SH::MIDR) pos -= SH::MIDR;
-    const float2 p0 = midr[pos], p1 = side[jl];
-    float2 y = make_float2(p0.x + p1.x, p0.y + p1.y);
-    if (j < 0) {                     // produced by an earlier call: its tail is the prefix halo of d_mid, older samples are never used
-      const int h = j + a.H_mid;
-      y = (h >= 0) ? a.mid[(long long)s * a.mid_stride + h] : make_float2(0.f, 0.f);
-    }
-    midr[pos] = y;
-    if (pos < SH::MIDM) midr[pos + SH::MIDR] = y;
-    // the next call's stage-B history: the last H_mid mid samples of this call, at their d_mid positions (k_shift_halo re-seats them)
-    if (j >= a.count_mid - a.H_mid && j < a.count_mid && j >= 0) a.mid[(long long)s * a.mid_stride + a.H_mid + j] = y;
-  }
-}
 
 // ---- role: stage B (a quarter of the k-steps of a macro tile per epoch) -----------------------------------
 template <int MT0, int NMT>
@@ -778,16 +547,9 @@ __global__ void k_fused_blk_reduce(const FusedPart *__restrict__ part, int n_til
 }
 
 // ABL: ablation mask for tools/bench_fused.hip (0 = product; 1 no stage-A arithmetic, 2 no stage-B MFMAs, 4 no input DMA)
-// FUSED_A_FORM: how stage A is laid over waves.  2 = quad form (product): 12-wave workgroup, eight stage-A waves, four
-// lanes per group of four outputs.  1 = k-split halves (12 waves, two waves per 42 x 3 outputs, partial sums through
-// LDS, one more epoch of latency).  0 = 8-wave workgroup, one wave per 42 x 3 outputs.  1 and 0 need FUSED_OPL = 3.
-#ifndef FUSED_A_FORM
-#define FUSED_A_FORM 2
-#endif
-#define FUSED_KSPLIT (FUSED_A_FORM == 1)
-#define FUSED_THREADS (FUSED_A_FORM ? 768 : 512)
+#define FUSED_THREADS 768     // twelve waves: loader, three stage-B waves, eight stage-A waves
 template <int D, int NA, int PAR, int ABL = 0>
-__global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedTaps taps) {
+__global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a) {
   using SH = FusedShape<D, NA>;
   constexpr bool DBG = (ABL & 32) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_f[];
@@ -798,7 +560,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedT
   const int i0 = blockIdx.x * a.tiles_per_wg;
   const int i1 = min(i0 + a.tiles_per_wg, a.n_tiles);
   if (i0 >= i1) return;
-  const int nt = i1 - i0, NE = SH::EPT * nt + SH::EPT + 2 + FUSED_KSPLIT, EA = SH::EPT * nt;       // EA = last stage-A epoch
+  const int nt = i1 - i0, NE = SH::EPT * nt + SH::EPT + 2, EA = SH::EPT * nt;       // EA = last stage-A epoch
   const int jE0 = a.j_ref + 1000 * i0;                         // first mid sample of epoch 0 (a macro tile = 1000 mid samples)
   const int pos00 = (a.pos_ref + 1000 * (i0 % 3)) % SH::MIDR;
   const int t3 = (a.t3_ref + i0) % 3;
@@ -843,12 +605,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedT
     if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[0] = busy; a.dbg[1] = FUSED_CLK() - t_begin; }
   } else if (wave == 1) {
     // ------------------------------------------------------------------ stage B (one row tile per wave) + a third of the epilogue
-    fused_role_b<SH::EPT, FUSED_KSPLIT, 0, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, 0, 0, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
   } else if (wave == 2) {
-    fused_role_b<SH::EPT, FUSED_KSPLIT, 1, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+    fused_role_b<SH::EPT, 0, 1, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
   } else if (wave == 3) {
-    fused_role_b<SH::EPT, FUSED_KSPLIT, 2, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
-  } else if (FUSED_A_FORM == 2) {
+    fused_role_b<SH::EPT, 0, 2, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);
+  } else {
     // ------------------------------------------------------------------ stage A, quad form
     const int aw = wave - 4;
     FusedQuad<D, NA, PAR> qa;
@@ -864,55 +626,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a, FusedT
         else qa.template run<FusedQuad<D, NA, PAR>::NW / 2, (ABL & 24)>(a, s, jE, pos0, sl, midr, aw, lane, (ABL & 1) != 0);
         slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
         if (aw == 7 && e < EA) fused_copy_preroll<D, NA>(sl, lds_f + (size_t)slot * SH::RS * 8, lane);
-        pos0 += SH::ME; if (pos0 >= SH::MIDR) pos0 -= SH::MIDR;
-        jE += SH::ME;
-      }
-      if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      busy += FUSED_CLK() - tb;
-      fused_barrier();
-    }
-    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[2 * wave] = busy; a.dbg[2 * wave + 1] = FUSED_CLK() - t_begin; }
-  } else if (FUSED_KSPLIT) {
-    // ------------------------------------------------------------------ stage A, two half-waves per output group
-    const int aw = (wave - 4) & 3, half = (wave - 4) >> 2;
-    float2 *side = stage + 384;
-    fused_barrier();
-    int slot = 0, pos0 = pos00, jE = jE0;
-    unsigned long long busy = 0, t_begin = FUSED_CLK();
-    for (int e = 0; e < NE; e++) {
-      const unsigned long long tb = FUSED_CLK();
-      if (half == 0 && e >= 1 && e <= EA + 1) {           // the epoch before this one: add the second half's partial sums
-        int pp = pos0 - SH::ME; if (pp < 0) pp += SH::MIDR;
-        fused_a_fixup<D, NA>(a, s, jE - SH::ME, pp, midr, side + ((e - 1) & 1) * SH::ME, aw, lane);
-      }
-      if (e <= EA) {
-        const unsigned char *sl = lds_f + (size_t)slot * SH::RS * 8;
-        if (half == 0) fused_stage_a_half<D, NA, PAR, 0>(a, taps, s, jE, pos0, sl, midr, side + (e & 1) * SH::ME, aw, lane, (ABL & 1) != 0);
-        else fused_stage_a_half<D, NA, PAR, 1>(a, taps, s, jE, pos0, sl, midr, side + (e & 1) * SH::ME, aw, lane, (ABL & 1) != 0);
-        slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
-        if (half == 1 && aw == 0 && e < EA) fused_copy_preroll<D, NA>(sl, lds_f + (size_t)slot * SH::RS * 8, lane);
-      }
-      if (e <= EA + 1) { pos0 += SH::ME; if (pos0 >= SH::MIDR) pos0 -= SH::MIDR; jE += SH::ME; }
-      if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      busy += FUSED_CLK() - tb;
-      fused_barrier();
-    }
-    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[2 * wave] = busy; a.dbg[2 * wave + 1] = FUSED_CLK() - t_begin; }
-  } else {
-    // ------------------------------------------------------------------ stage A (8-wave workgroup: one wave per output group)
-    const int aw = wave - 4;
-    FusedTapRegs<SH::NT> tv;
-    tv.load_sym(taps.h + FUSED_TAP_PAD);
-    fused_barrier();
-    int slot = 0, pos0 = pos00, jE = jE0;
-    unsigned long long busy = 0, t_begin = FUSED_CLK();
-    for (int e = 0; e < NE; e++) {
-      const unsigned long long tb = FUSED_CLK();
-      if (e <= EA) {
-        const unsigned char *sl = lds_f + (size_t)slot * SH::RS * 8;
-        fused_stage_a<D, NA, PAR>(a, tv, s, jE, pos0, sl, midr, aw, lane, (ABL & 1) != 0, ABL & 24);
-        slot = (slot == SH::NSLOT - 1) ? 0 : slot + 1;
-        if (aw == 0 && e < EA) fused_copy_preroll<D, NA>(sl, lds_f + (size_t)slot * SH::RS * 8, lane);
         pos0 += SH::ME; if (pos0 >= SH::MIDR) pos0 -= SH::MIDR;
         jE += SH::ME;
       }

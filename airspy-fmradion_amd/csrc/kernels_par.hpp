@@ -843,6 +843,15 @@ struct PllSync {
 // 0.31 ms).  Instead everything one workgroup hands to another inside a launch is stored and loaded with agent-scope
 // atomic accesses (write-through / L2-coherent), the producer waits for its stores to be acknowledged before it takes
 // its ticket, and the ticket itself is an agent-scope atomic.  The ticket is left at zero for the next launch.
+// This is NOT the HIP / LLVM memory model's release-acquire: it relies on gfx950's write-through agent-scope stores and
+// on s_waitcnt vmcnt(0) meaning "acknowledged by the L2".  Hence (i) the guard below, (ii) the rule that everything
+// handed over inside a launch goes through st_agent / ld_agent / atomics -- the buffers written with PLAIN stores in
+// these kernels (the `pre` composites and `ds` start deltas of k_pll_up, the nodes of k_pll_down, IterFlags by the
+// last arrival) are only read by LATER launches -- and (iii) tests/test_gpu_pll_forms.py: the three-launch form against
+// the seven-launch form (FMR_PLL_V1, no in-launch hand-off) over many rounds and streams: identical decisions, audio to 1e-9.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the in-launch hand-off of the PLL rounds is validated on gfx950 only"
+#endif
 __device__ __forceinline__ void st_agent(double *p, double v) {
   __hip_atomic_store((long long *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -873,12 +882,12 @@ __device__ __forceinline__ void pll_round_check(IterFlags &F, PllSync &Y, double
                                                 bool may_accept) {
   const int lane = threadIdx.x;
   const double mr = wave_max_d(__longlong_as_double((long long)__hip_atomic_load(&Y.rslot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-  Y.rslot[lane] = 0ull;
+  __hip_atomic_store(&Y.rslot[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (reset for the next launch: atomic like every other access to the slots)
   double mc[7];
 #pragma unroll
   for (int q = 0; q < 7; q++) {
     mc[q] = wave_max_d(__longlong_as_double((long long)__hip_atomic_load(&Y.dslot[lane][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-    Y.dslot[lane][q] = 0ull;
+    __hip_atomic_store(&Y.dslot[lane][q], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane != 0) return;
   double m = 0.0;

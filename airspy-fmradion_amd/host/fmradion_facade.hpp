@@ -203,37 +203,38 @@ public:
   // Latency for throughput: hold back `blocks` - 1 calls and decode `blocks` blocks in ONE batched call.  process()
   // then returns an empty vector ("nothing yet": the contract of FmDecode.cpp:89-92,185-188, which main.cpp:981-984
   // already handles) until the batch is full, and the audio of all its blocks at once.  One 65536-sample block per
-  // call costs ~0.37 ms, almost all of it launch overhead (~100 kernel launches); a batch costs about the same.
-  // Default 1 = the reference's call-by-call behaviour.  Call before the first process().
+  // call costs ~0.3 ms, almost all of it launch overhead (~85 kernel launches); a batch costs about the same.
+  // Default 1 = the reference's call-by-call behaviour.
+  //  * END OF STREAM: call flush() -- it decodes the blocks still held back (fewer than a batch).  Without it up to
+  //    blocks - 1 source blocks of audio would be lost; the reference decodes every block.
+  //  * The status getters (get_if_rms(), get_pps_events(), ...) describe the LAST block of the batch just decoded, the
+  //    PPS events all of its blocks.
+  //  * Raising the batch above the chain's capacity re-creates the chain and is therefore only possible before the first
+  //    process(); lowering it (or raising it again up to the capacity) is possible at any time and keeps held-back blocks.
   void set_batch_blocks(unsigned blocks) {
     if (blocks < 1) blocks = 1;
     if (blocks == m_batch) return;
+    if (blocks > m_capacity) {
+      if (m_started) fmr_detail::fail("FmDecoder::set_batch_blocks: a larger batch than the chain was created for, after the first process()");
+      fmr_destroy(m_chain);
+      m_cfg.max_blocks = (int)blocks;
+      m_chain = fmr_detail::make(m_cfg);
+      m_capacity = blocks;
+    }
     m_batch = blocks;
-    fmr_destroy(m_chain);
-    m_cfg.max_blocks = (int)blocks;
-    m_chain = fmr_detail::make(m_cfg);
   }
 
   // samples_in by value, audio resized by the callee, empty = "nothing yet" (FmDecode.cpp:85-92)
   void process(IQSampleVector samples_in, SampleVector &audio) {
     m_pps_fetched = false;       // PilotPhaseLock::process clears m_pps_events on every call (PilotPhaseLock.cpp:62)
     m_pps.clear();
-    if (m_batch > 1) {
+    m_started = true;
+    if (m_batch > 1 || !m_pending_len.empty()) {
       m_pending.insert(m_pending.end(), samples_in.begin(), samples_in.end());
       m_pending_len.push_back((uint32_t)samples_in.size());
       audio.clear();
       if (m_pending_len.size() < m_batch) { m_pps_fetched = true; return; }
-      audio.resize(2 * (m_pending.size() + 64 * m_pending_len.size()));
-      std::vector<uint32_t> alen(m_pending_len.size());
-      fmr_detail::check(fmr_process_blocks(m_chain, reinterpret_cast<const float *>(m_pending.data()), m_pending.size(),
-                                           m_pending_len.data(), (int)m_pending_len.size(), audio.data(), audio.size(),
-                                           alen.data()),
-                        "fmr_process_blocks");
-      size_t n = 0;
-      for (uint32_t v : alen) n += v;
-      audio.resize(n);
-      m_pending.clear();
-      m_pending_len.clear();
+      decode_pending(audio);
       return;
     }
     audio.resize(2 * (samples_in.size() + 64));
@@ -243,6 +244,16 @@ public:
                       "fmr_process");
     audio.resize(n);
   }
+  // Decode whatever set_batch_blocks() is still holding back (end of stream, or before a batch-size change that must
+  // not add latency).  audio is empty if nothing was pending.
+  void flush(SampleVector &audio) {
+    m_pps_fetched = false;
+    m_pps.clear();
+    audio.clear();
+    if (m_pending_len.empty()) { m_pps_fetched = true; return; }
+    decode_pending(audio);
+  }
+  size_t pending_blocks() const { return m_pending_len.size(); }
   bool stereo_detected() { return status().stereo_detected != 0; }
   float get_tuning_offset() { return status().baseband_mean * freq_dev; }
   float get_baseband_level() { return status().baseband_level; }
@@ -271,6 +282,26 @@ private:
     fmr_detail::check(fmr_get_status(m_chain, 0, &st), "fmr_get_status");
     return st;
   }
+  // the held-back blocks in calls of at most the chain's capacity (fmr_process_blocks takes any count up to max_blocks)
+  void decode_pending(SampleVector &audio) {
+    audio.resize(2 * (m_pending.size() + 64 * m_pending_len.size()));
+    size_t done_blocks = 0, done_samples = 0, n_audio = 0;
+    while (done_blocks < m_pending_len.size()) {
+      const size_t nb = std::min<size_t>(m_capacity, m_pending_len.size() - done_blocks);
+      size_t ns = 0;
+      for (size_t b = 0; b < nb; b++) ns += m_pending_len[done_blocks + b];
+      std::vector<uint32_t> alen(nb);
+      fmr_detail::check(fmr_process_blocks(m_chain, reinterpret_cast<const float *>(m_pending.data() + done_samples), ns,
+                                           m_pending_len.data() + done_blocks, (int)nb, audio.data() + n_audio,
+                                           audio.size() - n_audio, alen.data()),
+                        "fmr_process_blocks");
+      for (uint32_t v : alen) n_audio += v;
+      done_blocks += nb; done_samples += ns;
+    }
+    audio.resize(n_audio);
+    m_pending.clear();
+    m_pending_len.clear();
+  }
   void fetch_pps() {
     if (m_pps_fetched) return;
     fmr_pps_event ev[64];
@@ -284,7 +315,8 @@ private:
   bool m_stereo;
   bool m_pps_fetched = true;
   std::vector<PilotPhaseLock::PpsEvent> m_pps;
-  unsigned m_batch = 1;
+  unsigned m_batch = 1, m_capacity = 1;
+  bool m_started = false;
   IQSampleVector m_pending;
   std::vector<uint32_t> m_pending_len;
   std::vector<std::complex<float>> m_coeff;

@@ -8,7 +8,8 @@
 //                   2^-(bits-1) (u8: (b - 128) / 128), float is taken as is -- what sf_read_float delivers.
 //   AudioFileWriter the file side of AudioOutput (sfmbase/AudioOutput.cpp:34-167 SndfileOutput): RAW or WAV in int16
 //                   (lrint(x * 32767), libsndfile's normalised double -> short, no clipping) or float32; the WAV
-//                   header is finalised on close, as RF64 ('ds64' chunk) when the data passes 4 GiB -- the outcome of
+//                   header is valid from the start and refreshed as the data grow (SFC_SET_UPDATE_HEADER_AUTO, :91-93),
+//                   as RF64 ('ds64' chunk) when the data passes 4 GiB -- the outcome of
 //                   SFC_RF64_AUTO_DOWNGRADE (:78-89).
 //   adjust_gain     the -6 dB of main.cpp:1000-1002;  pps_line: the PPS text record of main.cpp:1084-1111.
 //
@@ -89,6 +90,7 @@ private:
     default: return 4;
     }
   }
+  static constexpr uint64_t kMaxHeaderChunk = 4096;
   static uint32_t rd32(const unsigned char *p) { return p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24; }
   bool parse_wav(const std::string &path) {
     unsigned char h[12];
@@ -104,12 +106,14 @@ private:
       if (std::fread(ck, 1, 8, m_fp) != 8) { m_error = "no data chunk in " + path; return false; }
       uint64_t size = rd32(ck + 4);
       if (!std::memcmp(ck, "ds64", 4)) {
+        if (size < 16 || size > kMaxHeaderChunk) { m_error = "bad ds64 chunk"; return false; }    // sizes come from an untrusted header
         std::vector<unsigned char> b((size_t)size);
-        if (std::fread(b.data(), 1, b.size(), m_fp) != b.size() || size < 16) { m_error = "bad ds64 chunk"; return false; }
+        if (std::fread(b.data(), 1, b.size(), m_fp) != b.size()) { m_error = "bad ds64 chunk"; return false; }
         data64 = (uint64_t)rd32(b.data() + 8) | (uint64_t)rd32(b.data() + 12) << 32;
       } else if (!std::memcmp(ck, "fmt ", 4)) {
+        if (size < 16 || size > kMaxHeaderChunk) { m_error = "bad fmt chunk"; return false; }
         std::vector<unsigned char> b((size_t)size);
-        if (std::fread(b.data(), 1, b.size(), m_fp) != b.size() || size < 16) { m_error = "bad fmt chunk"; return false; }
+        if (std::fread(b.data(), 1, b.size(), m_fp) != b.size()) { m_error = "bad fmt chunk"; return false; }
         unsigned tag = b[0] | b[1] << 8;
         const unsigned channels = b[2] | b[3] << 8, bits = b[14] | b[15] << 8;
         m_rate = rd32(b.data() + 4);
@@ -124,6 +128,9 @@ private:
       } else if (!std::memcmp(ck, "data", 4)) {
         if (!have_fmt) { m_error = "data chunk before fmt chunk"; return false; }
         m_left = (rf64 && size == 0xFFFFFFFFu) ? data64 : size;
+        // streaming recorders leave 0 or 0xFFFFFFFF in the data size (the header is never finalised): the data then
+        // run to the end of the file
+        if (m_left == 0 || (!rf64 && size == 0xFFFFFFFFu) || (rf64 && size == 0xFFFFFFFFu && data64 == 0)) m_left = UINT64_MAX;
         return true;
       } else {
         if (std::fseek(m_fp, (long)(size + (size & 1)), SEEK_CUR)) { m_error = "truncated file"; return false; }
@@ -149,8 +156,10 @@ public:
     close();
     m_fp = std::fopen(path.c_str(), "wb");
     if (!m_fp) { m_error = "can not open '" + path + "'"; return false; }
-    m_rate = samplerate; m_channels = stereo ? 2 : 1; m_fmt = fmt; m_bytes = 0;
-    if (is_wav()) { unsigned char z[80] = {0}; std::fwrite(z, 1, header_size(), m_fp); }   // finalised on close
+    m_rate = samplerate; m_channels = stereo ? 2 : 1; m_fmt = fmt; m_bytes = 0; m_header_at = 0;
+    // a valid header from the first byte on, refreshed as the data grow (the reference sets
+    // SFC_SET_UPDATE_HEADER_AUTO, AudioOutput.cpp:91-93): a receiver that is killed leaves a playable file
+    if (is_wav() && !write_header()) { m_error = "can not write the header of '" + path + "' (not seekable?)"; close_raw(); return false; }
     return true;
   }
   bool write(const SampleVector &samples) {
@@ -166,17 +175,19 @@ public:
       if (std::fwrite(m_f32.data(), 4, m_f32.size(), m_fp) != m_f32.size()) { m_error = "write failed"; return false; }
       m_bytes += 4 * m_f32.size();
     }
+    // refresh the header every ~second of audio (and on close): cheap, and the file stays valid
+    if (is_wav() && m_bytes - m_header_at >= (uint64_t)m_rate * m_channels * 2) {
+      if (!write_header()) { m_error = "header update failed"; return false; }
+    }
     return true;
   }
   void close() {
     if (!m_fp) return;
     if (is_wav()) {
       if (m_bytes & 1) std::fputc(0, m_fp);
-      std::fseek(m_fp, 0, SEEK_SET);
-      write_header();
+      if (!write_header()) m_error = "header update failed";
     }
-    std::fclose(m_fp);
-    m_fp = nullptr;
+    close_raw();
   }
   const std::string &error() const { return m_error; }
 
@@ -185,7 +196,9 @@ private:
   // one layout for both outcomes: 'RIFF' + 'JUNK' placeholder (plain WAV), or 'RF64' + 'ds64' (data >= 4 GiB)
   static constexpr size_t header_size() { return 12 + 8 + 28 + 8 + 16 + 8; }
   static void put32(unsigned char *p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; }
-  void write_header() {
+  void close_raw() { if (m_fp) std::fclose(m_fp); m_fp = nullptr; }
+  // (re)write the header for the bytes written so far and return to the end of the data
+  bool write_header() {
     unsigned char h[80] = {0};
     const bool f32 = m_fmt == AudioFormat::WAV_FLOAT32;
     const unsigned bits = f32 ? 32 : 16, align = m_channels * bits / 8;
@@ -209,12 +222,16 @@ private:
     h[68] = (unsigned char)align; h[70] = (unsigned char)bits;
     std::memcpy(h + 72, "data", 4);
     put32(h + 76, big ? 0xFFFFFFFFu : (uint32_t)m_bytes);
-    std::fwrite(h, 1, header_size(), m_fp);
+    if (std::fseek(m_fp, 0, SEEK_SET)) return false;
+    if (std::fwrite(h, 1, header_size(), m_fp) != header_size()) return false;
+    if (std::fseek(m_fp, 0, SEEK_END)) return false;
+    m_header_at = m_bytes;
+    return true;
   }
   std::FILE *m_fp = nullptr;
   unsigned m_rate = 0, m_channels = 2;
   AudioFormat m_fmt = AudioFormat::RAW_INT16;
-  uint64_t m_bytes = 0;
+  uint64_t m_bytes = 0, m_header_at = 0;
   std::vector<int16_t> m_i16;
   std::vector<float> m_f32;
   std::string m_error;

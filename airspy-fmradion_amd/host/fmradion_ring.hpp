@@ -39,27 +39,30 @@ class PinnedIqRing {
   // The default allocator is the library's page-locked one; tests of the ring logic alone may pass malloc / free.
   PinnedIqRing(size_t block_bytes, size_t n_blocks, alloc_fn alloc = fmr_host_alloc, free_fn release = fmr_host_free)
       : m_block(block_bytes), m_n(n_blocks), m_free(release) {
+    m_valid = new size_t[m_n]();
     m_mem = static_cast<unsigned char *>(alloc(m_block * m_n));
     if (!m_mem) {
       std::fprintf(stderr, "PinnedIqRing: cannot allocate %zu bytes of page-locked memory: %s\n", m_block * m_n, fmr_last_error());
       std::exit(1);                       // the reference's sources fail hard at start-up too; there is no pageable fallback
     }
   }
-  ~PinnedIqRing() { if (m_mem) m_free(m_mem); }
+  ~PinnedIqRing() { if (m_mem) m_free(m_mem); delete[] m_valid; }
   PinnedIqRing(const PinnedIqRing &) = delete;
   PinnedIqRing &operator=(const PinnedIqRing &) = delete;
 
   // ---- producer (driver callback thread) ----------------------------------------------------------------------
   // Copy one block (exactly block_bytes, or fewer for the last block of a stream: the rest is zero filled and the
-  // valid byte count is remembered).  false = ring full, the block is dropped and counted (DataBuffer::push, :35-45).
+  // valid byte count is kept per slot).  false = ring full, the block is dropped and counted (DataBuffer::push, :35-45);
+  // a buffer LARGER than a block is refused and counted too (nothing is truncated silently).
   bool push(const void *data, size_t bytes) {
     if (bytes == 0) return true;
-    if (bytes > m_block) bytes = m_block;
+    if (bytes > m_block) { m_oversize.fetch_add(1, std::memory_order_relaxed); return false; }
     const uint64_t h = m_head.load(std::memory_order_relaxed);
     if (h - m_tail.load(std::memory_order_acquire) >= m_n) { m_overruns.fetch_add(1, std::memory_order_relaxed); return false; }
     unsigned char *dst = m_mem + (h % m_n) * m_block;
     std::memcpy(dst, data, bytes);
     if (bytes < m_block) std::memset(dst + bytes, 0, m_block - bytes);
+    m_valid[h % m_n] = bytes;                      // published by the release store of m_head below
     m_last_bytes.store(bytes, std::memory_order_relaxed);
     m_head.store(h + 1, std::memory_order_release);
     { std::lock_guard<std::mutex> lk(m_mu); }
@@ -97,9 +100,12 @@ class PinnedIqRing {
 
   size_t queued() const { return (size_t)(m_head.load(std::memory_order_acquire) - m_tail.load(std::memory_order_acquire)); }   // DataBuffer::queue_size
   size_t overruns() const { return m_overruns.load(std::memory_order_relaxed); }
+  size_t oversize_rejected() const { return m_oversize.load(std::memory_order_relaxed); }
+  // valid bytes of block i of the run pull() has just returned (block_bytes except for a short final block)
+  size_t run_block_bytes(size_t i) const { return m_valid[(size_t)((m_tail.load(std::memory_order_relaxed) + i) % m_n)]; }
   size_t block_bytes() const { return m_block; }
   size_t depth() const { return m_n; }
-  // valid bytes of the block pushed last (a short final block)
+  // valid bytes of the block pushed LAST (ambiguous once more than one block is queued: prefer run_block_bytes)
   size_t last_block_bytes() const { return m_last_bytes.load(std::memory_order_relaxed); }
 
  private:
@@ -107,7 +113,8 @@ class PinnedIqRing {
   free_fn m_free;
   unsigned char *m_mem = nullptr;
   std::atomic<uint64_t> m_head{0}, m_tail{0};
-  std::atomic<size_t> m_overruns{0}, m_last_bytes{0};
+  std::atomic<size_t> m_overruns{0}, m_last_bytes{0}, m_oversize{0};
+  size_t *m_valid = nullptr;                       // [n_blocks]: valid bytes per slot
   std::atomic<bool> m_end{false};
   std::mutex m_mu;
   std::condition_variable m_cv;

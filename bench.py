@@ -112,6 +112,17 @@ def _cpu_worker(args):
             return done, dt
 
 
+def csrc_hash():
+    """sha256 (16 hex digits) over the kernel sources: stamps the PMC summary with the code it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "airspy-fmradion_amd", "csrc", "*"))):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def committed_pmc_traffic(dom_name, blocks, streams, args):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN_pmc_traffic.json,
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/collect_profiles.sh): counters
@@ -126,10 +137,43 @@ def committed_pmc_traffic(dom_name, blocks, streams, args):
             continue
         if d.get("blocks_per_step") != blocks:
             continue
+        if d.get("csrc_sha256_16") != csrc_hash():
+            # the counters were collected on other kernel sources: not this code's traffic
+            return None, os.path.relpath(fn, ROOT) + " is stale (kernel sources changed since the PMC pass): traffic dropped"
         for k, v in d.get("kernels", {}).items():
             if ("k_" + dom_name) in k:
-                return v["hbm_bytes"], os.path.relpath(fn, ROOT) + " (PMC pass of the same command; read bytes = 2 x FETCH_SIZE x 1024, gfx950)"
+                return v["hbm_bytes"], os.path.relpath(fn, ROOT) + " (PMC pass of the same command on these kernel sources; read bytes = 2 x FETCH_SIZE x 1024, gfx950)"
     return None, None
+
+
+def verify_timed_step(iq0, audio_last, alen_last, B, blk, blocks_done, n_cmp=20, settle=150):
+    """Oracle check of the LAST TIMED step.  The oracle cannot follow the whole run (57 MS/s), but every recurrence of the
+    chain forgets: started cold at a stream position where the resampler phase repeats (a multiple of 625 blocks of
+    65536 samples = 24 x 65536 IF samples) and `settle` blocks before the compared ones, it agrees with an oracle that
+    ran from sample 0 to 4e-12 (tests/test_oracle_end_to_end.py).  iq0: stream 0's periodic buffer (B blocks)."""
+    g_end = blocks_done                                  # the last timed step covered stream blocks [g_end - B, g_end)
+    q = max(0, (g_end - (settle + n_cmp)) // 625)
+    g0 = 625 * q
+    if g_end - g0 > 1500 or g_end - g0 < n_cmp + (settle if g0 else 0):
+        return None                                      # (cannot happen for B >= 20: kept as a guard)
+    ifr, dec = _oracle_chain("fm")
+    ref = []
+    for g in range(g0, g_end):
+        b = g % B
+        a = dec.process(ifr.process(iq0[b * blk:(b + 1) * blk]))
+        if g >= g_end - n_cmp:
+            ref.append(a)
+    offs = np.concatenate([[0], np.cumsum(alen_last)]).astype(np.int64)
+    errs, n = 0.0, 0
+    for i, a in enumerate(ref):
+        loc = B - n_cmp + i
+        got = audio_last[offs[loc]:offs[loc + 1]]
+        assert len(got) == len(a), (len(got), len(a), loc)
+        errs += float(np.sum((got - a) ** 2))
+        n += len(a)
+    return {"rms_err_vs_oracle": float("%.3e" % np.sqrt(errs / max(n, 1))), "blocks_compared": n_cmp, "audio_samples_compared": n,
+            "oracle_started_at_stream_block": g0, "stream_blocks_before_the_compared_ones": g_end - n_cmp - g0,
+            "what": "stream 0, the last blocks of the LAST TIMED step"}
 
 
 def cpu_baseline(mode, stages, seconds=8.0):
@@ -146,6 +190,56 @@ def cpu_baseline(mode, stages, seconds=8.0):
                       f"IfResampler + {'AmDecoder' if mode == 'am' else 'FmDecoder'} (VOLK-generic semantics), gcc -O3 no fast-math",
             "all_cores": {"value": round(agg / 1e6, 3), "unit": "MS/s", "cores": ncores,
                           "sample": f"{ncores} streams on {ncores} processes, {seconds:.0f} s each"}}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher in the environment: start one process per GPU here (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), wait for all of them and pass rank 0's JSON line
+    through.  A run that asks for N GPUs can therefore never quietly measure one."""
+    import subprocess
+    n = args.gpus
+    if not args.cpu_dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        assert have >= n, f"--gpus {n} but only {have} GPU(s) are visible"
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"rank return codes {rcs}")
+
+
+def pin_rank_to_cores():
+    """One slice of the host's cores per local rank: a step is ~85 kernel launches from one host thread, and N ranks
+    enqueueing from the same few cores would contend (host_enqueue_ms_per_step is more than half of a step)."""
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if lw <= 1 or not hasattr(os, "sched_setaffinity"):
+        return
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // lw
+        if per >= 1:
+            os.sched_setaffinity(0, cores[lr * per:(lr + 1) * per])
+    except OSError:
+        pass
 
 
 def main():
@@ -176,11 +270,18 @@ def main():
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="test hook: gloo backend, the per-rank step is the CPU oracle on a tiny sample -- exercises the "
                          "launch / barrier / aggregation contract without a GPU (tests/test_multi_process.py)")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="after the headline line, print one line each for configs[2] (AM), configs[3] (-E 64), configs[4] "
+                         "(32 streams per GPU) and the mono-station case, each with its own audio check and CPU baseline")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)              # `python bench.py --gpus N` without a launcher: spawn the N ranks here
 
     import torch
     import torch.distributed as dist
 
+    pin_rank_to_cores()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -260,6 +361,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    blocks_done = (1 + args.warmup + args.steps) * B     # stream blocks decoded so far (set-up call + warm-up + timed steps)
+    audio_last = audio[0, :int(alen.sum())].cpu().numpy().copy() if rank == 0 else None   # stream 0, the last TIMED step
     region = {}
     for name, ms in ch.kernel_times():
         region.setdefault(name, []).append(ms)
@@ -277,10 +380,14 @@ def main():
         a[0] += ms
         a[1] += 1
     ch.enable_kernel_timing(0)
+    per_rank_ms = [round(dt / args.steps * 1e3, 4)]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 4) for t in allt]
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        dt = float(mine.item())
     total_samples = world * S * n * args.steps
     value = total_samples / dt / 1e6
     if not am and not args.no_pilot:
@@ -307,6 +414,13 @@ def main():
                                 "blocks_checked": nchk, "audio_samples_checked": len(ref), "tolerance": 1e-5,
                                 "what": "stream 0, first call of this chain (cold start and lock included)"})
             assert err < 1e-5, f"audio RMS error {err} vs oracle exceeds the north-star tolerance"
+        if fmt == 0 and not am and not args.multipath_stages and B >= 20:
+            iq0 = iq[0].cpu().numpy().view(np.complex64).reshape(-1)
+            tv = verify_timed_step(iq0, audio_last, alen, B, blk, blocks_done)
+            del iq0
+            if tv is not None:
+                audio_check["timed_step"] = tv
+                assert tv["rms_err_vs_oracle"] < 1e-5, f"timed step: audio RMS error {tv} vs oracle exceeds the north-star tolerance"
         if am:
             workload = "configs[2]: AM 384 kS/s complex-float IQ in HBM, IfResampler(48 k) + AmDecoder narrow filter -> f64 audio"
         elif args.no_pilot:
@@ -324,6 +438,7 @@ def main():
             "metric": ("IQ MS/s (AM, 384 kS/s in), whole job" if am else "IQ MS/s (FM stereo, 10 MS/s in), whole job"),
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ranks_seen": world, "per_rank_ms_per_step": per_rank_ms,
             "vs_baseline": None, "dtype": "f32 front end / f64 after the discriminator", "data": "synthetic",
             "config": {"workload": workload,
                        "input_format": args.input_format, "streams_per_gpu": S, "blocks_per_step": B, "block_len": blk,
@@ -354,10 +469,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.mode, args.multipath_stages)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     ch.close()
     if world > 1:
         dist.destroy_process_group()
+    if args.all_configs and world == 1:
+        # the other configurations of BASELINE.json, one line each, same run, same box (never the headline)
+        import subprocess
+        extra = [["--mode", "am", "--steps", "20", "--warmup", "3"],                                            # configs[2]
+                 ["--multipath-stages", "64", "--blocks", "64", "--steps", "5", "--warmup", "3"],               # configs[3]
+                 ["--streams", "32", "--blocks", "128", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],  # configs[4] shard
+                 ["--no-pilot", "--blocks", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]]        # mono station
+        for fl in extra:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + fl, capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            print(line[-1] if line else json.dumps({"config": {"workload": " ".join(fl)}, "error": r.stderr[-400:]}), flush=True)
 
 
 def block_api(args, ch, iq, blk, fs, rank, world, am):
@@ -431,14 +557,19 @@ def dry_run(args, rank, world, S, B, blk):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = [round(dt / args.steps * 1e3, 4)]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt], dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 4) for t in allt]
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        dt = float(mine.item())
     total = world * S * nb * blk * args.steps
     if rank == 0:
         print(json.dumps({"metric": "IQ MS/s (FM stereo, 10 MS/s in), whole job", "value": round(total / dt / 1e6, 3), "unit": "MS/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                          "ranks_seen": world, "per_rank_ms_per_step": per_rank_ms,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "cpu oracle", "data": "DRY RUN (CPU oracle, gloo) -- not a measurement",
                           "config": {"workload": "dry run of the launch contract", "streams_per_gpu": S, "blocks_per_step": nb,
                                      "samples_per_step_per_gpu": S * nb * blk},

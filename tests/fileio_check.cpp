@@ -40,6 +40,17 @@ int main(int argc, char **argv) {
       adjust_gain(part, atof(argv[7]));
       if (!w.write(part)) return 4;
     }
+    if (argc >= 9) {
+      // snapshot of the file BEFORE close(): a receiver that is killed here must leave a playable file
+      FILE *a = fopen(argv[4], "rb"), *b = fopen(argv[8], "wb");
+      if (!a || !b) return 5;
+      std::vector<unsigned char> all;
+      unsigned char tmp[4096];
+      size_t n;
+      while ((n = fread(tmp, 1, sizeof tmp, a)) > 0) all.insert(all.end(), tmp, tmp + n);
+      fwrite(all.data(), 1, all.size(), b);
+      fclose(a); fclose(b);
+    }
     w.close();
     std::printf("%s\n%s\n", pps_line(3, 123456789, 1700000000.25, -12.3456).c_str(), pps_block_line(42, 1700000000.5, 3.2).c_str());
     return 0;

@@ -68,7 +68,15 @@ int main() {
     CHECK(p && n == 1);
     const unsigned char *q = static_cast<const unsigned char *>(p);
     for (int k = 0; k < 64; k++) CHECK(q[k] == (k < 10 ? 0xAB : 0));
+    CHECK(ring.run_block_bytes(0) == 10);             // valid bytes per slot, not only of the block pushed last
     ring.release(1);
+    // a buffer larger than a block is refused and counted -- never truncated
+    unsigned char big[65] = {0};
+    CHECK(!ring.push(big, 65) && ring.oversize_rejected() == 1 && ring.queued() == 0 && ring.overruns() == 1);
+    CHECK(ring.push(buf, 64) && ring.push(buf, 7));
+    p = ring.pull(16, n);
+    CHECK(p && n == 2 && ring.run_block_bytes(0) == 64 && ring.run_block_bytes(1) == 7 && ring.last_block_bytes() == 7);
+    ring.release(2);
     ring.push_end();
     p = ring.pull(16, n);
     CHECK(!p && n == 0 && ring.pull_end_reached());

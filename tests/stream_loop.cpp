@@ -73,6 +73,14 @@ int main(int argc, char **argv) {
         }
       }
     }
+    if (modtype == ModType::FM && fm.pending_blocks()) {
+      // end of stream in batch mode: the blocks the facade still holds back (variant C)
+      SampleVector audiosamples(0);
+      fm.flush(audiosamples);
+      fmr_io::adjust_gain(audiosamples, fm.get_if_rms() >= squelch_level ? 0.5 : 0.0);
+      fwrite(audiosamples.data(), sizeof(double), audiosamples.size(), fau);
+      if (argc >= 9) wav.write(audiosamples);
+    }
   } catch (const std::exception &e) {
     std::printf("no gpu: %s\n", e.what());
     return 10;

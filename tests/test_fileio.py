@@ -139,3 +139,45 @@ def test_stereo_wav_roundtrip_through_reader(exe, tmp_path):
     got, rate, _, s = _read(exe, str(tmp_path), dst, False, "FLOAT")
     assert rate == 48000 and s == 1234
     assert np.array_equal(got.view(np.float32), audio.astype(np.float32))
+
+
+def test_wav_with_unfinalised_data_size(exe, tmp_path):
+    """Streaming recorders leave 0 (or 0xFFFFFFFF) in the data chunk's size: the data then run to the end of the file."""
+    n = 3000
+    iq = RNG.integers(-32768, 32768, size=(n, 2)).astype(np.int16)
+    for size_field in (0, 0xFFFFFFFF):
+        path = os.path.join(tmp_path, f"stream_{size_field}.wav")
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 0xFFFFFFFF if size_field else 0) + b"WAVE")
+            f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 912000, 912000 * 4, 4, 16))
+            f.write(b"data" + struct.pack("<I", size_field))
+            f.write(iq.tobytes())
+        got, rate, blocks, samples = _read(exe, str(tmp_path), path, False, "FLOAT")
+        assert rate == 912000 and samples == n
+        assert np.array_equal(got.view(np.float32).reshape(-1, 2), (iq / 32768.0).astype(np.float32))
+
+
+def test_wav_header_chunk_sizes_are_bounded(exe, tmp_path):
+    """A header that announces a gigabyte-sized fmt chunk is refused, not allocated."""
+    path = os.path.join(tmp_path, "evil.wav")
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 100) + b"WAVE" + b"fmt " + struct.pack("<I", 0xF0000000) + b"\0" * 64)
+    r = subprocess.run([exe, "read", path, "0", "FLOAT", "1000", os.path.join(tmp_path, "o.cf32")], capture_output=True, text=True)
+    assert r.returncode == 3 and "bad fmt chunk" in r.stdout
+
+
+def test_wav_writer_file_is_valid_before_close(exe, tmp_path):
+    """The header is written at open and refreshed while the data grow (SFC_SET_UPDATE_HEADER_AUTO, AudioOutput.cpp:91-93):
+    a copy of the file taken BEFORE close() is a readable WAV holding all but (at most) the last second."""
+    n = 5 * 48000 * 2 + 777 * 2
+    x = RNG.uniform(-0.9, 0.9, n)
+    fin, fout, snap = (os.path.join(tmp_path, k) for k in ("a.f64", "a.wav", "snapshot.wav"))
+    x.tofile(fin)
+    r = subprocess.run([exe, "write", "WAV_INT16", fin, fout, "48000", "1", "1.0", snap], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    rate, full = wavfile.read(fout)
+    assert rate == 48000 and full.shape == (n // 2, 2)
+    rate_s, part = wavfile.read(snap)              # scipy refuses a zero / garbage header
+    assert rate_s == 48000 and part.shape[1] == 2
+    assert n // 2 - 48000 - 1 <= part.shape[0] <= n // 2
+    assert np.array_equal(part, full[:part.shape[0]])

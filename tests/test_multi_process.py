@@ -80,3 +80,23 @@ def test_bench_launch_contract_two_ranks_gloo():
     assert out["config"]["samples_per_step_per_gpu"] == 2 * 2 * 65536
     assert out["value"] == pytest.approx(2 * 2 * 2 * 65536 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6, rel=1e-2)
     assert "DRY RUN" in out["data"]
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with NO launcher in the environment must start two ranks itself (round 2: it silently ran
+    one) and say how many ranks it saw."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "2",
+           "--cpu-dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and len(out["per_rank_ms_per_step"]) == 2
+    assert out["config"]["samples_per_step_per_gpu"] == 2 * 2 * 65536
+    assert out["ms_per_step"] == pytest.approx(max(out["per_rank_ms_per_step"]), rel=1e-3)

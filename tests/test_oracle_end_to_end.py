@@ -141,3 +141,21 @@ def test_ssb_oracle_sideband_selection(am_narrow):
     pitch, _ = run(ora.MODE_CW, carrier)
     assert abs(f[np.argmax(np.abs(np.fft.rfft(pitch * np.hanning(16384))))] - 500.0) < 6.0
 
+
+
+def test_oracle_late_start_forgets(pilotcut):
+    """bench.py checks its LAST TIMED step against an oracle that starts cold 150+ blocks earlier, at a stream position
+    where the resampler phase repeats (a multiple of 625 blocks of 65536 samples).  Premise: every recurrence of the chain
+    forgets -- such an oracle agrees with one that ran from sample 0."""
+    blk, nb, g0 = 65536, 625 + 175, 625
+    x = siggen.fm_stereo_iq(nb * blk, 10e6)
+    def chain():
+        return ora.IfResampler(10e6, 384e3), ora.FmDecoder(False, DELAY3, True, 50.0, False, 0, pilotcut)
+    ifr, dec = chain()
+    full = [dec.process(ifr.process(x[i * blk:(i + 1) * blk])) for i in range(nb)]
+    ifr, dec = chain()
+    late = [dec.process(ifr.process(x[i * blk:(i + 1) * blk])) for i in range(g0, nb)]
+    for k in range(150, nb - g0):
+        a, b = full[g0 + k], late[k]
+        assert len(a) == len(b)
+        assert np.sqrt(np.mean((a - b) ** 2)) < 1e-10

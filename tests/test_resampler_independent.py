@@ -12,7 +12,7 @@
    Nyquist and rejects from Nyquist on; the product is flat to 88.5 % and lets 170..192 kHz fall off.  An "r8brain-class"
    resampler (same two-stage structure, 2 % transition, 180 dB, fp64) is built in the oracle and both decode the same
    FM signals -- alone, and with a second carrier 200 kHz / 100 kHz away.  The audio difference is asserted below the
-   north-star tolerance where the band is clean and REPORTED (profiles/r02_resampler_spec_gap.json) where it is not.
+   north-star tolerance where the band is clean and REPORTED (profiles/r03_resampler_spec_gap.json) where it is not.
 """
 import importlib
 import json
@@ -150,7 +150,7 @@ def test_specification_gap_vs_r8brain_class(pilotcut):
                         # what the neighbour does to the audio in the first place (against the station alone)
                         "interference_rms_r8brain_class": float(np.sqrt(np.mean((a_r8b[post] - clean[:m][post]) ** 2))),
                         "interference_rms_product": float(np.sqrt(np.mean((a_prod[post] - clean[:m][post]) ** 2)))}
-    out = os.path.join(ROOT, "profiles", "r02_resampler_spec_gap.json")
+    out = os.path.join(ROOT, "profiles", "r03_resampler_spec_gap.json")
     rs_p, rs_r = ora.Resampler(fs, 384e3, 140.0).info(), ora.Resampler(fs, 384e3, 180.0, 0.98, True).info()
     report["designs"] = {"product (0.885 x Nyquist, 140 dB)": {k: rs_p[k] for k in ("D", "NA", "LB", "MB", "TB")},
                          "r8brain-class (0.98 x Nyquist, stop band from Nyquist, 180 dB)": {k: rs_r[k] for k in ("D", "NA", "LB", "MB", "TB")}}

@@ -99,10 +99,12 @@ def test_stream_loop_48k_modes(tmp_path, mode, fs, am_narrow, nbfm_default, nbfm
 
 
 @pytest.mark.gpu
-def test_stream_loop_fm_batched_facade(tmp_path, pilotcut, monkeypatch):
+@pytest.mark.parametrize("nblk", [160, 163])
+def test_stream_loop_fm_batched_facade(tmp_path, pilotcut, monkeypatch, nblk):
     """FmDecoder::set_batch_blocks(8): process() returns nothing for seven calls and the audio of eight blocks on the
-    eighth -- the same samples as call-by-call decoding (main.cpp:981-984 skips the empty returns)."""
-    fs, blk, nblk = 384e3, 2517, 160
+    eighth -- the same samples as call-by-call decoding (main.cpp:981-984 skips the empty returns).  163 blocks: the
+    last three are held back when the source ends and come out of flush() -- no block is lost."""
+    fs, blk = 384e3, 2517
     x = siggen.fm_stereo_iq(nblk * blk, fs)
     exe = _build(str(tmp_path))
     monkeypatch.setenv("FMR_LOOP_BATCH", "8")

@@ -163,8 +163,8 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
     CK(hipMemcpy(c.d_wgblk, wb.data(), grid * 4, hipMemcpyHostToDevice));
     a.wg_blk0 = c.d_wgblk;
   }
-  if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, ABL>), dim3(grid, 1), dim3(FUSED_THREADS), kLds, 0, a, c.taps);
-  else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, ABL>), dim3(grid, 1), dim3(FUSED_THREADS), kLds, 0, a, c.taps);
+  if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, ABL>), dim3(grid, 1), dim3(FUSED_THREADS), kLds, 0, a);
+  else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, ABL>), dim3(grid, 1), dim3(FUSED_THREADS), kLds, 0, a);
 }
 
 static void halo_updates(Ctx &c, const CallGeom &g, const float2 *d_iq) {

@@ -2,7 +2,8 @@
 small per-kernel JSON under profiles/.  gfx950 correction (MI355X_MICROARCH.md, HBM section):
 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read, i.e. HALF the bytes -> doubled;
 WRITE_SIZE is used as reported.  Units of both counters: KiB."""
-import csv, json, sys
+import csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def per_kernel(fn):
     agg = {}
@@ -18,7 +19,7 @@ def per_kernel(fn):
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
-       "blocks_per_step": blocks, "units": "bytes per launch (median over launches)",
+       "blocks_per_step": blocks, "csrc_sha256_16": __import__("bench").csrc_hash(), "units": "bytes per launch (median over launches)",
        "correction": "read bytes = 2 * FETCH_SIZE * 1024 (gfx950 wide-read under-count), write bytes = WRITE_SIZE * 1024",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
