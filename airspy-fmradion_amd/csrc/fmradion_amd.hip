@@ -156,6 +156,11 @@ struct fmr_chain {
   int ntaps = 0, n_pilotcut = 0, mpf_N = 0, mpf_ref = 0;
   // device buffers
   DevBuf<float2> d_in, d_in_halo, d_mid, d_if, d_fir, d_mpf, d_mpf_coeff, d_mpf_state;
+  // FM with the equaliser: the serial IF AGC runs beside the equaliser kernel, which follows its progress counter
+  // (absolute sample count per stream; agc_progress_base = IF samples of the calls before this one)
+  DevBuf<unsigned long long> d_agc_progress;
+  unsigned long long agc_progress_base = 0;
+  bool agc_beside_mpf = false;
   DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
   int poly2_tile = 0;                  // staged mid samples per tile, 0 = v2 kernel not applicable
   double nbfm_freq_dev = 8000.0;
@@ -236,7 +241,7 @@ struct fmr_chain {
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     for (auto &k : dom_times) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     d_in.release(); d_in_halo.release(); d_mid.release(); d_if.release(); d_fir.release();
-    d_mpf.release(); d_mpf_coeff.release(); d_mpf_state.release(); d_gain.release(); d_dec.release();
+    d_mpf.release(); d_mpf_coeff.release(); d_mpf_state.release(); d_gain.release(); d_dec.release(); d_agc_progress.release();
     d_hA.release(); d_hB.release(); d_coeff.release(); d_atan.release(); d_if_rms_blk.release();
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
@@ -706,6 +711,7 @@ int fmr_chain::init(const fmr_config *c) {
     if ((rc = upload(d_mpf_coeff, cf.data(), cf.size()))) return rc;
     if ((rc = d_mpf_state.alloc((size_t)S * mpf_N))) return rc;
     if (enable_mpf && (rc = d_mpf.alloc((size_t)S * max_if))) return rc;
+    if (enable_mpf && (rc = d_agc_progress.alloc((size_t)S))) return rc;
   } else if (mode == FMR_MODE_NBFM) {
     nbfm_freq_dev = (c->nbfm_freq_dev > 0) ? c->nbfm_freq_dev : 8000.0;  // NbfmDecode.h:39 freq_dev_normal
     agc_init = 1.0f; agc_max = 100000.0f; agc_rate = 0.0001f;           // NbfmDecode.cpp:43
@@ -1241,7 +1247,7 @@ int fmr_chain::run_if_stage(CallCtx &k) {
   x_off = fir_enable ? 0 : H_if;
   // ---- IF AGC: Newton multiple shooting over chunks of C_AGC samples (kernels_par.hpp)
   disc_gain = d_gain.p;      // gain sequence the discriminator multiplies in (nullptr = none)
-  agc_on_side = false; agc_deferred = false;
+  agc_on_side = false; agc_deferred = false; agc_beside_mpf = false;
   enqueue_agc = nullptr;      // argument: event that gates the side stream (null: a new marker on the main stream)
   const int agc_nc = (int)((N_if + C_AGC - 1) / C_AGC);
   if (!iter_on_side)
@@ -1251,10 +1257,21 @@ int fmr_chain::run_if_stage(CallCtx &k) {
                        pll_tick2_per_stream);
   // With the equaliser on, the AGC'd amplitude feeds the constant-modulus error, and
   // the equaliser kernel is the serial bottleneck anyway: use the exact serial AGC.
-  if (serial_mode || enable_mpf) {
+  if (enable_mpf && !serial_mode && mode == FMR_MODE_FM) {
+    // beside the equaliser, which consumes the gains as they are published (k_if_agc / k_mpf3, kernels.hpp)
+    HIPCHK(hipEventRecord(ev_if, stream));
+    HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
+    timed_on(side2, "if_agc", [&] {
+      hipLaunchKernelGGL(k_if_agc, dim3((S + 63) / 64), dim3(64), 0, side2, xin, x_stride, x_off, (int)N_if, d_gain.p,
+                         (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_agc_progress.p, agc_progress_base);
+    });
+    HIPCHK(hipEventRecord(ev_agc, side2));
+    ev_agc_live = true;
+    agc_beside_mpf = true;
+  } else if (serial_mode || enable_mpf) {
     timed("if_agc", [&] {
       hipLaunchKernelGGL(k_if_agc, dim3((S + 63) / 64), dim3(64), 0, stream, xin, x_stride, x_off, (int)N_if, d_gain.p,
-                         (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate);
+                         (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, (unsigned long long *)nullptr, 0ull);
     });
   } else {
     // FM without the equaliser: the AGC output only feeds atan2, which is invariant to the
@@ -1415,7 +1432,8 @@ int fmr_chain::run_fm(CallCtx &k) {
       auto go = [&](auto kern, int threads, size_t bytes) {
         hipLaunchKernelGGL(kern, dim3(S), dim3(threads), bytes, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
                            bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
-                           d_mpf_ok.p, d_state.p);
+                           d_mpf_ok.p, d_state.p, agc_beside_mpf ? d_agc_progress.p : (const unsigned long long *)nullptr,
+                           agc_progress_base);
       };
       // four waves per stream (kernels.hpp), taps per lane and row by equaliser length
       if (mpf_N <= 64 * 5) go(k_mpf3<4, 5>, 256, lds3);
@@ -1423,6 +1441,12 @@ int fmr_chain::run_fm(CallCtx &k) {
       else if (mpf_N <= 64 * 20) go(k_mpf3<4, 20>, 256, lds3);                                   // N <= 1280
       else set_err("equaliser length out of range");
     });
+  }
+  if (agc_beside_mpf) {
+    // the discriminator multiplies the gains into the blocks the equaliser passed over (warm-up, resets), and the AGC's
+    // state must be committed before the next call: the AGC kernel finished long ago (it is three times faster)
+    HIPCHK(hipStreamWaitEvent(stream, ev_agc, 0));
+    agc_progress_base += (unsigned long long)N_if;
   }
   const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
   const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
