@@ -21,6 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 MODE_NONE, MODE_FM, MODE_NBFM, MODE_AM, MODE_DSB, MODE_USB, MODE_LSB, MODE_CW, MODE_WSPR = -1, 0, 1, 2, 3, 4, 5, 6, 7
 IQ_CF32, IQ_S16, IQ_U8, IQ_S8 = 0, 1, 2, 3
+RESAMPLER_FAST, RESAMPLER_R8B = 0, 1
 _IQ_DTYPE = {0: np.complex64, 1: np.int16, 2: np.uint8, 3: np.int8}
 OK, ERR_NO_DEVICE, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP = 0, -1, -2, -3, -4, -5
 
@@ -28,8 +29,8 @@ EXPORTS = [
     "fmr_create", "fmr_destroy", "fmr_last_error", "fmr_version", "fmr_resampler_info", "fmr_process",
     "fmr_process_blocks", "fmr_process_blocks_device", "fmr_synchronize", "fmr_resample", "fmr_get_status",
     "fmr_get_pps_events", "fmr_get_multipath_coefficients", "fmr_debug_read", "fmr_get_kernel_times",
-    "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert", "fmr_design_taps", "fmr_host_alloc",
-    "fmr_host_free",
+    "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert", "fmr_design_taps", "fmr_design_taps_class",
+    "fmr_host_alloc", "fmr_host_free",
 ]
 
 
@@ -44,7 +45,7 @@ class Config(C.Structure):
         ("filter_coeff", C.POINTER(C.c_float)), ("n_filter_coeff", C.c_int), ("stereo", C.c_int),
         ("deemphasis_us", C.c_double), ("pilot_shift", C.c_int), ("multipath_stages", C.c_uint),
         ("max_block_len", C.c_size_t), ("max_blocks", C.c_int), ("nbfm_freq_dev", C.c_double),
-        ("input_format", C.c_int), ("output_rate", C.c_double),
+        ("input_format", C.c_int), ("output_rate", C.c_double), ("resampler_class", C.c_int),
     ]
 
 
@@ -126,6 +127,8 @@ def lib():
     L.fmr_fourth_convert.argtypes = [vp, fp, C.c_size_t, fp, C.c_int, C.POINTER(C.c_uint)]
     L.fmr_design_taps.restype = C.c_longlong
     L.fmr_design_taps.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, dp, C.c_longlong, C.POINTER(C.c_longlong)]
+    L.fmr_design_taps_class.restype = C.c_longlong
+    L.fmr_design_taps_class.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, dp, C.c_longlong, C.POINTER(C.c_longlong)]
     L.fmr_filter_table.restype = C.c_int
     L.fmr_filter_table.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int)]
     _lib = L
@@ -155,6 +158,19 @@ def design_taps(in_rate, out_rate, atten_db, stage):
     return (buf.reshape(rows, d["TB"]) if stage else buf), d
 
 
+def design_taps_class(in_rate, out_rate, resampler_class, stage):
+    """IfResampler(in_rate, out_rate) of a resampler class (RESAMPLER_FAST / RESAMPLER_R8B): (taps, info dict)."""
+    info = (C.c_longlong * 6)()
+    n = lib().fmr_design_taps_class(in_rate, out_rate, resampler_class, stage, None, 0, info)
+    if n < 0:
+        raise FmrError(f"fmr_design_taps_class failed ({n}): {lib().fmr_last_error().decode()}")
+    buf = np.empty(n, dtype=np.float64)
+    lib().fmr_design_taps_class(in_rate, out_rate, resampler_class, stage, buf.ctypes.data_as(C.POINTER(C.c_double)), n, info)
+    d = dict(zip(["D", "NA", "LB", "MB", "TB", "LT"], [int(v) for v in info]))
+    rows = d["LT"] + 1 if d["LT"] else d["LB"]
+    return (buf.reshape(rows, d["TB"]) if stage else buf), d
+
+
 DELAY_3TAPS = np.array([0.0, 1.0, 0.0], dtype=np.float32)  # FilterParameters::delay_3taps_only_iq
 
 
@@ -164,7 +180,7 @@ class Chain:
     def __init__(self, mode=MODE_FM, input_rate=384000.0, enable_resampler=False, fourth_down=False,
                  fmfilter_enable=False, filter_coeff=None, stereo=True, deemphasis_us=50.0, pilot_shift=False,
                  multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0, nbfm_freq_dev=0.0, input_format=0,
-                 output_rate=0.0):
+                 output_rate=0.0, resampler_class=RESAMPLER_FAST):
         coeff = np.ascontiguousarray(DELAY_3TAPS if filter_coeff is None else filter_coeff, dtype=np.float32)
         self._coeff = coeff
         cfg = Config()
@@ -179,6 +195,7 @@ class Chain:
         cfg.nbfm_freq_dev = float(nbfm_freq_dev)
         cfg.input_format = int(input_format)
         cfg.output_rate = float(output_rate)
+        cfg.resampler_class = int(resampler_class)
         self.input_format = int(input_format)
         self.n_streams, self.mode, self.stereo = n_streams, mode, bool(stereo) and mode == MODE_FM
         self.h = C.c_void_p()

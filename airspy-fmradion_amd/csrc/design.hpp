@@ -163,13 +163,16 @@ struct ResamplerDesign {
   std::vector<double> hA;  // [NA]
   std::vector<double> hB;  // [LB][TB], or [LT + 1][TB]
 
-  bool design(double in_r, double out_r, double atten_db) {
+  // pass_frac: pass band edge as a fraction of out / 2; stop_nyquist: the stop band starts at out / 2 (nothing aliases at
+  // all) instead of at out - f_pass.  (0.885, false) is the FAST class of DESIGN.md; (0.98, true) at 180 dB the
+  // R8B class -- the defaults of r8b::CDSPResampler24 (sfmbase/IfResampler.cpp:25-29).
+  bool design(double in_r, double out_r, double atten_db, double pass_frac = 0.885, bool stop_nyquist = false) {
     in_rate = in_r; out_rate = out_r; atten = atten_db;
     const double A = atten_db;
     const double beta = 0.1102 * (A - 8.7);
     const double i0b = bessel_i0(beta);
-    const double fpass = 0.885 * out_rate * 0.5;
-    const double fstop = out_rate - fpass;
+    const double fpass = pass_frac * out_rate * 0.5;
+    const double fstop = stop_nyquist ? out_rate * 0.5 : out_rate - fpass;
     long long in_i = llround(in_rate), out_i = llround(out_rate);
     if (!(in_rate > 0.5) || !(out_rate > 0.5) || in_rate > 4e9 || out_rate > 4e9) return false;
     if (std::fabs(in_rate - in_i) > 1e-6 || std::fabs(out_rate - out_i) > 1e-6) {
@@ -200,7 +203,7 @@ struct ResamplerDesign {
         sum += hA[k];
       }
       for (int k = 0; k < N; k++) hA[k] /= sum;
-      if (A <= 150.0 && D <= 78) {
+      if (A <= 150.0 && !stop_nyquist && D <= 78) {
         // The IF class (float32 data, 140 dB): an equiripple stage A of 0.68 x the Kaiser length.  Pass band weight 1,
         // stop bands k mid -+ fstop (k = 1 .. D / 2, cut at in / 2) weight 800, the bands between them free: what falls
         // there is removed by stage B.  D = 2 .. 20: ripple <= 0.0010 dB peak to peak, aliases of the pass band

@@ -54,7 +54,8 @@ void set_err(const char *fmt, ...) {
 constexpr double kFmRate = 384000.0;   // FmDecoder::sample_rate_if   (FmDecode.h:38)
 constexpr double kPcmRate = 48000.0;   // FmDecoder::sample_rate_pcm  (FmDecode.h:40)
 constexpr double kAmRate = 48000.0;    // AmDecoder::internal_rate_pcm (AmDecode.h:36)
-constexpr double kIfAtten = 140.0;     // resampler spec, DESIGN.md
+constexpr double kIfAtten = 140.0;     // resampler spec, DESIGN.md (FAST class)
+constexpr double kR8bAtten = 180.0, kR8bPassFrac = 0.98;   // R8B class: the defaults of r8b::CDSPResampler24 (IfResampler.cpp:25-29)
 constexpr double kAudioAtten = 180.0;
 constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
@@ -172,6 +173,9 @@ struct fmr_chain {
   int in_fmt = 0, in_bps = 8;          // source sample format (fmr_config.input_format) and its bytes per IQ sample
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
+  bool poly5 = false;                  // stage-B v5 (f32 MFMA, 48/125 with any TB: the R8B class); its k-steps: poly5_nks
+  int poly5_nks = 0;
+  DevBuf<float> d_afrag5;
   DevBuf<float> d_afrag;               // v4: constant A fragments
   // fused front end (kernels_fused.hpp): stage A + stage B + discriminator in one persistent kernel
   bool fused_ok = false;               // the chain's shape fits (10 MS/s class, cf32, no Fs/4, no IF FIR, no equaliser)
@@ -246,7 +250,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_taps.release(); d_fused_part.release(); d_afrag.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_taps.release(); d_fused_part.release(); d_afrag.release(); d_afrag5.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -419,7 +423,12 @@ int fmr_chain::init(const fmr_config *c) {
     return FMR_ERR_UNSUPPORTED;
   }
   if (has_rs) {
-    if (!rs.design(c->input_rate, dec_rate, kIfAtten)) {
+    if (c->resampler_class != FMR_RESAMPLER_FAST && c->resampler_class != FMR_RESAMPLER_R8B) {
+      set_err("unknown resampler_class %d", c->resampler_class);
+      return FMR_ERR_BAD_ARG;
+    }
+    const bool r8b = c->resampler_class == FMR_RESAMPLER_R8B;
+    if (!(r8b ? rs.design(c->input_rate, dec_rate, kR8bAtten, kR8bPassFrac, true) : rs.design(c->input_rate, dec_rate, kIfAtten))) {
       set_err("resampling ratio %.9g -> %.9g is outside the supported design range", c->input_rate, dec_rate);
       return FMR_ERR_UNSUPPORTED;
     }
@@ -447,8 +456,8 @@ int fmr_chain::init(const fmr_config *c) {
     if (rs.D >= 2) {
       int q = (rs.NA + rs.D - 1) / rs.D;
       if (q & 1) q++;
-      if (q <= 16) {
-        qa = 16;
+      if (q <= 24) {
+        qa = (q <= 16) ? 16 : 24;          // 24: stage A of the R8B class (195 taps at D = 10), cf32 input only
         std::vector<float> hp((size_t)rs.D * qa, 0.f);
         for (int k = 0; k < rs.NA; k++) hp[(size_t)(k % rs.D) * qa + k / rs.D] = fa[k];
         if ((rc = upload(d_hpA, hp.data(), hp.size()))) return rc;
@@ -461,7 +470,7 @@ int fmr_chain::init(const fmr_config *c) {
       while ((s_pad & 15) != 2) s_pad++;
       const size_t lds2 = sizeof(float2) * ((size_t)rs.D * s_pad + 2);
       if (!(qa == 16 && lds2 <= 64000 && (size_t)rs.D * (T2 + 16) <= (size_t)2 * 16 * BL2)) {
-        set_err("input_format != cf32 needs a source rate with integer pre-decimation >= 2 (%.0f -> %.0f Hz gives D = %d): "
+        set_err("input_format != cf32 needs the FAST resampler class and a source rate with integer pre-decimation >= 2 (%.0f -> %.0f Hz gives D = %d): "
                 "convert on the host or use cf32 input", c->input_rate, dec_rate, rs.D);
         return FMR_ERR_UNSUPPORTED;
       }
@@ -492,6 +501,25 @@ int fmr_chain::init(const fmr_config *c) {
           poly3 = true;
           HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly3<384, Q3>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        }
+        if (rs.LB == 48 && rs.MB == 125 && rs.TB != 210 && (rs.TB & 1) == 0) {
+          // any other stage-B length at 48 / 125 (R8B class: TB = 3122): dense MFMA product, A fragments streamed through LDS
+          constexpr int KC = FMR_POLY5_KC;
+          const int nks = (((off[47] + rs.TB + 3) / 4 + KC - 1) / KC) * KC;
+          const size_t lds5 = sizeof(float2) * (size_t)((((int)tl + 64 + 127) / 128) * 128 + 4 * 8 * 48) + sizeof(float) * 2 * KC * 3 * 64;
+          if (lds5 <= 160 * 1024) {
+            std::vector<float> af((size_t)nks * 3 * 64, 0.f);
+            for (int ks = 0; ks < nks; ks++)
+              for (int mt = 0; mt < 3; mt++)
+                for (int l = 0; l < 64; l++) {
+                  const int pp = 16 * mt + (l & 15), m = 4 * ks + (l >> 4), j = m - off[pp];
+                  if (j >= 0 && j < rs.TB) af[((size_t)ks * 3 + mt) * 64 + l] = fb[(size_t)phi[pp] * rs.TB + j];
+                }
+            if ((rc = upload(d_afrag5, af.data(), af.size()))) return rc;
+            poly2_tile = (int)tl + 64;
+            poly5 = true; poly5_nks = nks;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly5<48, 125>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+          }
         }
         if (poly3 && rs.LB == 48 && rs.MB == 125 && rs.TB == 210) {
           using SH = Poly4Shape<48, 125, 210>;
@@ -938,10 +966,10 @@ int fmr_chain::run_front_end(CallCtx &k) {
       bool v2_done = false;
       auto launch_decim2 = [&](auto bl_tag) {
         constexpr int BL2 = decltype(bl_tag)::value, T2 = 2 * BL2;
-        int s_pad = T2 + 16;
+        int s_pad = T2 + qa;
         while ((s_pad & 15) != 2) s_pad++;
         const size_t lds2 = sizeof(float2) * ((size_t)rs.D * s_pad + 2);   // + the spare slot
-        if (!(qa == 16 && lds2 <= 64000 && (size_t)rs.D * (T2 + 16) <= (size_t)2 * 16 * BL2)) return;
+        if (!((qa == 16 || (qa == 24 && in_fmt == 0)) && lds2 <= 64000 && (size_t)rs.D * (T2 + qa) <= (size_t)2 * 16 * BL2)) return;
         const unsigned magic = (unsigned)((1u << 24) / (unsigned)rs.D + 1);
         const dim3 grid2((count_mid + T2 - 1) / T2, S);
         timed_on(fes, "ifr_decim", [&] {
@@ -952,6 +980,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
                                (int)cfg.enable_fourth_down, s_pad, magic);
           };
           const bool f4 = cfg.enable_fourth_down != 0;
+          if (qa == 24) { f4 ? go(k_ifr_decim2<BL2, 24, 0, true>) : go(k_ifr_decim2<BL2, 24, 0, false>); return; }
           switch (in_fmt) {
           case 1: f4 ? go(k_ifr_decim2<BL2, 16, 0, true, 1, 1>) : go(k_ifr_decim2<BL2, 16, 0, false, 1, 1>); break;
           case 2: f4 ? go(k_ifr_decim2<BL2, 16, 0, true, 1, 2>) : go(k_ifr_decim2<BL2, 16, 0, false, 1, 2>); break;
@@ -979,7 +1008,12 @@ int fmr_chain::run_front_end(CallCtx &k) {
       const long long P_first = kB_prev / rs.LB, P_last = (kB_prev + N_if - 1) / rs.LB;
       const int tiles = (int)((P_last - P_first) / 64 + 1);
       timed_on(fes, "ifr_poly", [&] {
-        if (poly4)
+        if (poly5)
+          hipLaunchKernelGGL((k_ifr_poly5<48, 125>), dim3(std::min(tiles, n_cu), S), dim3(256),
+                             sizeof(float2) * (size_t)(((poly2_tile + 127) / 128) * 128 + 4 * 8 * 48) + sizeof(float) * 2 * FMR_POLY5_KC * 3 * 64,
+                             fes, d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag5.p,
+                             poly5_nks, rs.TB, kB_prev, (int)N_if, ifbuf, (long long)(H_if + max_if), H_if, poly2_tile, tiles);
+        else if (poly4)
           hipLaunchKernelGGL((k_ifr_poly4<48, 125, 210>), dim3(std::min(tiles, 512), S), dim3(256),
                              sizeof(float2) * (size_t)(((poly2_tile + 127) / 128) * 128 + 4 * 8 * 48), fes, d_mid.p,
                              (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag.p, kB_prev,
@@ -1721,10 +1755,25 @@ long long fmr_resampler_info(const fmr_chain *c, int which) {
   return -1;
 }
 
+static long long design_taps_out(const ResamplerDesign &d, int stage, double *taps, long long cap, long long *info);
+long long fmr_design_taps_class(double in_rate, double out_rate, int resampler_class, int stage, double *taps,
+                                long long cap, long long *info) {
+  ResamplerDesign d;
+  const bool r8b = resampler_class == FMR_RESAMPLER_R8B;
+  if (resampler_class != FMR_RESAMPLER_FAST && !r8b) { set_err("unknown resampler_class %d", resampler_class); return FMR_ERR_BAD_ARG; }
+  if (!(r8b ? d.design(in_rate, out_rate, kR8bAtten, kR8bPassFrac, true) : d.design(in_rate, out_rate, kIfAtten))) {
+    set_err("resampling ratio outside the design range");
+    return FMR_ERR_UNSUPPORTED;
+  }
+  return design_taps_out(d, stage, taps, cap, info);
+}
 long long fmr_design_taps(double in_rate, double out_rate, double atten_db, int stage, double *taps, long long cap,
                           long long *info) {
   ResamplerDesign d;
   if (!d.design(in_rate, out_rate, atten_db)) { set_err("resampling ratio outside the design range"); return FMR_ERR_UNSUPPORTED; }
+  return design_taps_out(d, stage, taps, cap, info);
+}
+static long long design_taps_out(const ResamplerDesign &d, int stage, double *taps, long long cap, long long *info) {
   if (info) { info[0] = d.D; info[1] = d.NA; info[2] = d.LB; info[3] = d.MB; info[4] = d.TB; info[5] = d.LT; }
   const std::vector<double> &h = stage ? d.hB : d.hA;
   if (!taps) return (long long)h.size();

@@ -135,11 +135,13 @@ private:
 class IfResampler {
 public:
   static constexpr int max_input_length = 65536;   // IfResampler.h:31
-  IfResampler(const double input_rate, const double output_rate, int device = 0) {
+  // resampler_class: FMR_RESAMPLER_FAST (default: the throughput specification) or FMR_RESAMPLER_R8B -- the defaults of
+  // the r8b::CDSPResampler24 this class wraps in the reference (IfResampler.cpp:25-29): the reference-equivalent filter
+  IfResampler(const double input_rate, const double output_rate, int device = 0, int resampler_class = FMR_RESAMPLER_FAST) {
     if (input_rate == output_rate) return;
     fmr_config cfg{};
     cfg.device = device; cfg.n_streams = 1; cfg.mode = -1; cfg.input_rate = input_rate; cfg.output_rate = output_rate;
-    cfg.enable_resampler = 1; cfg.max_block_len = max_input_length; cfg.max_blocks = 1;
+    cfg.enable_resampler = 1; cfg.max_block_len = max_input_length; cfg.max_blocks = 1; cfg.resampler_class = resampler_class;
     m_chain = fmr_detail::make(cfg);
   }
   ~IfResampler() { if (m_chain) fmr_destroy(m_chain); }
@@ -194,9 +196,10 @@ public:
 
   // Fuse FourthConverterIQ + IfResampler into this decoder's chain: process() then takes
   // the source-rate IQ block (what main.cpp:889 pulls) and the IF never leaves the GPU.
-  void attach_front_end(double input_rate, bool fourth_down) {
+  void attach_front_end(double input_rate, bool fourth_down, int resampler_class = FMR_RESAMPLER_FAST) {
     fmr_destroy(m_chain);
     m_cfg.input_rate = input_rate; m_cfg.enable_resampler = 1; m_cfg.enable_fourth_down = fourth_down;
+    m_cfg.resampler_class = resampler_class;
     m_chain = fmr_detail::make(m_cfg);
   }
 
@@ -340,9 +343,10 @@ public:
   ~AmDecoder() { fmr_destroy(m_chain); }
   AmDecoder(const AmDecoder &) = delete;
   AmDecoder &operator=(const AmDecoder &) = delete;
-  void attach_front_end(double input_rate, bool fourth_down) {
+  void attach_front_end(double input_rate, bool fourth_down, int resampler_class = FMR_RESAMPLER_FAST) {
     fmr_destroy(m_chain);
     m_cfg.input_rate = input_rate; m_cfg.enable_resampler = 1; m_cfg.enable_fourth_down = fourth_down;
+    m_cfg.resampler_class = resampler_class;
     m_chain = fmr_detail::make(m_cfg);
   }
   void process(IQSampleVector samples_in, SampleVector &audio) {
@@ -385,9 +389,10 @@ public:
   ~NbfmDecoder() { fmr_destroy(m_chain); }
   NbfmDecoder(const NbfmDecoder &) = delete;
   NbfmDecoder &operator=(const NbfmDecoder &) = delete;
-  void attach_front_end(double input_rate, bool fourth_down) {
+  void attach_front_end(double input_rate, bool fourth_down, int resampler_class = FMR_RESAMPLER_FAST) {
     fmr_destroy(m_chain);
     m_cfg.input_rate = input_rate; m_cfg.enable_resampler = 1; m_cfg.enable_fourth_down = fourth_down;
+    m_cfg.resampler_class = resampler_class;
     m_chain = fmr_detail::make(m_cfg);
   }
   void process(const IQSampleVector &samples_in, SampleVector &audio) {

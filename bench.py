@@ -82,6 +82,9 @@ def synth_am_torch(n, fs, stream_id, device):
 
 
 # ----------------------------------------------------------------------------- CPU oracle legs
+R8B = False       # set by main(): the oracle's IfResampler then takes the r8brain-class specification too
+
+
 def _oracle_chain(mode, stages=0):
     import oracle_py as ora
     if mode == "am":
@@ -89,7 +92,7 @@ def _oracle_chain(mode, stages=0):
         ifr, dec = ora.IfResampler(AM_FS, 48e3), ora.AmDecoder(narrow, ora.MODE_AM)
     else:
         pilotcut = np.load(os.path.join(ROOT, "tests", "golden", "filters", "jj1bdx_48khz_fmaudio.npy"))
-        ifr = ora.IfResampler(FS, 384e3)
+        ifr = ora.IfResampler(FS, 384e3, 180.0, 0.98, True) if R8B else ora.IfResampler(FS, 384e3)
         dec = ora.FmDecoder(False, np.array([0, 1, 0], dtype=np.float32), True, 50.0, False, stages, pilotcut)
     return ifr, dec
 
@@ -270,11 +273,17 @@ def main():
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="test hook: gloo backend, the per-rank step is the CPU oracle on a tiny sample -- exercises the "
                          "launch / barrier / aggregation contract without a GPU (tests/test_multi_process.py)")
+    ap.add_argument("--resampler-class", choices=["fast", "r8b"], default="fast",
+                    help="r8b: the IF resampler to the defaults of the reference's r8b::CDSPResampler24 (0.98 x Nyquist, stop "
+                         "band from Nyquist, 180 dB; IfResampler.cpp:25-29) -- the reference-equivalent class, its own line, "
+                         "never the headline")
     ap.add_argument("--all-configs", action="store_true",
                     help="after the headline line, print one line each for configs[2] (AM), configs[3] (-E 64), configs[4] "
                          "(32 streams per GPU) and the mono-station case, each with its own audio check and CPU baseline")
     args = ap.parse_args()
 
+    global R8B
+    R8B = args.resampler_class == "r8b"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)              # `python bench.py --gpus N` without a launcher: spawn the N ranks here
 
@@ -321,7 +330,8 @@ def main():
     else:
         ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, enable_resampler=True, stereo=True, n_streams=S,
                        max_block_len=blk, max_blocks=B, device=local_rank, input_format=fmt,
-                       multipath_stages=args.multipath_stages)
+                       multipath_stages=args.multipath_stages,
+                       resampler_class=fmr.RESAMPLER_R8B if args.resampler_class == "r8b" else fmr.RESAMPLER_FAST)
     block_len = [blk] * B
     torch.cuda.synchronize()
 
@@ -427,13 +437,26 @@ def main():
             workload = "FM stereo decoder on a mono station (no pilot): unlocked steady state, serial PLL"
         elif args.multipath_stages:
             workload = f"configs[3]: as configs[1] with the MultipathFilter equaliser -E {args.multipath_stages}"
+        elif R8B:
+            workload = ("as configs[1] with the IF resampler in the R8B class (r8b::CDSPResampler24 defaults: 0.98 x Nyquist, "
+                        "stop band from Nyquist, 180 dB) -- the reference-equivalent filter, stage B 3122 taps per phase on f32 MFMA")
         elif S > 1:
             workload = (f"configs[4] shard: {S} independent FM stereo streams per GPU, 10 MS/s complex-float IQ in HBM, "
                         "PilotPhaseLock on, IfResampler+FmDecoder -> f64 stereo 48 kHz")
         else:
             workload = ("configs[1]: single FM stereo stream per GPU, 10 MS/s complex-float IQ in HBM, "
                         "PilotPhaseLock on, IfResampler+FmDecoder -> f64 stereo 48 kHz")
-        pmc_traffic = committed_pmc_traffic(dom_name, B, S, args)
+        pmc_traffic = committed_pmc_traffic(dom_name, B, S, args) if not R8B else (None, None)
+        mfma_roofline = None
+        if R8B and stage_src.get("ifr_poly", 0) > 0:
+            info = ch.resampler_info()
+            n_if = float(S) * n * info["LB"] / (info["MB"] * info["D"])                 # IF samples per launch
+            flops = 2.0 * 2.0 * info["TB"] * n_if                                        # taps x (re, im) x multiply-add
+            tf = flops / (stage_src["ifr_poly"] * 1e-3) / 1e12
+            mfma_roofline = {"bound": "mfma", "kernel": "ifr_poly (k_ifr_poly5: stage B, %d taps per phase, f32 MFMA)" % info["TB"],
+                             "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None,
+                             "avg_launch_ms": round(stage_src["ifr_poly"], 5), "algorithmic_flops_per_launch": flops,
+                             "peak_source": "MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate, 157.3 TFLOP/s"}
         out = {
             "metric": ("IQ MS/s (AM, 384 kS/s in), whole job" if am else "IQ MS/s (FM stereo, 10 MS/s in), whole job"),
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -453,6 +476,7 @@ def main():
                                    "ms": round(stage_ms, 5), "achieved": round(stage_achieved, 2),
                                    "frac": round(stage_achieved / HBM_PEAK_GBS, 4),
                                    "kernels_ms": {k: round(stage_src[k], 5) for k in STAGE_KERNELS if k in stage_src}}},
+            **({"roofline_mfma": mfma_roofline} if mfma_roofline else {}),
             "kernel_ms_per_step": {k: round(v, 5) for k, v in kavg.items()},
             "kernel_ms_note": "from one extra instrumented step; kernels on the chain's three HIP streams overlap, so the entries sum to more than ms_per_step",
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),

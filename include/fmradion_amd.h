@@ -45,6 +45,13 @@ enum {
 enum { FMR_MODE_FM = 0, FMR_MODE_NBFM = 1, FMR_MODE_AM = 2, FMR_MODE_DSB = 3, FMR_MODE_USB = 4, FMR_MODE_LSB = 5,
        FMR_MODE_CW = 6, FMR_MODE_WSPR = 7 };
 enum { FMR_IQ_CF32 = 0, FMR_IQ_S16 = 1, FMR_IQ_U8 = 2, FMR_IQ_S8 = 3 };
+/* Specification of the IfResampler stand-in ("Resampler specification"; r8brain itself is absent from the
+ * reference tree).  FAST: pass band 0.885 x Nyquist, aliases of the pass band rejected by 140 dB, what falls between
+ * 0.885 x Nyquist and Nyquist rolls off -- the throughput configuration.  R8B: the defaults of the
+ * r8b::CDSPResampler24 the reference constructs (sfmbase/IfResampler.cpp:25-29): pass band 0.98 x Nyquist, stop band
+ * from Nyquist on, 180 dB -- the reference-equivalent configuration (a neighbouring station 200 kHz away is filtered
+ * exactly as the reference filters it), 15 x the stage-B arithmetic. */
+enum { FMR_RESAMPLER_FAST = 0, FMR_RESAMPLER_R8B = 1 };
 
 /* PilotPhaseLock::PpsEvent (include/PilotPhaseLock.h:40-44) + the index of the
  * block (within the call) that produced it. */
@@ -90,6 +97,7 @@ typedef struct {
   /* Front-end-only chains (mode = -1): IfResampler(input_rate, output_rate) of include/IfResampler.h:35; 0 = the FM
    * IF rate (384 kHz).  Decoder chains ignore it (their rate is fixed: FmDecode.h:38, AmDecode.h:36). */
   double output_rate;
+  int resampler_class;        /* FMR_RESAMPLER_FAST (default) | FMR_RESAMPLER_R8B: specification of the IF resampler */
 } fmr_config;
 
 /* Per-stream status after the most recent call (getters of FmDecode.h:77-105 /
@@ -136,6 +144,10 @@ long long fmr_resampler_info(const fmr_chain *c, int which);
  * ratio).  Lets tests check the design against an independent construction without a device. */
 long long fmr_design_taps(double in_rate, double out_rate, double atten_db, int stage, double *taps, long long cap,
                           long long *info);
+/* The same for a resampler class (FMR_RESAMPLER_FAST / _R8B) of the IF resampler: IfResampler(in_rate, out_rate) as
+ * fmr_create builds it (sfmbase/IfResampler.cpp:25-29). */
+long long fmr_design_taps_class(double in_rate, double out_rate, int resampler_class, int stage, double *taps,
+                                long long cap, long long *info);
 
 /* --- live sources: page-locked host memory for the ring between a driver's callback thread and the decoder thread.
  * Replaces the heap vectors that AirspySource::callback (sfmbase/AirspySource.cpp:488-500) and RtlSdrSource::get_samples

@@ -238,3 +238,28 @@ def test_fractional_phase_resampling_of_an_analytic_signal(in_rate, out_rate):
     ref = g0 * np.cos(2 * np.pi * f0 * tt) + 0.3 * g1 * np.cos(2 * np.pi * 0.31 * f0 * tt + 1.0)
     err = (y - ref)[3000:]
     assert np.sqrt(np.mean(err ** 2)) < 3e-7
+
+
+def test_r8b_class_design_is_the_r8brain_class_of_the_oracle():
+    """fmr_config.resampler_class = FMR_RESAMPLER_R8B: the specification of r8b::CDSPResampler24 as the reference
+    constructs it (IfResampler.cpp:25-29: 2 % transition band ending at Nyquist, 180 dB).  Product design == the oracle's
+    r8brain-class design (ora.Resampler(..., 180, 0.98, stop_nyquist)), and an independent scipy construction of stage A."""
+    ha, d = fmr.design_taps_class(10e6, 384e3, fmr.RESAMPLER_R8B, 0)
+    hb, _ = fmr.design_taps_class(10e6, 384e3, fmr.RESAMPLER_R8B, 1)
+    rs = ora.Resampler(10e6, 384e3, 180.0, 0.98, True)
+    info = rs.info()
+    assert d == {k: info[k] for k in ("D", "NA", "LB", "MB", "TB", "LT")}
+    assert (d["D"], d["NA"], d["LB"], d["MB"], d["TB"]) == (10, 195, 48, 125, 3122)
+    assert np.array_equal(ha, rs.taps_a()) and np.array_equal(hb, rs.taps_b())
+    fpass, fstop, mid = 0.98 * 192e3, 192e3, 1e6
+    n, beta = signal.kaiserord(180.0, ((mid - fstop) - fpass) / (0.5 * 10e6))
+    n += n % 2 == 0
+    h = signal.firwin(n, 0.5 * (fpass + mid - fstop), window=("kaiser", beta), fs=10e6, scale=False)
+    h /= h.sum()
+    assert len(h) == len(ha) and np.max(np.abs(ha - h)) < 1e-12 * np.max(np.abs(h))
+    # the FAST class through the same entry point is the default design
+    hf, df = fmr.design_taps_class(10e6, 384e3, fmr.RESAMPLER_FAST, 0)
+    h0, d0 = fmr.design_taps(10e6, 384e3, 140.0, 0)
+    assert df == d0 and np.array_equal(hf, h0)
+    with pytest.raises(fmr.FmrError):
+        fmr.design_taps_class(10e6, 384e3, 7, 0)

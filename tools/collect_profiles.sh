@@ -25,6 +25,7 @@ python bench.py --multipath-stages 64 --streams 32 --blocks 64 --steps 3 --warmu
 python bench.py --mode am --steps 20 --warmup 3 > gpurun_out/${tag}_bench_config3_am.json 2>/dev/null
 python bench.py --mode am --streams 32 --blocks 1024 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_config3_am_32streams.json 2>/dev/null
 python bench.py --no-pilot --steps 3 --warmup 1 --blocks 256 --no-cpu-baseline > gpurun_out/${tag}_bench_no_pilot.json 2>/dev/null
+timeout 120 tools/bench_fused.bin > gpurun_out/${tag}_fused_harness.log 2>&1
 tail -3 gpurun_out/${tag}_pytest_gpu.log
 cat gpurun_out/${tag}_smoke.log | tail -2
 cut -c1-400 gpurun_out/${tag}_bench.json
