@@ -221,12 +221,26 @@ def self_launch(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    # wait for all of them; if one rank dies the others would sit in a collective until its time-out: stop them (our own
+    # children, by handle) and report
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        failed = next((r for r, p in enumerate(procs) if p.poll() not in (None, 0)), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write("".join(out0))
     sys.stdout.flush()
     if any(rcs):
-        raise SystemExit(f"rank return codes {rcs}")
+        raise SystemExit(f"rank return codes {rcs}" + (f" (rank {failed} failed first; the others were stopped)" if failed is not None else ""))
 
 
 def pin_rank_to_cores():

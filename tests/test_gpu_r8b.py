@@ -67,3 +67,45 @@ def test_r8b_fm_stereo_end_to_end(scene, pilotcut):
     assert fm.stereo_detected() and ch.status(0).stereo_detected == 1
     assert rms(got - ref) < 1e-5
     ch.close()
+
+
+def test_r8b_other_rate_fourth_shift_ragged_blocks_two_streams(pilotcut):
+    """6 MS/s (Airspy Mini) zero-IF input: Fs/4 shift + R8B class (D = 6, stage A 117 taps = 20 per phase, stage B again
+    48/125 x 3122), two streams, ragged blocks in calls of several blocks -- against FourthConverterIQ + the r8brain-class
+    resampler + FmDecoder of the oracle, block by block."""
+    fs, S = 6e6, 2
+    rng = np.random.default_rng(3)
+    lens = [int(rng.integers(1, 49153)) if rng.random() < 0.4 else 49152 for _ in range(60)]
+    n = sum(lens)
+    xs = []
+    for s in range(S):
+        x = siggen.fm_stereo_iq(n, fs, stream_id=s)
+        xs.append((x * (1j ** (np.arange(n) % 4))).astype(np.complex64))      # the station sits at +fs/4 (main.cpp:912-919)
+    xs = np.stack(xs)
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, enable_resampler=True, fourth_down=True, stereo=True, n_streams=S,
+                   max_block_len=49152, max_blocks=7, resampler_class=fmr.RESAMPLER_R8B)
+    info = ch.resampler_info()
+    assert (info["D"], info["LB"], info["MB"], info["TB"]) == (6, 48, 125, 3122)
+    got = [[] for _ in range(S)]
+    pos = 0
+    for i in range(0, len(lens), 7):
+        ll = lens[i:i + 7]
+        m = sum(ll)
+        a, _ = ch.process_blocks(xs[:, pos:pos + m], ll)
+        pos += m
+        for s in range(S):
+            got[s].append(a[s])
+    for s in range(S):
+        f4, r = ora.FourthConverterIQ(False), ora.IfResampler(fs, 384e3, 180.0, 0.98, True)
+        fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
+        ref, p = [], 0
+        for L in lens:
+            if_s = r.process(f4.process(xs[s, p:p + L]))
+            p += L
+            if len(if_s):
+                ref.append(fm.process(if_s))
+        ref = np.concatenate(ref)
+        g = np.concatenate(got[s])
+        assert len(g) == len(ref) > 20000
+        assert rms(g - ref) < 1e-5
+    ch.close()
