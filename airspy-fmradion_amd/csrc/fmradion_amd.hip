@@ -506,7 +506,7 @@ int fmr_chain::init(const fmr_config *c) {
           // any other stage-B length at 48 / 125 (R8B class: TB = 3122): dense MFMA product, A fragments streamed through LDS
           constexpr int KC = FMR_POLY5_KC;
           const int nks = (((off[47] + rs.TB + 3) / 4 + KC - 1) / KC) * KC;
-          const size_t lds5 = sizeof(float2) * (size_t)((((int)tl + 64 + 127) / 128) * 128 + 4 * 8 * 48) + sizeof(float) * 2 * KC * 3 * 64;
+          const size_t lds5 = sizeof(float2) * (size_t)((((int)tl + 64 + 127) / 128) * 128 + FMR_POLY5_WAVES * 8 * 48) + sizeof(float) * 2 * KC * 3 * 64;
           if (lds5 <= 160 * 1024) {
             std::vector<float> af((size_t)nks * 3 * 64, 0.f);
             for (int ks = 0; ks < nks; ks++)
@@ -1009,8 +1009,8 @@ int fmr_chain::run_front_end(CallCtx &k) {
       const int tiles = (int)((P_last - P_first) / 64 + 1);
       timed_on(fes, "ifr_poly", [&] {
         if (poly5)
-          hipLaunchKernelGGL((k_ifr_poly5<48, 125>), dim3(std::min(tiles, n_cu), S), dim3(256),
-                             sizeof(float2) * (size_t)(((poly2_tile + 127) / 128) * 128 + 4 * 8 * 48) + sizeof(float) * 2 * FMR_POLY5_KC * 3 * 64,
+          hipLaunchKernelGGL((k_ifr_poly5<48, 125>), dim3(std::min(tiles, n_cu), S), dim3(64 * FMR_POLY5_WAVES),
+                             sizeof(float2) * (size_t)(((poly2_tile + 127) / 128) * 128 + FMR_POLY5_WAVES * 8 * 48) + sizeof(float) * 2 * FMR_POLY5_KC * 3 * 64,
                              fes, d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag5.p,
                              poly5_nks, rs.TB, kB_prev, (int)N_if, ifbuf, (long long)(H_if + max_if), H_if, poly2_tile, tiles);
         else if (poly4)

@@ -786,23 +786,29 @@ __global__ __launch_bounds__(256, 2) void k_ifr_poly4(
 //   tile = 64 periods = 3072 IF samples; window = 64 x 125 + 41 + TB mid samples (89 KB at TB = 3122)
 //   wave w: column tiles w and w + 4 (8 periods x (re, im) each) x three row tiles = six accumulators, six MFMAs per
 //           k-step on one B read per column tile and one A read per row tile -- MFMA-bound by construction
+//           (FMR_POLY5_WAVES = 8, one column tile per wave and two waves per SIMD: 2.1 instead of 0.68 ms)
 // fp32 accuracy: a sum of 3122 products carried in one fp32 accumulator drifts by ~sqrt(3122) ulp; the accumulators are
 // therefore flushed into a second set every KC k-steps (64 taps), which bounds the error of each partial sum.
 // afrag layout: [k-step][row tile][lane], zero outside a row's band and in the padding up to a multiple of KC k-steps.
 // ---------------------------------------------------------------------------
 #define FMR_POLY5_KC 32
+#ifndef FMR_POLY5_WAVES
+#define FMR_POLY5_WAVES 4      // waves per workgroup: 4 = two column tiles (8 periods each) per wave, one wave per SIMD; 8 (one tile per wave, two waves per SIMD) measured 3x slower
+#endif
 template <int LB, int MB>
-__global__ __launch_bounds__(256) void k_ifr_poly5(
+__global__ __launch_bounds__(64 * FMR_POLY5_WAVES) void k_ifr_poly5(
     const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
     const float *__restrict__ afrag, int n_ks, int TB, long long k0, int count, float2 *__restrict__ out,
     long long out_stride, int out_off, int tile_len, int n_tiles) {
   static_assert(LB == 48, "three 16-row tiles");
   constexpr int KC = FMR_POLY5_KC, MT = LB / 16, CH = KC * MT * 64;          // floats per A chunk
+  constexpr int NWV = FMR_POLY5_WAVES, NT = 64 * NWV, NH = 8 / NWV;           // column tiles (8 periods each) per wave
+  static_assert(NWV == 4 || NWV == 8, "64 periods per tile");
   typedef float v4f __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float2 lds_b5[];
   const int x_len = ((tile_len + 127) / 128) * 128;          // the x region holds whole 1 KB wave chunks
-  float2 *stage = lds_b5 + x_len;                            // 4 waves x (8 periods x LB) float2
-  float *abuf = reinterpret_cast<float *>(stage + 4 * 8 * LB);   // [2][CH]
+  float2 *stage = lds_b5 + x_len;                            // NWV waves x (8 periods x LB) float2
+  float *abuf = reinterpret_cast<float *>(stage + NWV * 8 * LB);   // [2][CH]
   const int s = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
@@ -811,11 +817,11 @@ __global__ __launch_bounds__(256) void k_ifr_poly5(
   float2 *os = out + (long long)s * out_stride + out_off;
   float2 *mystage = stage + wave * (8 * LB);
   const int n_chunks = n_ks / KC;
-  // A chunk c -> buffer c & 1: CH floats = CH / 256 one-KB pieces, wave w issues pieces w, w + 4, ...
+  // A chunk c -> buffer c & 1: CH floats = CH / 256 one-KB pieces, wave w issues pieces w, w + NWV, ...
   auto fetch_a = [&](int c) {
     const float *src = afrag + (size_t)c * CH;
     float *dst = abuf + (c & 1) * CH;
-    for (int p = wave; p < CH / 256; p += 4)
+    for (int p = wave; p < CH / 256; p += NWV)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 256 + lane * 4),
                                        (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
   };
@@ -826,22 +832,23 @@ __global__ __launch_bounds__(256) void k_ifr_poly5(
     const long long src0 = a0 - mid_abs0;
     if (src0 >= 0 && src0 + x_len <= mid_valid) {
       const float2 *src = ms + src0;
-      for (int c = wave; c < x_len / 128; c += 4)
+      for (int c = wave; c < x_len / 128; c += NWV)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c * 128 + lane * 2),
                                          (__attribute__((address_space(3))) void *)(lds_b5 + c * 128), 16, 0, 0);
     } else {
-      for (int i = tid; i < x_len; i += 256) {                // (zeros up to x_len: the padded k-steps multiply them by zero taps)
+      for (int i = tid; i < x_len; i += NT) {                 // (zeros up to x_len: the padded k-steps multiply them by zero taps)
         const long long idx = a0 + i - mid_abs0;
         lds_b5[i] = (i < tile_len && idx >= 0 && idx < mid_valid) ? ms[idx] : make_float2(0.f, 0.f);
       }
     }
     fetch_a(0);
     const float *xf = reinterpret_cast<const float *>(lds_b5);
-    const float *xb0 = xf + 2 * ((wave * 8 + (n >> 1)) * MB + kq) + (n & 1);
-    const float *xb1 = xf + 2 * (((wave + 4) * 8 + (n >> 1)) * MB + kq) + (n & 1);
-    v4f acc[2][MT], tot[2][MT];
+    const float *xb[NH];
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < NH; h++) xb[h] = xf + 2 * (((wave + NWV * h) * 8 + (n >> 1)) * MB + kq) + (n & 1);
+    v4f acc[NH][MT], tot[NH][MT];
+#pragma unroll
+    for (int h = 0; h < NH; h++)
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) tot[h][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < n_chunks; c++) {
@@ -850,34 +857,36 @@ __global__ __launch_bounds__(256) void k_ifr_poly5(
       if (c + 1 < n_chunks) fetch_a(c + 1);
       const float *ab = abuf + (c & 1) * CH + lane;
 #pragma unroll
-      for (int h = 0; h < 2; h++)
+      for (int h = 0; h < NH; h++)
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) acc[h][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < KC; k++) {
         const int ks = c * KC + k;
-        const float b0 = xb0[8 * ks], b1 = xb1[8 * ks];
+        float b[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) b[h] = xb[h][8 * ks];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
           const float a = ab[(k * MT + mt) * 64];
-          acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0][mt], 0, 0, 0);
-          acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1][mt], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < NH; h++) acc[h][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[h], acc[h][mt], 0, 0, 0);
         }
       }
 #pragma unroll
-      for (int h = 0; h < 2; h++)
+      for (int h = 0; h < NH; h++)
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) tot[h][mt] += acc[h][mt];
     }
     // D[row = 4 kq + v][col = n] -> position p = 16 mt + 4 kq + v of period q0 + n/2, component n & 1
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
-      const int q0 = (wave + 4 * h) * 8;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      const int q0 = (wave + NWV * h) * 8;
       float *sf = reinterpret_cast<float *>(mystage);
 #pragma unroll
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * LB + 16 * mt + 4 * kq + v) + (n & 1)] = h ? tot[1][mt][v] : tot[0][mt][v];
+        for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * LB + 16 * mt + 4 * kq + v) + (n & 1)] = tot[h][mt][v];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave writes and reads its own staging area
       const long long kb = (P0 + q0) * LB - k0;               // local output index of the staged run
 #pragma unroll
