@@ -93,3 +93,47 @@ def test_if_resampler_complex_lockstep():
     assert y.dtype == np.complex64
     # FM signal keeps its constant envelope (0.3) through the front end
     assert np.abs(np.abs(y[300:]).mean() - 0.3) < 1e-3
+
+
+@pytest.mark.parametrize("fin,fout", [(10e6, 384e3), (30e6, 384e3), (40e6, 384e3), (61.44e6, 384e3), (2e6, 48e3),
+                                      (2.048e6, 384e3), (3.2e6, 384e3), (1.92e6, 48e3), (912e3, 48e3), (6e6, 384e3)])
+def test_equiripple_stage_a_rule_holds_across_shapes(fin, fout):
+    """Stage A of the IF class is an equiripple design of 0.68 x the Kaiser length (a fixed formula, not a search: product
+    and oracle cannot pick different lengths).  Measured directly on the PRODUCT's taps (host arithmetic): the pass band
+    stays within 0.0012 dB of unity and every alias of the protected band is at least 139 dB down, for D = 2 ... 61."""
+    import importlib
+    fmr = importlib.import_module("airspy-fmradion_amd")
+    h, d = fmr.design_taps(fin, fout, 140.0, 0)
+    D = d["D"]
+    assert D >= 2 and len(h) == d["NA"] and np.array_equal(h, h[::-1]) and abs(h.sum() - 1.0) < 1e-12
+    mid, fp = fin / D, 0.885 * fout / 2
+    fstop = fout - fp
+    n = np.arange(len(h))
+    resp = lambda f: np.abs(np.exp(-2j * np.pi * np.outer(f, n) / fin) @ h)
+    assert np.max(np.abs(20 * np.log10(resp(np.linspace(0, fp, 1501))))) < 1.2e-3
+    worst = -400.0
+    for k in range(1, D // 2 + 1):
+        lo, hi = k * mid - fstop, min(k * mid + fstop, fin / 2)
+        if lo >= fin / 2:
+            break
+        worst = max(worst, 20 * np.log10(resp(np.linspace(lo, hi, 601)).max()))
+    assert worst < -139.0
+    # 0.68 x the Kaiser length
+    dw = 2 * np.pi * ((mid - fstop) - fp) / fin
+    nk = int(np.ceil((140.0 - 7.95) / (2.285 * dw))) + 1
+    nk += nk % 2 == 0
+    ne = int(np.ceil(0.68 * nk))
+    ne += ne % 2 == 0
+    assert len(h) == ne
+
+
+def test_very_large_decimation_keeps_the_kaiser_stage_a():
+    """Above D = 78 the exchange is not attempted (40 bands is its limit): the Kaiser design of rounds 1 and 2 stays."""
+    import importlib
+    fmr = importlib.import_module("airspy-fmradion_amd")
+    h, d = fmr.design_taps(10e6, 48e3, 140.0, 0)
+    assert d["D"] == 80
+    fp = 0.885 * 24e3
+    n = np.arange(len(h))
+    H = np.abs(np.exp(-2j * np.pi * np.outer(np.linspace(0, fp, 501), n) / 10e6) @ h)
+    assert np.max(np.abs(20 * np.log10(H))) < 1e-5
