@@ -178,7 +178,8 @@ struct fmr_chain {
   DevBuf<float> d_afrag5;
   DevBuf<float> d_afrag;               // v4: constant A fragments
   // fused front end (kernels_fused.hpp): stage A + stage B + discriminator in one persistent kernel
-  bool fused_ok = false;               // the chain's shape fits (10 MS/s class, cf32, no Fs/4, no IF FIR, no equaliser)
+  bool fused_ok = false;               // the chain's shape fits (10 MS/s class, FM, cf32, no Fs/4)
+  bool fused_disc_ok = false;          // ... and nothing sits between the resampler and the discriminator (no IF FIR, no equaliser)
   FusedTaps fused_taps{};
   DevBuf<float> d_hB_last;             // stage-B tap row of position 47
   DevBuf<float> d_fused_taps;          // device copy of fused_taps
@@ -337,6 +338,7 @@ struct fmr_chain {
     int *t_mpf = nullptr;
     long long N_if{};
     bool use_fused{};
+    bool fused_disc{};     // the fused kernel's epilogue is the discriminator (else: IF samples only)
     FusedGeom fused_geom{};
     int par{};
     float2 *ifbuf = nullptr;
@@ -534,12 +536,12 @@ int fmr_chain::init(const fmr_config *c) {
           poly4 = true;
           HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 125, 210>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-          // fused front end: the 10 MS/s shape (D = 10, NA = 103) with a symmetric stage-A filter; FM without IF FIR /
-          // equaliser (the discriminator then reads the IF directly), cf32 input, no Fs/4 shift
+          // fused front end: the 10 MS/s shape (D = 10, NA = 103) with a symmetric stage-A filter, FM, cf32 input, no
+          // Fs/4 shift.  Without IF FIR and equaliser the discriminator reads the IF directly and is the kernel's
+          // epilogue; with either of them the epilogue stores the IF samples and the chain goes on as usual.
           bool sym = rs.D == kFusedD && rs.NA == kFusedNA;
           for (int k = 0; sym && k < rs.NA / 2; k++) sym = (fa[k] == fa[rs.NA - 1 - k]);
-          if (sym && mode == FMR_MODE_FM && !c->fmfilter_enable && c->multipath_stages == 0 && in_fmt == 0 &&
-              !c->enable_fourth_down && !env.no_fused) {
+          if (sym && mode == FMR_MODE_FM && in_fmt == 0 && !c->enable_fourth_down && !env.no_fused) {
             for (int k = 0; k < FUSED_TAP_LEN; k++) fused_taps.h[k] = 0.f;
             for (int k = 0; k < rs.NA; k++) fused_taps.h[FUSED_TAP_PAD + k] = fa[k];
             if ((rc = upload(d_hB_last, fb.data() + (size_t)phi[47] * rs.TB, (size_t)rs.TB))) return rc;
@@ -550,6 +552,7 @@ int fmr_chain::init(const fmr_config *c) {
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
             fused_ok = true;
+            fused_disc_ok = !c->fmfilter_enable && c->multipath_stages == 0;
           }
         }
       }
@@ -914,6 +917,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
   long long count_mid_call = 0;
   N_if = 0;
   use_fused = false;
+  k.fused_disc = false;
   fused_geom = FusedGeom{};
   // Cross-call pipelining: the front end of call N+1 (its own stream, its own IF buffer) runs
   // beside the decoder of call N, whose recurrence kernels leave most of the chip idle.
@@ -947,7 +951,8 @@ int fmr_chain::run_front_end(CallCtx &k) {
       use_fused = true;
       for (int b = 0; b < nb; b++) if (t_if_len[b] != 0 && t_if_len[b] < 128) use_fused = false;
     }
-    dec_valid = !use_fused || debug_taps;      // the float copy of the discriminator output is a debug tap of the fused kernel
+    k.fused_disc = use_fused && fused_disc_ok;
+    dec_valid = !k.fused_disc || debug_taps;   // the float copy of the discriminator output is a debug tap of the fused kernel
     if (use_fused) {
       fused_geom = {mA_prev, kB_prev, n_prev, count_mid};
     } else if (count_mid > 0) {
@@ -1217,7 +1222,8 @@ int fmr_chain::run_tables(CallCtx &k) {
     a.tiles_per_wg = fused_tiles_per_wg;
     const int grid = fused_grid;
     a.wg_blk0 = d_tab_slot + (tab_ints - kMaxFusedWg);
-    a.base = d_base.p; a.base_stride = H_b + (long long)max_if; a.base_off = H_b;
+    a.base = k.fused_disc ? d_base.p : nullptr;      // null: IF samples only (an IF FIR or the equaliser comes first)
+    a.base_stride = H_b + (long long)max_if; a.base_off = H_b;
     a.dec = debug_taps ? d_dec.p : nullptr; a.dec_stride = (long long)max_if;
     a.nf = disc_nf; a.bound = disc_bound;
     a.st = d_state.p; a.hB_last = d_hB_last.p; a.part = d_fused_part.p;
@@ -1383,10 +1389,9 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
         if (it < pll_jac_rounds) { if (wout) shoot(k_pll_shoot<true, true>); else shoot(k_pll_shoot<true, false>); }
         else shoot(k_pll_shoot<false, true>);
         if (it == 0 && agc_deferred) {
-          // side2: the AGC and the mono audio tail beside the PLL.  Gated on an event that
-          // exists already -- the front end's (ev_disc) or k_stats', which fires about when the first pass ends
-          // (FMR_AGC_LATE=1) -- because a marker of its own on this stream costs ~10 us between the first pass
-          // and the node pass (FMR_ORDER_V1=1: that marker).
+          // side2: the AGC and the mono audio tail beside the PLL.  Gated on an event that exists already -- the
+          // front end's (ev_disc) -- because a marker of its own on this stream costs ~10 us between the first pass
+          // and the node pass.
           agc_deferred = false;
           hipEvent_t gate = ev_disc;
           if (!gate) { (void)hipEventRecord(ev_if, stream); gate = ev_if; }
@@ -1484,7 +1489,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   }
   const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
   const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
-  if (!use_fused)        // (the fused front end has already written the discriminator output and the block statistics)
+  if (!k.fused_disc)     // (the fused front end's discriminator epilogue has already written the MPX and the block statistics)
   timed("disc", [&] {
     hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
                        (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,
@@ -1499,7 +1504,7 @@ int fmr_chain::run_fm(CallCtx &k) {
     });
   timed_on(side, "stats", [&] {     // (fused front end: the block values are summed from its partial sums on the fly)
     hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
-                       d_bb_rms_blk.p, d_state.p, S, 1, use_fused ? d_fused_part.p : (const FusedPart *)nullptr,
+                       d_bb_rms_blk.p, d_state.p, S, 1, k.fused_disc ? d_fused_part.p : (const FusedPart *)nullptr,
                        fused_n_tiles, fused_kb_ref);
   });
   HIPCHK(hipEventRecord(ev_stats, side));

@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BLK = 65536                    # Airspy block length (main.cpp:687)
 FS = 10e6
 AM_BLK, AM_FS = 2048, 384e3    # FileSource default block length (FileSource.h:34), configs[2] rate
-STAGE_KERNELS = ("ifr_fused", "ifr_decim", "ifr_poly", "disc")
+STAGE_KERNELS = ("ifr_fused", "ifr_decim", "ifr_poly", "fm_block", "disc")
 
 
 def synth_fm_stereo_torch(n, fs, stream_id, device, pilot=0.10):
@@ -85,6 +85,9 @@ def synth_am_torch(n, fs, stream_id, device):
 R8B = False       # set by main(): the oracle's IfResampler then takes the r8brain-class specification too
 
 
+IF_FILTER = False         # --if-filter: the FM IF filter "medium" (main.cpp -f medium) between resampler and discriminator
+
+
 def _oracle_chain(mode, stages=0):
     import oracle_py as ora
     if mode == "am":
@@ -93,7 +96,9 @@ def _oracle_chain(mode, stages=0):
     else:
         pilotcut = np.load(os.path.join(ROOT, "tests", "golden", "filters", "jj1bdx_48khz_fmaudio.npy"))
         ifr = ora.IfResampler(FS, 384e3, 180.0, 0.98, True) if R8B else ora.IfResampler(FS, 384e3)
-        dec = ora.FmDecoder(False, np.array([0, 1, 0], dtype=np.float32), True, 50.0, False, stages, pilotcut)
+        fir = (np.load(os.path.join(ROOT, "tests", "golden", "filters", "jj1bdx_fm_384kHz_medium.npy")) if IF_FILTER
+               else np.array([0, 1, 0], dtype=np.float32))
+        dec = ora.FmDecoder(IF_FILTER, fir, True, 50.0, False, stages, pilotcut)
     return ifr, dec
 
 
@@ -131,7 +136,7 @@ def committed_pmc_traffic(dom_name, blocks, streams, args):
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/collect_profiles.sh): counters
     cannot be read from inside the timed run.  None when no summary matches this configuration."""
     import glob
-    if streams != 1 or args.mode != "fm" or args.input_format != "cf32" or args.multipath_stages or args.no_pilot:
+    if streams != 1 or args.mode != "fm" or args.input_format != "cf32" or args.multipath_stages or args.no_pilot or args.if_filter:
         return None, None
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
@@ -291,13 +296,16 @@ def main():
                     help="r8b: the IF resampler to the defaults of the reference's r8b::CDSPResampler24 (0.98 x Nyquist, stop "
                          "band from Nyquist, 180 dB; IfResampler.cpp:25-29) -- the reference-equivalent class, its own line, "
                          "never the headline")
+    ap.add_argument("--if-filter", action="store_true",
+                    help="FM: the IF filter 'medium' (main.cpp -f medium) on; the fused front end then stores IF samples")
     ap.add_argument("--all-configs", action="store_true",
                     help="after the headline line, print one line each for configs[2] (AM), configs[3] (-E 64), configs[4] "
                          "(32 streams per GPU) and the mono-station case, each with its own audio check and CPU baseline")
     args = ap.parse_args()
 
-    global R8B
+    global R8B, IF_FILTER
     R8B = args.resampler_class == "r8b"
+    IF_FILTER = bool(args.if_filter)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)              # `python bench.py --gpus N` without a launcher: spawn the N ranks here
 
@@ -345,6 +353,8 @@ def main():
         ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, enable_resampler=True, stereo=True, n_streams=S,
                        max_block_len=blk, max_blocks=B, device=local_rank, input_format=fmt,
                        multipath_stages=args.multipath_stages,
+                       **({"fmfilter_enable": True, "filter_coeff": np.load(os.path.join(
+                           ROOT, "tests", "golden", "filters", "jj1bdx_fm_384kHz_medium.npy"))} if args.if_filter else {}),
                        resampler_class=fmr.RESAMPLER_R8B if args.resampler_class == "r8b" else fmr.RESAMPLER_FAST)
     block_len = [blk] * B
     torch.cuda.synchronize()
@@ -451,6 +461,8 @@ def main():
             workload = "FM stereo decoder on a mono station (no pilot): unlocked steady state, serial PLL"
         elif args.multipath_stages:
             workload = f"configs[3]: as configs[1] with the MultipathFilter equaliser -E {args.multipath_stages}"
+        elif args.if_filter:
+            workload = "as configs[1] with the IF filter on (main.cpp -f medium): resampler -> 127-tap FIR -> discriminator"
         elif R8B:
             workload = ("as configs[1] with the IF resampler in the R8B class (r8b::CDSPResampler24 defaults: 0.98 x Nyquist, "
                         "stop band from Nyquist, 180 dB) -- the reference-equivalent filter, stage B 3122 taps per phase on f32 MFMA")
