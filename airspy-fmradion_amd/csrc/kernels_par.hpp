@@ -1611,24 +1611,35 @@ __global__ __launch_bounds__(64) void k_pll_finish(
   unsigned long long pps_cnt = S.pps_cnt, sample_cnt = S.sample_cnt;
   int n_pps = 0;
   long long wr = 0, ns = 0;
-  // the per-block values of the NEXT 64 blocks are fetched while this batch is walked (the walk is a chain of
-  // cross-lane steps; with the loads inside it every batch paid a memory latency first: 0.12 ms for 2048 blocks)
-  int nx_n = 0, nx_w = 0;
-  double nx_level = 0.0;
-  auto fetch = [&](int b0) {
-    const int bl = min(b0 + lane, bt.nb - 1);
-    const bool in = b0 + lane < bt.nb;
-    nx_n = in ? bt.if_len[bl] : 0;
-    nx_w = in ? blk_wraps[(long long)s * bt.nb + bl] : 0;
-    nx_level = blk_level[(long long)s * bt.nb + bl];
-  };
-  fetch(0);
+  // The per-block values come in through LDS, 1024 blocks per stage with all of a lane's loads in flight at once: the
+  // walk is a chain of cross-lane steps that takes well under a memory latency per batch of 64 blocks, so with the
+  // loads inside it -- or one batch ahead of it, as in round 2 -- every batch waited for memory (0.12 / 0.09 ms for
+  // 2048 blocks).
+  constexpr int kStage = 1024;
+  __shared__ int s_n[kStage], s_w[kStage];
+  __shared__ double s_level[kStage];
   for (int b0 = 0; b0 < bt.nb; b0 += 64) {
+    if ((b0 & (kStage - 1)) == 0) {
+      __syncthreads();                         // (one wave: orders the LDS accesses of the two stages)
+      int vn[kStage / 64], vw[kStage / 64];
+      double vl[kStage / 64];
+#pragma unroll
+      for (int u = 0; u < kStage / 64; u++) {
+        const int b = b0 + u * 64 + lane;
+        const bool in = b < bt.nb;
+        const int bl = in ? b : bt.nb - 1;
+        vn[u] = in ? bt.if_len[bl] : 0;
+        vw[u] = in ? blk_wraps[(long long)s * bt.nb + bl] : 0;
+        vl[u] = blk_level[(long long)s * bt.nb + bl];
+      }
+#pragma unroll
+      for (int u = 0; u < kStage / 64; u++) { s_n[u * 64 + lane] = vn[u]; s_w[u * 64 + lane] = vw[u]; s_level[u * 64 + lane] = vl[u]; }
+      __syncthreads();
+    }
     const int cnt = min(64, bt.nb - b0);
     const bool mine = lane < cnt;
-    const int my_n = nx_n, my_w = nx_w;
-    const double my_level = nx_level;
-    if (b0 + 64 < bt.nb) fetch(b0 + 64);
+    const int my_n = s_n[(b0 & (kStage - 1)) + lane], my_w = s_w[(b0 & (kStage - 1)) + lane];
+    const double my_level = s_level[(b0 & (kStage - 1)) + lane];
     const bool my_ok = (2 * my_level > pc.minsignal) || my_n == 0;    // block keeps the lock (or is empty)
     int my_flag = 0;
     // one block through the reference's per-block logic (PilotPhaseLock.cpp:133-167)
@@ -1644,9 +1655,17 @@ __global__ __launch_bounds__(64) void k_pll_finish(
         // the 19000th period ends inside this block: find the chunk and the sample from the wrap masks
         int kth = pc.pilot_frequency - pilot_periods;      // the kth wrap of this block (1-based)
         const int after = w - kth;                          // wraps of the block after the event
-        for (int c = ct.first[b]; c < ct.first[b + 1]; c++) {
-          const int cw = ck_wraps[(long long)s * ct.nck + c];
-          if (kth > cw) { kth -= cw; continue; }
+        // the chunk that holds it: 64 chunks per step (prefix sum of their wrap counts across the wave) instead of a
+        // chain of dependent loads, one per chunk -- ~20 of them per event, 13 events per 2048-block call
+        const int cf0 = ct.first[b], cf1 = ct.first[b + 1];
+        for (int cb = cf0; cb < cf1; cb += 64) {
+          const int cw_l = (cb + lane < cf1) ? ck_wraps[(long long)s * ct.nck + cb + lane] : 0;
+          const int pre = wave_scan_dpp(cw_l);              // inclusive
+          const int tot = __builtin_amdgcn_readlane(pre, 63);
+          if (kth > tot) { kth -= tot; continue; }
+          const int hit = __ffsll((long long)__ballot(pre >= kth)) - 1;
+          kth -= __builtin_amdgcn_readlane(pre, hit) - __builtin_amdgcn_readlane(cw_l, hit);
+          const int c = cb + hit;
           const unsigned long long *mk = ck_mask + ((long long)s * ct.nck + c) * mask_words;
           int q = -1;
           for (int wd = 0; wd < mask_words && q < 0; wd++) {

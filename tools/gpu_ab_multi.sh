@@ -10,7 +10,7 @@ for r in $(seq 1 $rounds); do
 import json,sys
 v=sys.argv[1]
 b=json.loads([l for l in open(f'gpurun_out/ab/{v}.json') if l.startswith('{')][-1]); k=b['kernel_ms_per_step']
-print(v, b['value'], b['ms_per_step'], 'host', b['host_enqueue_ms_per_step'], 'fused', k.get('ifr_fused'), 'pll', k.get('pll'), 'if_agc', k.get('if_agc'), 'audio', b['audio_check'].get('rms_err'), b['audio_check'].get('timed_step'))
+print(v, b['value'], b['ms_per_step'], 'host', b['host_enqueue_ms_per_step'], 'fused', k.get('ifr_fused'), 'pll', k.get('pll'), 'pll_finish', k.get('pll_finish'), 'fm_out', k.get('fm_out'), 'audio', b['audio_check'].get('rms_err'), b['audio_check'].get('timed_step'))
 PY
   done
 done
