@@ -29,6 +29,7 @@ EXPORTS = [
     "fmr_create", "fmr_destroy", "fmr_last_error", "fmr_version", "fmr_resampler_info", "fmr_process",
     "fmr_process_blocks", "fmr_process_blocks_device", "fmr_synchronize", "fmr_resample", "fmr_get_status",
     "fmr_get_pps_events", "fmr_get_multipath_coefficients", "fmr_debug_read", "fmr_get_kernel_times",
+    "fmr_probe_read_bandwidth",
     "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert", "fmr_design_taps", "fmr_design_taps_class",
     "fmr_host_alloc", "fmr_host_free",
 ]
@@ -169,6 +170,18 @@ def design_taps_class(in_rate, out_rate, resampler_class, stage):
     d = dict(zip(["D", "NA", "LB", "MB", "TB", "LT"], [int(v) for v in info]))
     rows = d["LT"] + 1 if d["LT"] else d["LB"]
     return (buf.reshape(rows, d["TB"]) if stage else buf), d
+
+
+def probe_read_bandwidth(device, dev_ptr, nbytes, reps=5):
+    """GB/s of a plain streaming-read kernel over device memory [dev_ptr, dev_ptr + nbytes): what this box delivers."""
+    out = C.c_double(0.0)
+    L = lib()
+    L.fmr_probe_read_bandwidth.restype = C.c_int
+    L.fmr_probe_read_bandwidth.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    rc = L.fmr_probe_read_bandwidth(int(device), C.c_void_p(int(dev_ptr)), int(nbytes), int(reps), C.byref(out))
+    if rc != 0:
+        raise FmrError(f"fmr_probe_read_bandwidth failed ({rc}): {L.fmr_last_error().decode()}")
+    return out.value
 
 
 DELAY_3TAPS = np.array([0.0, 1.0, 0.0], dtype=np.float32)  # FilterParameters::delay_3taps_only_iq

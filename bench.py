@@ -403,6 +403,18 @@ def main():
     if not args.no_region_events:
         assert all(len(v) == args.steps for v in region.values()), {k: len(v) for k, v in region.items()}
     st = ch.status(0)
+    # The host's own cost per call.  Inside the timed loop the host runs ahead of the GPU until the chain's eight table
+    # slots are taken and is then paced by the GPU: over a long loop t_enq / steps converges to ms_per_step whatever the
+    # host spends.  Four calls enqueued into an idle queue (fewer than the slots) are not paced by anything.
+    ch.enable_kernel_timing(0)
+    t1 = time.perf_counter()
+    for _ in range(4):
+        step()
+    host_unpaced_ms = (time.perf_counter() - t1) / 4 * 1e3
+    ch.synchronize()
+    torch.cuda.synchronize()
+    # what this box delivers to a kernel that only reads the same input buffer (context for the roofline fraction)
+    box_read = fmr.probe_read_bandwidth(local_rank, iq.data_ptr(), iq.numel() * iq.element_size())
     # one extra, untimed step with every kernel instrumented: the per-kernel table.  The instrumented step
     # serialises nothing, but its event pairs span the overlap of the chain's three HIP streams: the entries
     # sum to more than ms_per_step.
@@ -497,6 +509,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic[0], "traffic_source": pmc_traffic[1],
                          "avg_launch_ms": round(dec_ms, 5), "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "box_streaming_read": {"GB/s": round(box_read, 1), "frac_of_peak": round(box_read / HBM_PEAK_GBS, 4),
+                                                "kernel_vs_box": round(achieved / box_read, 4) if box_read > 0 else None,
+                                                "what": "a plain read-only kernel (16-byte loads, 8 workgroups per CU) over the same "
+                                                        "input buffer on this box, best of 5: the roofline's peak is the data sheet's"},
                          "stage": {"what": "FIR + discriminator stage (north star): sum of the average launch durations of "
                                            + " + ".join(k for k in STAGE_KERNELS if k in stage_src),
                                    "ms": round(stage_ms, 5), "achieved": round(stage_achieved, 2),
@@ -505,7 +521,10 @@ def main():
             **({"roofline_mfma": mfma_roofline} if mfma_roofline else {}),
             "kernel_ms_per_step": {k: round(v, 5) for k, v in kavg.items()},
             "kernel_ms_note": "from one extra instrumented step; kernels on the chain's three HIP streams overlap, so the entries sum to more than ms_per_step",
-            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
+            "host_enqueue_ms_per_step": round(host_unpaced_ms, 4),
+            "host_enqueue_note": "host time per call for four calls enqueued into an idle queue (the host's own cost); in the "
+                                 "timed loop the host is paced by the GPU once it is eight calls ahead: " +
+                                 "%.4f ms per step there" % (t_enq / args.steps * 1e3),
             "cold_first_call_ms": round(cold_ms, 2),
             "audio_check": audio_check,
             "recurrences": {"agc_newton_rounds": st.agc_iterations, "pll_newton_rounds": st.pll_iterations,

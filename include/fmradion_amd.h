@@ -208,11 +208,18 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
 
 /* Kernel timing with HIP events on the chain's own streams.  enable = 1: every kernel of
  * the most recent call (diagnostics; the extra events cost host time).  enable = 2: only the
- * dominant front-end kernel ("ifr_decim"), one entry per call accumulated until queried
+ * kernels of the FIR + discriminator stage ("ifr_fused", or "ifr_decim" / "ifr_poly" / "disc", and the IF FIR
+ * "fm_block" of an FM chain), one entry per launch accumulated until queried
  * (what bench.py uses inside its timed region).  Fills names/ms for up to cap entries,
  * returns the count. */
 int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap);
 void fmr_enable_kernel_timing(fmr_chain *c, int enable);
+
+/* Measurement aid (no counterpart in the reference): the rate at which a plain streaming-read kernel (16-byte loads,
+ * every CU busy, nothing else) reads `bytes` of device memory at d_buf on this device, best of `reps` passes, in GB/s.
+ * bench.py reports it next to the roofline fraction: the 8 TB/s of the roofline is the data-sheet peak, this is what
+ * the box the run landed on delivers to a kernel that does nothing but read. */
+int fmr_probe_read_bandwidth(int device, const void *d_buf, size_t bytes, int reps, double *gbytes_per_s);
 
 /* Filter tables of FilterParameters (include/FilterParameters.h:31-49), by name
  * e.g. "jj1bdx_fm_384kHz_medium"; returns the length, *is_double tells the type. */

@@ -8,12 +8,15 @@ root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 cd "$root"
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1
+[ "${2:-}" = "quick" ] || python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o ${tag} -- python bench.py --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_write.log 2>&1
+# tools/collect_profiles.sh <tag> quick: stop here (bench line, stats and PMC passes of the main configuration only;
+# the lines of the other configurations stay as the last full collection left them under gpurun_out/)
+if [ "${2:-}" = "quick" ]; then cut -c1-400 gpurun_out/${tag}_bench.json; exit 0; fi
 # the three-kernel front end (FMR_NO_FUSED=1) under the same counters, for the traffic comparison
 FMR_NO_FUSED=1 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_nofused.json 2> gpurun_out/${tag}_bench_nofused.err
 FMR_NO_FUSED=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch_nofused -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch_nofused.log 2>&1
@@ -25,6 +28,8 @@ python bench.py --multipath-stages 64 --streams 32 --blocks 64 --steps 3 --warmu
 python bench.py --mode am --steps 20 --warmup 3 > gpurun_out/${tag}_bench_config3_am.json 2>/dev/null
 python bench.py --mode am --streams 32 --blocks 1024 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_config3_am_32streams.json 2>/dev/null
 python bench.py --no-pilot --steps 3 --warmup 1 --blocks 256 --no-cpu-baseline > gpurun_out/${tag}_bench_no_pilot.json 2>/dev/null
+timeout 300 python bench.py --resampler-class r8b --steps 20 --warmup 3 > gpurun_out/${tag}_bench_r8b.json 2>/dev/null < /dev/null
+timeout 300 python bench.py --if-filter --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_if_filter.json 2>/dev/null < /dev/null
 timeout 120 tools/bench_fused.bin > gpurun_out/${tag}_fused_harness.log 2>&1
 tail -3 gpurun_out/${tag}_pytest_gpu.log
 cat gpurun_out/${tag}_smoke.log | tail -2
