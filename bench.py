@@ -402,6 +402,8 @@ def main():
         region.setdefault(name, []).append(ms)
     if not args.no_region_events:
         assert all(len(v) == args.steps for v in region.values()), {k: len(v) for k, v in region.items()}
+    if os.environ.get("FMR_BENCH_SERIES") and rank == 0:      # diagnostics: the stage kernels' launch-by-launch durations
+        json.dump({k: [round(float(x), 5) for x in v] for k, v in region.items()}, open(os.environ["FMR_BENCH_SERIES"], "w"))
     st = ch.status(0)
     # The host's own cost per call.  Inside the timed loop the host runs ahead of the GPU until the chain's eight table
     # slots are taken and is then paced by the GPU: over a long loop t_enq / steps converges to ms_per_step whatever the

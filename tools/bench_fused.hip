@@ -399,5 +399,24 @@ int main(int argc, char **argv) {
   launch_new(c, g, d_iq, c.d_if_new, 256);
   CK(hipDeviceSynchronize());
   if (compare("timing geometry: fused vs old", c.d_if_old + c.H_if, c.d_if_new + c.H_if, (size_t)g.N_if) > 2e-6) fails++;
+  // ---- does the placement of the input buffer matter?  The same kernels over six more allocations of the input (all
+  // kept until the end), and over the first one again
+  if (argc > 2) {
+    std::vector<float2 *> bufs;
+    for (int a = 0; a < 6; a++) {
+      float2 *p = nullptr;
+      if (hipMalloc(&p, N * 8 + (size_t)a * 4096 * 17) != hipSuccess) break;
+      CK(hipMemcpy(p, d_iq, N * 8, hipMemcpyDeviceToDevice));
+      bufs.push_back(p);
+    }
+    bufs.push_back(d_iq);
+    for (size_t a = 0; a < bufs.size(); a++) {
+      char nm[96];
+      snprintf(nm, sizeof nm, "allocation %zu (%p): DMA only", a, (void *)bufs[a]);
+      time_it(nm, bytes, [&] { launch_new<3>(c, g, bufs[a], c.d_if_new, 256); });
+      snprintf(nm, sizeof nm, "allocation %zu: product", a);
+      time_it(nm, bytes, [&] { launch_new(c, g, bufs[a], c.d_if_new, 256); });
+    }
+  }
   return fails ? 1 : 0;
 }
