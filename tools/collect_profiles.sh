@@ -25,6 +25,7 @@ FMR_NO_FUSED=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d 
 python bench.py --streams 32 --blocks 128 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_config5_32streams.json 2>/dev/null
 python bench.py --multipath-stages 64 --blocks 64 --steps 5 --warmup 3 > gpurun_out/${tag}_bench_config4_E64.json 2>/dev/null
 python bench.py --multipath-stages 64 --streams 32 --blocks 64 --steps 3 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_config4_E64_32streams.json 2>/dev/null
+for s in 128 256; do timeout 250 python bench.py --multipath-stages 64 --streams $s --blocks 64 --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_config4_E64_${s}streams.json 2>/dev/null < /dev/null; done
 python bench.py --mode am --steps 20 --warmup 3 > gpurun_out/${tag}_bench_config3_am.json 2>/dev/null
 python bench.py --mode am --streams 32 --blocks 1024 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_config3_am_32streams.json 2>/dev/null
 python bench.py --no-pilot --steps 3 --warmup 1 --blocks 256 --no-cpu-baseline > gpurun_out/${tag}_bench_no_pilot.json 2>/dev/null

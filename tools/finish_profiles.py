@@ -102,7 +102,9 @@ rows = {
         (f"{cb.get('value', 0):.1f} MS/s on 1 core; {((cb.get('all_cores') or {}).get('value') or 0):.0f} MS/s with one oracle process per core ({(cb.get('all_cores') or {}).get('cores', '?')} cores)" if cb else "n/a"),
     "audio check inside the bench run (stream 0, first call, vs oracle)": f"RMS error {bench['audio_check'].get('audio_rms_err_vs_oracle')} over {bench['audio_check'].get('audio_samples_checked')} samples (tolerance 1e-5)",
     "config 5 shard: 32 FM stereo streams per GPU": (f"{gs(o('config5_32streams').get('value'))} ({o('config5_32streams').get('ms_per_step')} ms per step of 32 × 128 blocks)" if o('config5_32streams') else "n/a"),
-    "config 4: `-E 64`, one stream / 32 streams": (f"{gs(o('config4_E64').get('value'))} / {gs(o('config4_E64_32streams').get('value'))}" if o('config4_E64') else "n/a"),
+    "config 4: `-E 64`, one stream / 32 streams": (f"{gs(o('config4_E64').get('value'))} / {gs(o('config4_E64_32streams').get('value'))}"
+        + (f"; 128 / 256 streams (one equaliser workgroup per stream: the 256 CUs fill up) {gs(o('config4_E64_128streams').get('value'))} / {gs(o('config4_E64_256streams').get('value'))}" if o('config4_E64_256streams') else "")
+        if o('config4_E64') else "n/a"),
     "config 3: AM 384 kS/s → 48 k, one stream / 32 streams": (f"{gs(o('config3_am').get('value'))} / {gs(o('config3_am_32streams').get('value'))}" if o('config3_am') else "n/a"),
     "stereo decoder on a mono station (unlocked PLL, serial fallback)": (f"{gs(o('no_pilot').get('value'))}" if o('no_pilot') else "n/a"),
 }
