@@ -29,6 +29,7 @@ for s in 128 256; do timeout 250 python bench.py --multipath-stages 64 --streams
 python bench.py --mode am --steps 20 --warmup 3 > gpurun_out/${tag}_bench_config3_am.json 2>/dev/null
 python bench.py --mode am --streams 32 --blocks 1024 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_config3_am_32streams.json 2>/dev/null
 python bench.py --no-pilot --steps 3 --warmup 1 --blocks 256 --no-cpu-baseline > gpurun_out/${tag}_bench_no_pilot.json 2>/dev/null
+for s in 64 256; do timeout 250 python bench.py --no-pilot --streams $s --blocks 32 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_no_pilot_${s}streams.json 2>/dev/null < /dev/null; done
 timeout 300 python bench.py --resampler-class r8b --steps 20 --warmup 3 > gpurun_out/${tag}_bench_r8b.json 2>/dev/null < /dev/null
 timeout 300 python bench.py --if-filter --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_if_filter.json 2>/dev/null < /dev/null
 timeout 120 tools/bench_fused.bin > gpurun_out/${tag}_fused_harness.log 2>&1

@@ -106,7 +106,9 @@ rows = {
         + (f"; 128 / 256 streams (one equaliser workgroup per stream: the 256 CUs fill up) {gs(o('config4_E64_128streams').get('value'))} / {gs(o('config4_E64_256streams').get('value'))}" if o('config4_E64_256streams') else "")
         if o('config4_E64') else "n/a"),
     "config 3: AM 384 kS/s → 48 k, one stream / 32 streams": (f"{gs(o('config3_am').get('value'))} / {gs(o('config3_am_32streams').get('value'))}" if o('config3_am') else "n/a"),
-    "stereo decoder on a mono station (unlocked PLL, serial fallback)": (f"{gs(o('no_pilot').get('value'))}" if o('no_pilot') else "n/a"),
+    "stereo decoder on a mono station (unlocked PLL, serial fallback)": ((f"{gs(o('no_pilot').get('value'))}"
+        + (f" one stream; 64 / 256 streams per GPU (the serial loop runs one stream per lane: 64 streams cost one wave what one costs) {gs(o('no_pilot_64streams').get('value'))} / {gs(o('no_pilot_256streams').get('value'))}" if o('no_pilot_256streams') else ""))
+        if o('no_pilot') else "n/a"),
 }
 pd = os.path.join(root, "DESIGN.md")
 sd = open(pd).read()
