@@ -93,7 +93,7 @@ rows = {
     "`k_ifr_fused` average launch (HIP events in the timed region / rocprofv3)":
         f"{rf['avg_launch_ms'] * 1e3:.1f} µs (bench run) / {summary['hip_events_profiled_run_ms'] * 1e3:.1f} µs vs {rs['average_us_full_batch_launches']:.1f} µs (events vs rocprofv3 kernel trace, the {rs['full_batch_launches']} full-batch launches of the profiled run; `--stats` average over all {rs['calls']} launches incl. the shorter set-up launches: {rs['average_us_all_launches']:.1f} µs)",
     "`roofline` (HBM, 8 B × 2^27 per launch ÷ launch time ÷ 8 TB/s) — dominant kernel = the whole FIR + discriminator stage": f"{rf['achieved']:.0f} GB/s = **{rf['frac']:.3f}** of peak",
-    "same stage with the three-kernel front end (`FMR_NO_FUSED=1`, round 1's path; the full collection's box, where the fused kernel measured 0.246 ms)":
+    "same stage with the three-kernel front end (`FMR_NO_FUSED=1`, round 1's path, same box)":
         (f"{nf['roofline']['stage']['ms']:.3f} ms = {nf['roofline']['stage']['frac']:.3f}; whole job {gs(nf['value'])}" if nf else "not collected"),
     "PMC traffic of the stage (FETCH_SIZE×2 + WRITE_SIZE, separate passes)":
         (f"{fk[0]['hbm_bytes'] / 1e9:.3f} GB per launch = {fk[0]['hbm_bytes'] / alg:.3f} × algorithmic ({fk[0]['read_bytes'] / 1e9:.3f} GB read, {fk[0]['write_bytes'] / 1e9:.3f} GB write: IF + f64 MPX)" if fk else "n/a")
