@@ -623,3 +623,15 @@ def test_library_is_the_hip_path():
     data = open(fmr.LIB_PATH, "rb").read()
     assert b"gfx950" in data
     assert b"ora_fm_process" not in data
+
+
+def test_probe_read_bandwidth_is_plausible():
+    """fmr_probe_read_bandwidth (the measurement aid behind bench.py's roofline.box_streaming_read): a plain read-only
+    kernel over 1 GiB of device memory (four times the last-level cache) reports a rate between a tenth of and the whole data-sheet peak, and refuses
+    a null buffer."""
+    import torch
+    buf = torch.zeros(1 << 28, dtype=torch.float32, device="cuda:0")
+    gbs = fmr.probe_read_bandwidth(0, buf.data_ptr(), buf.numel() * 4, reps=3)
+    assert 800.0 < gbs < 8000.0, gbs
+    with pytest.raises(fmr.FmrError):
+        fmr.probe_read_bandwidth(0, 0, 1 << 28)
