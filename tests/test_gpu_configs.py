@@ -177,6 +177,41 @@ def _run_pair(x, blk, batch, pilotcut, stereo=True):
     return ch, fm, np.concatenate(got), np.concatenate(ref), hist
 
 
+@pytest.mark.parametrize("narrow", [False, True])
+def test_if_filter_behind_the_fused_front_end(narrow, pilotcut, fm_medium):
+    """10 MS/s FM stereo with the IF filter on (main.cpp -f medium / narrow): the fused front end stores the IF samples
+    (its IF-only epilogue), k_fm_block2 filters them block by block (head path at every block start, H1) and k_disc
+    follows -- against IfResampler + FmDecoder(fmfilter_enable) of the oracle, ragged blocks included."""
+    from conftest import load_filter
+    fir = load_filter("jj1bdx_fm_384kHz_narrow") if narrow else fm_medium
+    rng = np.random.default_rng(21)
+    lens = [65536] * 70 + [int(rng.integers(3000, 65537)) for _ in range(20)] + [65536] * 70
+    x = siggen.fm_stereo_iq(sum(lens), 10e6, stream_id=2)
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, fmfilter_enable=True,
+                   filter_coeff=fir, max_block_len=65536, max_blocks=40)
+    r = ora.IfResampler(10e6, 384e3)
+    fm = ora.FmDecoder(True, fir, True, 50.0, False, 0, pilotcut)
+    got, ref, pos = [], [], 0
+    for i in range(0, len(lens), 40):
+        ll = lens[i:i + 40]
+        seg = x[pos:pos + sum(ll)]; pos += sum(ll)
+        a, alen = ch.process_blocks(seg[None, :], ll)
+        got.append(a[0])
+        o = 0
+        for n in ll:
+            ref.append(fm.process(r.process(seg[o:o + n]))); o += n
+        assert list(alen) == [len(q) for q in ref[-len(ll):]]
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    err = rms(got - ref)
+    st = ch.status()
+    _report(f"if_filter_10msps_{'narrow' if narrow else 'medium'}", audio_rms_err=err, n_audio=len(ref), if_rms=st.if_rms,
+            ref_if_rms=fm.get_if_rms())
+    assert err < 1e-5                                   # north-star tolerance
+    assert st.stereo_detected == int(fm.stereo_detected()) == 1
+    assert st.if_rms == pytest.approx(fm.get_if_rms(), rel=1e-5)
+    ch.close()
+
+
 def test_stereo_decoder_on_a_mono_station(pilotcut):
     """stereo=True, no pilot at all (a mono station): the PLL never locks; its phase error is the atan2 of filtered
     noise and wraps at +-pi all the time (PilotPhaseLock.cpp:103), so the chunk maps are not smooth, Newton cannot
