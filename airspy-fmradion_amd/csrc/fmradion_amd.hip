@@ -92,7 +92,13 @@ struct EnvKnobs {
   // Run-time switches (environment).  Everything else that rounds 1 and 2 compared side by side has been decided and
   // removed; what is left selects a MODE of the product or the slower form a test compares the product with.
   bool serial = false;          // FMR_SERIAL=1       serial recurrence kernels (reference loop order on one lane)
-  bool pipeline = false;        // FMR_PIPELINE=1     front end of call N+1 beside the decoder of call N
+  int pipeline = -1;            // FMR_PIPELINE=0/1   the three stages of a call (front end | PLL | audio tail) of consecutive calls
+                                //                    beside each other (1, the default for FM chains with the resampler) or one
+                                //                    in-order chain per call (0: the form the tests compare the product with)
+  int fe_cus = 0;               // FMR_FE_CUS=n       workgroups (= CUs) the persistent front-end kernel takes (0: all)
+  int fe_gate = 1;              // FMR_FE_GATE=0/1/2  what the front end of call N+1 waits for: nothing / the PLL of call N / the tail of call N
+  int prio = 1;                 // FMR_PRIO=0/1       stream priorities: decoder high, front end normal, audio tail low
+  int fe_mask = 0;              // FMR_FE_MASK=n      front-end stream restricted to n CUs (hipExtStreamCreateWithCUMask; 0: no mask)
   bool debug_taps = false;      // FMR_DEBUG_TAPS=1   keep intermediate signals readable through fmr_debug_read
   bool host_prof = false;       // FMR_HOST_PROF=1    host enqueue time per call on stderr
   bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end (tests: fused vs three-kernel property test)
@@ -102,7 +108,10 @@ struct EnvKnobs {
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
   void load() {
-    serial = on("FMR_SERIAL"); pipeline = on("FMR_PIPELINE"); debug_taps = on("FMR_DEBUG_TAPS");
+    serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS");
+    auto num = [](const char *n, int dflt) { const char *e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
+    pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0); fe_gate = num("FMR_FE_GATE", 1);
+    prio = num("FMR_PRIO", 1); fe_mask = num("FMR_FE_MASK", 0);
     host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED"); pll_v1 = set("FMR_PLL_V1");
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
   }
@@ -132,14 +141,38 @@ struct fmr_chain {
   DevBuf<unsigned int> d_pll_tick2;
   int pll_jac_rounds = 1;                // rounds that re-integrate the sensitivities
   double hp_fe = 0, hp_tab = 0, hp_dec = 0; long long hp_calls = 0; bool host_prof = false;   // FMR_HOST_PROF=1
-  hipStream_t fe = nullptr;              // front-end stream (cross-call pipelining)
+  // ---- cross-call pipelining (FM chains with the resampler; DESIGN.md section 5 "Three stages in flight").  A call is
+  // three stages on three streams -- front end (fe: IfResampler + discriminator), PLL stage (stream / side / side2:
+  // statistics, AGC, pilot PLL, lock logic) and audio tail (tail: de-emphasis, audio resampler, pilot cut, DC block,
+  // mux) -- and stage k of call N runs beside stage k-1 of call N+1.  What one stage hands the next lives in a ring
+  // of kPipe slots (IF samples, MPX, L-R, partial sums, per-block lock flags); a slot is refilled once the tail of the
+  // call that used it kPipe calls ago has finished (h_marks[1], polled by the host).  Everything a stage carries from
+  // call to call (halos, StreamState fields) is written by that stage only.
+  hipStream_t fe = nullptr, tail = nullptr;
   bool pipelined = false;
-  int if_parity = 0;
-  static constexpr int kPipe = 3;       // IF buffers in flight when pipelined
-  unsigned long long pipe_seq = 0;       // pipelined calls issued
-  DevBuf<float2> d_if_pp[kPipe];
+  static constexpr int kPipe = 4;        // ring slots
+  unsigned long long pipe_seq = 0;       // decoded calls issued (slot = pipe_seq % kPipe)
+  int ring_prev = -1;                    // slot of the previous decoded call (-1: none yet) and its IF sample count:
+  long long ring_prev_n = 0;             //   the halos of the next slot are carried over from there
+  DevBuf<float2> d_if_pp[kPipe];         // slots 1 .. kPipe-1 (slot 0 = d_if / d_base / d_raw / d_fused_part / d_stereo_blk)
+  DevBuf<double> d_base_pp[kPipe], d_raw_pp[kPipe];
+  DevBuf<FusedPart> d_part_pp[kPipe];
+  DevBuf<int> d_stereo_pp[kPipe];
+  float2 *if_slot(int q) { return q ? d_if_pp[q].p : d_if.p; }
+  double *base_slot(int q) { return q ? d_base_pp[q].p : d_base.p; }
+  double *raw_slot(int q) { return q ? d_raw_pp[q].p : d_raw.p; }
+  FusedPart *part_slot(int q) { return q ? d_part_pp[q].p : d_fused_part.p; }
+  int *stereo_slot(int q) { return q ? d_stereo_pp[q].p : d_stereo_blk.p; }
   float2 *last_if = nullptr;
   hipEvent_t ev_fe[kPipe] = {};
+  bool ev_pll_live = false, ev_tail_live = false;
+  bool disc_commit_on_side = false;      // the last decoded call's discriminator phase is committed by its k_stats (side stream)
+  hipEvent_t ev_tail = nullptr;
+  int sync_all() {                       // every stream of the chain is idle afterwards
+    for (hipStream_t st : {fe, stream, side, side2, tail})
+      if (st) HIPCHK(hipStreamSynchronize(st));
+    return FMR_OK;
+  }
   hipStream_t side = nullptr, side2 = nullptr;   // side2: the IF AGC when it is off the critical path
   hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr,
              ev_tab = nullptr, ev_mono = nullptr;
@@ -242,7 +275,7 @@ struct fmr_chain {
       if (FILE *f = fopen(getenv("FMR_PLL_TRACE_OUT"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
 #endif
-    if (stream) (void)hipStreamSynchronize(stream);
+    for (hipStream_t st : {fe, stream, side, side2, tail}) if (st) (void)hipStreamSynchronize(st);
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     for (auto &k : dom_times) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     d_in.release(); d_in_halo.release(); d_mid.release(); d_if.release(); d_fir.release();
@@ -264,9 +297,15 @@ struct fmr_chain {
       fprintf(stderr, "[fmr host prof] calls %lld  front-end %.1f us  tables %.1f us  decoder %.1f us per call\n", hp_calls,
               hp_fe / hp_calls, hp_tab / hp_calls, hp_dec / hp_calls);
     if (side2 && side2 != side) { (void)hipStreamSynchronize(side2); (void)hipStreamDestroy(side2); }
-    if (fe) { (void)hipStreamSynchronize(fe); (void)hipStreamDestroy(fe); }
+    if (fe) (void)hipStreamDestroy(fe);
+    if (tail) (void)hipStreamDestroy(tail);
     for (auto &e : ev_fe) if (e) (void)hipEventDestroy(e);
+    if (ev_tail) (void)hipEventDestroy(ev_tail);
     for (auto &b : d_if_pp) b.release();
+    for (auto &b : d_base_pp) b.release();
+    for (auto &b : d_raw_pp) b.release();
+    for (auto &b : d_part_pp) b.release();
+    for (auto &b : d_stereo_pp) b.release();
     if (ev_agc) (void)hipEventDestroy(ev_agc);
     if (ev_tab) (void)hipEventDestroy(ev_tab);
     if (ev_mono) (void)hipEventDestroy(ev_mono);
@@ -365,11 +404,17 @@ struct fmr_chain {
     bool agc_deferred{};
     std::function<int(hipEvent_t)> enqueue_agc{};
     bool done = false;                 // the front end found nothing to decode
+    long long count_mid_call{};        // stage-A outputs of this call
+    // this call's slot of the rings the stages hand each other (plain chain: the one buffer of each kind)
+    double *base = nullptr, *raw = nullptr;
+    FusedPart *part = nullptr;
+    int *stereo_blk = nullptr;
     void add_halo(void *buf, long long stride_e, int H, long long N) {   // history to move to the buffer heads at the end of the call
       if (H > 0 && N > 0) ht.d[ht.n++] = HaloDesc{(unsigned long long *)buf, stride_e, H, (int)N};
     }
   };
   int run_front_end(CallCtx &k);
+  int finish_front_end_stage(CallCtx &k);
   int run_tables(CallCtx &k);
   int run_if_stage(CallCtx &k);
   int run_fm(CallCtx &k);
@@ -405,9 +450,38 @@ int fmr_chain::init(const fmr_config *c) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err("no HIP device"); return FMR_ERR_NO_DEVICE; }
   if (c->device < 0 || c->device >= ndev) { set_err("device %d out of range (%d devices)", c->device, ndev); return FMR_ERR_BAD_ARG; }
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
+  // The stages of consecutive calls run beside each other for FM chains with the resampler (the default; FMR_PIPELINE=0:
+  // one in-order chain per call).  The decoder's streams then get the high priority -- their kernels are short, dependent
+  // and latency-bound --, the front end the normal one and the audio tail the low one: what the dispatcher has to choose
+  // between is a front end that holds every CU for a quarter of a millisecond and kernels that need a few wave slots.
+  // (Streams of different priorities also draw from different pools of hardware queues: five streams do not share one.)
+  pipelined = mode == FMR_MODE_FM && c->enable_resampler != 0 && !env.serial && env.pipeline != 0;
+  {
+    int pr_low = 0, pr_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&pr_low, &pr_high);
+    const bool use_prio = pipelined && env.prio && pr_low != pr_high;
+    auto mk = [&](hipStream_t *st, int level) -> hipError_t {     // level: +1 high, 0 normal, -1 low
+      if (!use_prio) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+      const int pr = level > 0 ? pr_high : level < 0 ? pr_low : (pr_low + pr_high) / 2;
+      return hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr);
+    };
+    HIPCHK(mk(&stream, 1));
+    HIPCHK(mk(&side, 1));
+    HIPCHK(mk(&side2, 1));
+    if (pipelined) {
+      if (env.fe_mask > 0) {
+        // bit i of the mask is CU (i / 8) of XCD (i % 8) on this part: the first n bits spread over the eight XCDs
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < env.fe_mask && i < 256; i++) mask[i / 32] |= 1u << (i % 32);
+        HIPCHK(hipExtStreamCreateWithCUMask(&fe, 8, mask));
+      } else {
+        HIPCHK(mk(&fe, 0));
+      }
+      HIPCHK(mk(&tail, -1));
+      HIPCHK(hipEventCreateWithFlags(&ev_tail, hipEventDisableTiming));
+      for (int q = 0; q < kPipe; q++) HIPCHK(hipEventCreateWithFlags(&ev_fe[q], hipEventDisableTiming));
+    }
+  }
   HIPCHK(hipEventCreateWithFlags(&ev_agc, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ev_tab, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ev_mono, hipEventDisableTiming));
@@ -579,22 +653,9 @@ int fmr_chain::init(const fmr_config *c) {
   last_if = d_if.p;
   host_prof = env.host_prof; debug_taps = env.debug_taps;
   if (env.pll_rtol >= 0.0) pll_rtol = env.pll_rtol;
-  {
-    // Opt-in (FMR_PIPELINE=1): +5 % whole-job rate on config 2, but the front-end kernel then shares HBM
-    // with the decoder's tail and its own launch takes 0.28 ms instead of 0.20 ms.
-    pipelined = has_rs && has_dec && !fir_enable && env.pipeline;
-    if (pipelined) {
-      // HIP multiplexes streams onto 4 hardware queues: a fifth stream would share one with the AGC stream and the
-      // front end would queue behind 0.45 ms of AGC kernels.  The AGC moves onto `side` (after the statistics).
-      (void)hipStreamDestroy(side2);
-      side2 = side;
-      HIPCHK(hipStreamCreateWithFlags(&fe, hipStreamNonBlocking));
-      for (int q = 0; q < kPipe; q++) {
-        if ((rc = d_if_pp[q].alloc((size_t)S * (H_if + max_if)))) return rc;
-        HIPCHK(hipEventCreateWithFlags(&ev_fe[q], hipEventDisableTiming));
-      }
-    }
-  }
+  if (pipelined)
+    for (int q = 1; q < kPipe; q++)
+      if ((rc = d_if_pp[q].alloc((size_t)S * (H_if + max_if)))) return rc;
   h_state.assign(S, StreamState{});
   for (auto &st : h_state) {
     st.agc_gain = 1.0f;
@@ -700,6 +761,13 @@ int fmr_chain::init(const fmr_config *c) {
     H_b = FMR_DE_WARMUP + H_a;           // warm-up of the fused de-emphasis reaches below the oldest stage-A tap
     if ((rc = d_base.alloc((size_t)S * (H_b + max_if)))) return rc;
     if ((rc = d_raw.alloc((size_t)S * (H_b + max_if)))) return rc;
+    if (pipelined)
+      for (int q = 1; q < kPipe; q++) {
+        if ((rc = d_base_pp[q].alloc((size_t)S * (H_b + max_if)))) return rc;
+        if ((rc = d_raw_pp[q].alloc((size_t)S * (H_b + max_if)))) return rc;
+        if (fused_ok && (rc = d_part_pp[q].alloc(d_fused_part.n))) return rc;
+        if ((rc = d_stereo_pp[q].alloc((size_t)S * max_blocks))) return rc;
+      }
     if ((rc = d_base_de.alloc((size_t)S * (H_a + max_if)))) return rc;
     if ((rc = d_raw_de.alloc((size_t)S * (H_a + max_if)))) return rc;
     if ((rc = d_pll_nodes.alloc((size_t)S * (max_ck + 1) * 7))) return rc;
@@ -893,16 +961,23 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   k.t_if_off = t_if_off; k.t_if_len = t_if_len; k.t_au_off = t_au_off; k.t_au_len = t_au_len; k.t_mpf = t_mpf;
   if (int rc = run_front_end(k)) return rc;
   if (k.done) return FMR_OK;
+  k.base = base_slot(k.par); k.raw = raw_slot(k.par); k.part = part_slot(k.par); k.stereo_blk = stereo_slot(k.par);
   hp1 = std::chrono::steady_clock::now();
   if (int rc = run_tables(k)) return rc;
   hp2 = std::chrono::steady_clock::now();
   if (int rc = run_if_stage(k)) return rc;
   if (int rc = (mode == FMR_MODE_FM) ? run_fm(k) : (mode == FMR_MODE_NBFM) ? run_nbfm(k) : run_am(k)) return rc;
   HaloTable &ht = k.ht;
+  hipStream_t last = pipelined ? tail : stream;       // the stream that carries the end of the call
   if (ht.n) {
-    timed("shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht); });
+    timed_on(last, "shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, last, ht); });
   }
-  if (pipelined) hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, stream, &h_marks[1], pipe_seq);
+  if (pipelined) {
+    hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, tail, &h_marks[1], pipe_seq);
+    HIPCHK(hipEventRecord(ev_tail, tail));
+    ev_tail_live = true;
+    ring_prev = k.par; ring_prev_n = k.N_if;
+  }
   HIPCHK(hipGetLastError());
   return FMR_OK;
 }
@@ -920,20 +995,8 @@ int fmr_chain::run_front_end(CallCtx &k) {
   use_fused = false;
   k.fused_disc = false;
   fused_geom = FusedGeom{};
-  // Cross-call pipelining: the front end of call N+1 (its own stream, its own IF buffer) runs
-  // beside the decoder of call N, whose recurrence kernels leave most of the chip idle.
-  par = pipelined ? (if_parity = (if_parity + 1) % kPipe) : 0;
   hipStream_t fes = pipelined ? fe : stream;
-  ifbuf = pipelined ? d_if_pp[par].p : d_if.p;
-  last_if = ifbuf;
-  // The decoder that last read this IF buffer (kPipe calls ago) must be done before the front end refills it.
-  // The host polls a counter that a one-thread kernel at the end of every decoder writes into pinned host memory:
-  // HIP event waits (stream-side or host-side) resolve against the newest signal of the other stream at call
-  // time -- most of the PREVIOUS call -- and serialise the two stages again (measured).
-  if (pipelined) {
-    pipe_seq++;
-    if (int rcw = wait_mark(&h_marks[1], pipe_seq > (unsigned long long)kPipe ? pipe_seq - kPipe : 0)) return rcw;
-  }
+  par = 0;
   if (has_rs) {
     const long long mA_prev = rsc.mA, kB_prev = rsc.kB, n_prev = rsc.n_in;
     for (int b = 0; b < nb; b++) {
@@ -942,12 +1005,30 @@ int fmr_chain::run_front_end(CallCtx &k) {
       t_if_len[b] = (int)k;
       N_if += k;
     }
+    // Cross-call pipelining: this call's front end (its own stream, its own slot of the IF / MPX / partial-sum ring) runs
+    // beside the PLL stage of the call before it and the audio tail of the call before that.  The slot was last read by the
+    // tail of the call kPipe calls ago: the host polls a counter that a one-thread kernel at the end of every tail writes
+    // into pinned host memory -- HIP event waits (stream-side or host-side) resolve against the newest signal of the other
+    // stream at call time and would tie the stages together again (measured).  A call that yields no IF sample
+    // decodes nothing and takes no slot.
+    if (pipelined && N_if > 0) {
+      pipe_seq++;
+      par = (int)(pipe_seq % kPipe);
+      // (one slot less than the ring holds: the slot of call N is still read at the head of call N+1, by the kernel that
+      // carries its halos over, and that kernel is only ordered before the tail of call N+1)
+      if (int rcw = wait_mark(&h_marks[1], pipe_seq > (unsigned long long)(kPipe - 1) ? pipe_seq - (kPipe - 1) : 0)) return rcw;
+      // where in the previous call's chain this front end may start (FMR_FE_GATE; scheduling only, no data dependence)
+      if (env.fe_gate == 1 && ev_pll_live) HIPCHK(hipStreamWaitEvent(fe, ev_pll, 0));
+      if (env.fe_gate == 2 && ev_tail_live) HIPCHK(hipStreamWaitEvent(fe, ev_tail, 0));
+    }
+    ifbuf = if_slot(par);
+    last_if = ifbuf;
     const int count_mid = (int)(rsc.mA - mA_prev);
     count_mid_call = count_mid;
     if ((size_t)count_mid > max_mid || (size_t)N_if > max_if) { set_err("internal capacity exceeded"); return FMR_ERR_CAPACITY; }
     // Fused front end (stage A + stage B + discriminator in one persistent kernel) when this call is long enough and
     // its blocks are not tiny; any other call takes the three-kernel path -- both keep the same carried state.
-    if (fused_ok && has_dec && !serial_mode && !pipelined && N_if >= 4 * 384 && count_mid >= H_mid &&
+    if (fused_ok && has_dec && !serial_mode && N_if >= 4 * 384 && count_mid >= H_mid &&
         ((uintptr_t)d_iq % 16) == 0 && (stride % 2) == 0) {
       use_fused = true;
       for (int b = 0; b < nb; b++) if (t_if_len[b] != 0 && t_if_len[b] < 128) use_fused = false;
@@ -1067,6 +1148,8 @@ int fmr_chain::run_front_end(CallCtx &k) {
       });
     }
   } else {
+    ifbuf = d_if.p;
+    last_if = ifbuf;
     for (int b = 0; b < nb; b++) { t_if_off[b] = (int)N_if; t_if_len[b] = (int)block_len[b]; N_if += block_len[b]; }
     if (N_if > 0)
       HIPCHK(hipMemcpy2DAsync(ifbuf + H_if, sizeof(float2) * (H_if + max_if), d_iq, sizeof(float2) * stride,
@@ -1076,27 +1159,40 @@ int fmr_chain::run_front_end(CallCtx &k) {
   last_n_if = N_if; last_nb = nb; last_n_au = 0;
   ht = HaloTable{};
   ht.n = 0;
+  k.count_mid_call = count_mid_call;
   if (has_rs && pipelined) {
-    if (count_mid_call > 0) {
-      HaloTable hm{};
-      hm.d[0] = HaloDesc{(unsigned long long *)d_mid.p, H_mid + (long long)max_mid, H_mid, (int)count_mid_call};
-      hm.n = 1;
-      hipLaunchKernelGGL(k_shift_halo<256>, dim3(1, S), dim3(256), 0, fe, hm);
+    // the front-end stage keeps its own history: the stage-B halo is re-seated on its stream (after the fused kernel,
+    // which is launched from run_tables, when that one runs)
+    if (!use_fused) {
+      if (int rcf = finish_front_end_stage(k)) return rcf;
     }
-    HIPCHK(hipEventRecord(ev_fe[par], fe));
-    HIPCHK(hipStreamWaitEvent(stream, ev_fe[par], 0));
   } else if (has_rs) {
     add_halo(d_mid.p, H_mid + (long long)max_mid, H_mid, count_mid_call);
   }
   if (!has_dec || N_if == 0) {
     hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, side, &h_marks[0], call_seq);   // no table this call
-    if (pipelined) hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, stream, &h_marks[1], pipe_seq);
     if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = 0;
-    if (has_dec && fir_enable) add_halo(ifbuf, H_if + (long long)max_if, H_if, N_if);
+    if (has_dec && fir_enable && !pipelined) add_halo(ifbuf, H_if + (long long)max_if, H_if, N_if);
     if (ht.n) hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht);
     HIPCHK(hipGetLastError());
     k.done = true;                      // nothing to decode this call
     return FMR_OK;
+  }
+  return FMR_OK;
+}
+
+// Pipelined chain, end of the front-end stage on its stream: stage-B history for the next call, then the event the PLL
+// stage of this call waits for.
+int fmr_chain::finish_front_end_stage(CallCtx &k) {
+  if (k.count_mid_call > 0) {
+    HaloTable hm{};
+    hm.d[0] = HaloDesc{(unsigned long long *)d_mid.p, H_mid + (long long)max_mid, H_mid, (int)k.count_mid_call};
+    hm.n = 1;
+    hipLaunchKernelGGL(k_shift_halo<256>, dim3(1, S), dim3(256), 0, fe, hm);
+  }
+  if (has_dec && k.N_if > 0) {
+    HIPCHK(hipEventRecord(ev_fe[k.par], fe));
+    HIPCHK(hipStreamWaitEvent(stream, ev_fe[k.par], 0));
   }
   return FMR_OK;
 }
@@ -1157,7 +1253,8 @@ int fmr_chain::run_tables(CallCtx &k) {
     const long long P_first = fused_geom.kB_prev / 48, P_last = (fused_geom.kB_prev + N_if - 1) / 48;
     fused_T_first = P_first / 8;
     fused_n_tiles = (int)(P_last / 8 - fused_T_first + 1);
-    const int wg_per_stream = std::max(1, std::min(kMaxFusedWg, n_cu / S));
+    const int fe_cus = (pipelined && env.fe_cus > 0) ? std::min(env.fe_cus, n_cu) : n_cu;
+    const int wg_per_stream = std::max(1, std::min(kMaxFusedWg, fe_cus / S));
     fused_tiles_per_wg = (fused_n_tiles + wg_per_stream - 1) / wg_per_stream;
     fused_grid = (fused_n_tiles + fused_tiles_per_wg - 1) / fused_tiles_per_wg;
     int *t_wg = h_tab + (tab_ints - kMaxFusedWg);
@@ -1168,8 +1265,15 @@ int fmr_chain::run_tables(CallCtx &k) {
       while (b < nb && (long long)t_if_off[b] + t_if_len[b] <= kf) b++;
       t_wg[w] = b;
     }
-    hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((fused_grid + 255) / 256)), dim3(256), 0, side,
+    // the kernel's own tables: first block of every workgroup and, when the front end runs a call ahead of the decoder,
+    // the block table too (the side stream's copy of it sits behind the previous call's lock logic; both copies write
+    // the same values)
+    hipStream_t ts = pipelined ? fe : side;
+    hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((fused_grid + 255) / 256)), dim3(256), 0, ts,
                        (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), fused_grid);
+    if (pipelined)
+      hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((2 * (size_t)max_blocks + 255) / 256)), dim3(256), 0, fe,
+                         (const int *)h_tab, d_tab_slot, 2 * max_blocks);
   }
   int *d_first = d_tab_slot + 5 * (size_t)max_blocks;
   int *d_ck = d_tab_slot + head_ints;
@@ -1193,6 +1297,17 @@ int fmr_chain::run_tables(CallCtx &k) {
     const int nc = (int)((N_if + C_AGC - 1) / C_AGC);
     hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, side, d_flags.p, d_agc_nodes.p, nc, d_state.p, S,
                        (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p, pll_tick2_per_stream);
+  }
+  if (pipelined && ring_prev >= 0 && ring_prev != k.par) {
+    // halos of this call's ring slot = the tail of the previous call's slot (its writers -- front end, discriminator, PLL
+    // -- are ordered before this stream's lock logic of that call; nothing of this call touches the head of a slot)
+    CarryTable ctab{};
+    const long long bstr = H_b + (long long)max_if;
+    const int np = (int)ring_prev_n;
+    ctab.d[ctab.n++] = CarryDesc{(const unsigned long long *)base_slot(ring_prev), (unsigned long long *)k.base, bstr, H_b, np};
+    if (stereo) ctab.d[ctab.n++] = CarryDesc{(const unsigned long long *)raw_slot(ring_prev), (unsigned long long *)k.raw, bstr, H_b, np};
+    if (fir_enable) ctab.d[ctab.n++] = CarryDesc{(const unsigned long long *)if_slot(ring_prev), (unsigned long long *)ifbuf, H_if + (long long)max_if, H_if, np};
+    hipLaunchKernelGGL(k_carry_halo<256>, dim3(ctab.n, S), dim3(256), 0, side, ctab);
   }
   HIPCHK(hipEventRecord(ev_tab, side));
   HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
@@ -1223,11 +1338,11 @@ int fmr_chain::run_tables(CallCtx &k) {
     a.tiles_per_wg = fused_tiles_per_wg;
     const int grid = fused_grid;
     a.wg_blk0 = d_tab_slot + (tab_ints - kMaxFusedWg);
-    a.base = k.fused_disc ? d_base.p : nullptr;      // null: IF samples only (an IF FIR or the equaliser comes first)
+    a.base = k.fused_disc ? k.base : nullptr;        // null: IF samples only (an IF FIR or the equaliser comes first)
     a.base_stride = H_b + (long long)max_if; a.base_off = H_b;
     a.dec = debug_taps ? d_dec.p : nullptr; a.dec_stride = (long long)max_if;
     a.nf = disc_nf; a.bound = disc_bound;
-    a.st = d_state.p; a.hB_last = d_hB_last.p; a.part = d_fused_part.p;
+    a.st = d_state.p; a.hB_last = d_hB_last.p; a.part = k.part;
     a.if_off = bt.if_off; a.if_len = bt.if_len; a.nb = nb;
     {   // the first block k_stats walks (kernels.hpp, same rule): earlier blocks need no partial sums
       int seen = 0, b_first = 0;
@@ -1239,11 +1354,22 @@ int fmr_chain::run_tables(CallCtx &k) {
     }
     if ((size_t)a.n_tiles * 3 * S > d_fused_part.n) { set_err("internal capacity exceeded (fused tiles)"); return FMR_ERR_CAPACITY; }
     constexpr size_t kLds = FusedShape<D, NA>::LDS_BYTES;
-    timed("ifr_fused", [&] {
-      if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, stream, a);
-      else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, stream, a);
+    hipStream_t fes = pipelined ? fe : stream;
+    // the discriminator's carried phase: when the previous call ran the discriminator in its decoder stage (a call too
+    // short for the fused kernel), its phase is committed by that call's statistics kernel on the side stream
+    if (pipelined && k.fused_disc && disc_commit_on_side) HIPCHK(hipStreamWaitEvent(fe, ev_stats, 0));
+    timed_on(fes, "ifr_fused", [&] {
+      if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, a);
+      else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, a);
     });
     fused_kb_ref = a.kb_ref;
+    if (pipelined) {
+      // what the front-end stage carries into its next call: the discriminator's last phase, the input history, the
+      // stage-B history -- all on its own stream
+      if (k.fused_disc) hipLaunchKernelGGL(k_disc_commit, dim3((S + 63) / 64), dim3(64), 0, fe, d_state.p, S);
+      hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, fe, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
+      if (int rcf = finish_front_end_stage(k)) return rcf;
+    }
   }
   return FMR_OK;
 }
@@ -1365,8 +1491,8 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
   auto &nb = k.nb; auto &N_if = k.N_if; auto &nck = k.nck; auto &ct = k.ct; auto &bt = k.bt; auto &agc_on_side = k.agc_on_side; auto &agc_deferred = k.agc_deferred; auto &enqueue_agc = k.enqueue_agc;
   if (serial_mode) {
     timed("pll", [&] {
-      hipLaunchKernelGGL(k_pll, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt, d_raw.p,
-                         base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p, S);
+      hipLaunchKernelGGL(k_pll, dim3((S + 63) / 64), dim3(64), 0, stream, k.base, base_stride, H_b, bt, k.raw,
+                         base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, k.stereo_blk, d_state.p, S);
     });
   } else {
     // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
@@ -1380,8 +1506,8 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
         // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
         PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
         auto shoot = [&](auto kern) {
-          hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, stream, d_base.p, base_stride, H_b, ct,
-                             d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
+          hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, stream, k.base, base_stride, H_b, ct,
+                             k.raw, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
                              d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
                              pll_rtol, (int)(it > 0));
         };
@@ -1429,8 +1555,8 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
         hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                            nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
       }
-      hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, d_base.p, base_stride, H_b, bt,
-                         d_raw.p, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_stereo_blk.p, d_state.p,
+      hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, k.base, base_stride, H_b, bt,
+                         k.raw, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, k.stereo_blk, d_state.p,
                          S, d_flags.p);
     });
     if (rc_agc) return rc_agc;
@@ -1441,9 +1567,9 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
     timed_on(side, "pll_finish", [&] {
       hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, side, bt, ct, d_pll_G.p,
                          d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
-      hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, side, d_base.p, base_stride, H_b, bt, ct, d_atan.p,
+      hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, side, k.base, base_stride, H_b, bt, ct, d_atan.p,
                          pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
-                         d_blk_wraps.p, d_blk_level.p, d_stereo_blk.p, d_state.p, d_flags.p);
+                         d_blk_wraps.p, d_blk_level.p, k.stereo_blk, d_state.p, d_flags.p);
     });
     // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
     // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
@@ -1494,21 +1620,22 @@ int fmr_chain::run_fm(CallCtx &k) {
   timed("disc", [&] {
     hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
                        (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,
-                       disc_nf, disc_bound, d_dec.p, (long long)max_if, d_base.p, base_stride, H_b,
+                       disc_nf, disc_bound, d_dec.p, (long long)max_if, k.base, base_stride, H_b,
                        d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p, rms_in_disc ? d_if_rms_blk.p : (float *)nullptr);
   });
   HIPCHK(hipEventRecord(ev_disc, stream));
   HIPCHK(hipStreamWaitEvent(side, ev_disc, 0));
-  if (use_fused)      // input history for the next call's front end: off the critical path (the next
+  if (use_fused && !pipelined)      // input history for the next call's front end: off the critical path (the next
     timed_on(side, "in_halo", [&] {   // front end waits for this stream's table kernels anyway)
       hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, side, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
     });
   timed_on(side, "stats", [&] {     // (fused front end: the block values are summed from its partial sums on the fly)
     hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
-                       d_bb_rms_blk.p, d_state.p, S, 1, k.fused_disc ? d_fused_part.p : (const FusedPart *)nullptr,
-                       fused_n_tiles, fused_kb_ref);
+                       d_bb_rms_blk.p, d_state.p, S, (int)!(pipelined && k.fused_disc),   // (the front-end stage commits its own phase)
+                       k.fused_disc ? k.part : (const FusedPart *)nullptr, fused_n_tiles, fused_kb_ref);
   });
   HIPCHK(hipEventRecord(ev_stats, side));
+  disc_commit_on_side = !(pipelined && k.fused_disc);
   bool fin_on_side = false, fin_covers_all = false;
   const int nch = stereo ? 2 : 1;
   // ---------------------------------------------------- audio resampler + tail
@@ -1537,7 +1664,7 @@ int fmr_chain::run_fm(CallCtx &k) {
           const int tiles = (count_am + de_tout - 1) / de_tout;
           const size_t lds = sizeof(double) * (size_t)(DE_SLOTS + DE_SLOTS / 16 + 1);
           auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(tiles, S, nch_l), dim3(DE_BLOCK), lds, st, d_base.p, d_raw.p, base_stride, H_b,
+            hipLaunchKernelGGL(kern, dim3(tiles, S, nch_l), dim3(DE_BLOCK), lds, st, k.base, k.raw, base_stride, H_b,
                                (int)N_if, deemph.b0, deemph.a1, de_scan, 1, (int)(stereo && !pilot_shift), d_ahA.p,
                                ars.NA, ars.D, a_top0, count_am, de_tout, d_am0.p, d_am1.p, am_stride, H_am,
                                debug_taps ? d_base_de.p : (double *)nullptr,
@@ -1551,7 +1678,7 @@ int fmr_chain::run_fm(CallCtx &k) {
       // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
       timed_on(st, "deemph", [&] {
         const int nt = (int)((N_if + C_DE - 1) / C_DE);
-        hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch_l), dim3(64), 0, st, d_base.p, d_raw.p,
+        hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch_l), dim3(64), 0, st, k.base, k.raw,
                            base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
                            (int)(stereo && !pilot_shift));
       });
@@ -1598,50 +1725,65 @@ int fmr_chain::run_fm(CallCtx &k) {
                            (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc, ch_base);
       });
   };
-  const bool split_mono = stereo && !serial_mode && de_fused && (ars.LB == 3 && ars.MB == 8) &&
+  // In the pipelined chain both channels belong to the tail STAGE (its own stream, a call behind the PLL stage): the mono
+  // channel's buffers are still being read by the previous call's DC block and mux while this call's PLL iterates.
+  const bool split_mono = stereo && !serial_mode && !pipelined && de_fused && (ars.LB == 3 && ars.MB == 8) &&
                           n_pilotcut <= FMR_PCUT_MAXTAPS;
   bool mono_enqueued = false;
   if (stereo) {
     if (int rcp = run_fm_pll(k, base_stride, split_mono, enqueue_tail_channels, mono_enqueued, fin_on_side, fin_covers_all)) return rcp;
   }
   if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr)) return rca; }   // PLL path not taken
-  if (mono_enqueued) enqueue_tail_channels(stream, 1, 1);
-  else enqueue_tail_channels(stream, 0, nch);
-  if (mono_enqueued) HIPCHK(hipStreamWaitEvent(stream, ev_mono, 0));   // DC-block node pass needs both channels
+  hipStream_t ts = stream;
+  if (pipelined) {
+    // end of the PLL stage on the decoder stream: the next call's front end may be gated on it (FMR_FE_GATE), the tail
+    // of this call starts from it
+    if (!stereo) HIPCHK(hipEventRecord(ev_pll, stream));
+    ev_pll_live = true;
+    ts = tail;
+    HIPCHK(hipStreamWaitEvent(tail, ev_pll, 0));
+  }
+  if (mono_enqueued) enqueue_tail_channels(ts, 1, 1);
+  else enqueue_tail_channels(ts, 0, nch);
+  if (mono_enqueued) HIPCHK(hipStreamWaitEvent(ts, ev_mono, 0));   // DC-block node pass needs both channels
   if (N_au > 0) {
-    if (fin_on_side && serial_mode) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
+    if (fin_on_side && serial_mode) HIPCHK(hipStreamWaitEvent(ts, ev_fin, 0));
     if (serial_mode) {
       timed("fm_out", [&] {
         hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
                            dcblock.b0, dcblock.b1, dcblock.b2, dcblock.a1, dcblock.a2, (int)stereo, (int)pilot_shift,
-                           d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
+                           k.stereo_blk, d_aud, (long long)astride, d_state.p);
       });
     } else {
       // ---- DC block by linear multiple shooting + output mux
-      timed("fm_out", [&] {
+      timed_on(ts, "fm_out", [&] {
         const int dc_nw = std::max(1, std::min(FMR_DC_MAXW, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
-        hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, dc_nc, dk,
+        hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, ts, d_dc_G.p, d_dc_start.p, dc_nc, dk,
                            d_state.p, S, nch);
-        if (fin_on_side) (void)hipStreamWaitEvent(stream, ev_fin, 0);   // only the mux needs the lock flags
-        hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, stream, d_pc0.p, d_pc1.p,
+        if (fin_on_side) (void)hipStreamWaitEvent(ts, ev_fin, 0);   // only the mux needs the lock flags
+        hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, ts, d_pc0.p, d_pc1.p,
                            (long long)max_au, bt, (int)N_au, dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,
-                           d_stereo_blk.p, d_aud, (long long)astride, d_state.p);
+                           k.stereo_blk, d_aud, (long long)astride, d_state.p);
       });
     }
   }
-  if (fir_enable) add_halo(ifbuf, if_stride, H_if, N_if);
-  add_halo(d_base.p, base_stride, H_b, N_if);
-  if (stereo) add_halo(d_raw.p, base_stride, H_b, N_if);
-  add_halo(d_base_de.p, de_stride, H_a, N_if);
-  if (stereo) add_halo(d_raw_de.p, de_stride, H_a, N_if);
+  if (!pipelined) {      // (pipelined: the halos of the ring slots are carried over at the head of the next call, run_tables)
+    if (fir_enable) add_halo(ifbuf, if_stride, H_if, N_if);
+    add_halo(k.base, base_stride, H_b, N_if);
+    if (stereo) add_halo(k.raw, base_stride, H_b, N_if);
+  }
+  if (!de_fused || debug_taps) {     // (the fused de-emphasis keeps the 384 kHz signal in LDS: these are taps then)
+    add_halo(d_base_de.p, de_stride, H_a, N_if);
+    if (stereo) add_halo(d_raw_de.p, de_stride, H_a, N_if);
+  }
   add_halo(d_am0.p, am_stride, H_am, count_am);
   if (stereo) add_halo(d_am1.p, am_stride, H_am, count_am);
   add_halo(d_a10.p, a1_stride, H_pc, N_au);
   if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
   if (!(fin_covers_all && N_au > 0)) {        // (otherwise the wait before the output mux covered all three)
-    HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
-    if (agc_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_agc, 0));
-    if (fin_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_fin, 0));
+    HIPCHK(hipStreamWaitEvent(ts, ev_stats, 0));
+    if (agc_on_side) HIPCHK(hipStreamWaitEvent(ts, ev_agc, 0));
+    if (fin_on_side) HIPCHK(hipStreamWaitEvent(ts, ev_fin, 0));
   }
   if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
   return FMR_OK;
@@ -1741,7 +1883,7 @@ int fmr_create(const fmr_config *cfg, fmr_chain **out) {
   fmr_chain *c = new fmr_chain();
   const int rc = c->init(cfg);
   if (rc != FMR_OK) { delete c; return rc; }
-  if (hipStreamSynchronize(c->stream) != hipSuccess) { delete c; return FMR_ERR_HIP; }
+  if (c->sync_all() != FMR_OK) { delete c; return FMR_ERR_HIP; }
   *out = c;
   return FMR_OK;
 }
@@ -1803,8 +1945,7 @@ void fmr_host_free(void *p) {
 
 int fmr_synchronize(fmr_chain *c) {
   if (!c) return FMR_ERR_BAD_ARG;
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return FMR_OK;
+  return c->sync_all();
 }
 
 // how many doubles per stream the blocks would produce, from copies of the count-law counters (nothing is advanced)
@@ -1833,7 +1974,7 @@ int fmr_process_blocks_device(fmr_chain *c, const float *d_iq, size_t stream_str
     }
     const int rc = c->run_cold_aware((const float2 *)d_iq, stream_stride, block_len, n_blocks, d_audio, audio_stride, audio_len);
     if (rc) return rc;
-    if (sync) HIPCHK(hipStreamSynchronize(c->stream));
+    if (sync) return c->sync_all();
     return FMR_OK;
   } catch (const std::exception &e) { set_err("exception: %s", e.what()); return FMR_ERR_HIP; }
 }
@@ -1864,10 +2005,9 @@ int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, cons
   if (total && audio) {
     if (total > audio_stride) { set_err("audio capacity too small"); return FMR_ERR_CAPACITY; }
     HIPCHK(hipMemcpy2DAsync(audio, sizeof(double) * audio_stride, c->d_audio.p, sizeof(double) * dstride,
-                            sizeof(double) * total, c->S, hipMemcpyDeviceToHost, c->stream));
+                            sizeof(double) * total, c->S, hipMemcpyDeviceToHost, c->pipelined ? c->tail : c->stream));
   }
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return FMR_OK;
+  return c->sync_all();
   } catch (const std::exception &e) { set_err("exception: %s", e.what()); return FMR_ERR_HIP; }
 }
 
@@ -1917,7 +2057,7 @@ int fmr_resample(fmr_chain *c, const float *iq, size_t n, float *out_iq, size_t 
 
 static int fetch_state(fmr_chain *c) {
   HIPCHK(hipSetDevice(c->cfg.device));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (int rc = c->sync_all()) return rc;
   HIPCHK(hipMemcpy(c->h_state.data(), c->d_state.p, sizeof(StreamState) * c->S, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(c->h_flags.data(), c->d_flags.p, sizeof(IterFlags) * c->S, hipMemcpyDeviceToHost));
   return FMR_OK;
@@ -1971,7 +2111,7 @@ int fmr_get_multipath_coefficients(fmr_chain *c, int stream, float *coeff, int c
   if (!c || stream < 0 || stream >= c->S || c->mpf_N == 0) return FMR_ERR_BAD_ARG;
   if (cap < 2 * c->mpf_N) return FMR_ERR_CAPACITY;
   HIPCHK(hipSetDevice(c->cfg.device));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (int rc = c->sync_all()) return rc;
   HIPCHK(hipMemcpy(coeff, c->d_mpf_coeff.p + (size_t)stream * c->mpf_N, sizeof(float2) * c->mpf_N, hipMemcpyDeviceToHost));
   return c->mpf_N;
 }
@@ -1979,7 +2119,7 @@ int fmr_get_multipath_coefficients(fmr_chain *c, int stream, float *coeff, int c
 long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t cap_bytes) {
   if (!c || stream < 0 || stream >= c->S) return FMR_ERR_BAD_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (int rc = c->sync_all()) return rc;
   const long long n = c->last_n_if;
   const void *src = nullptr;
   size_t esz = 0;
@@ -2042,7 +2182,7 @@ void fmr_enable_kernel_timing(fmr_chain *c, int enable) { if (c) c->timing = ena
 
 int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap) {
   if (!c) return FMR_ERR_BAD_ARG;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (int rc = c->sync_all()) return rc;
   int n = 0;
   if (c->timing == 2) {   // dominant kernel only: one entry per call since the last query
     for (auto &k : c->dom_times) {

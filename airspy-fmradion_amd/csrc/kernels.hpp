@@ -928,6 +928,23 @@ __global__ __launch_bounds__(BLOCK) void k_shift_halo(HaloTable tab) {
   }
 }
 
+// Pipelined chain: the halo of a ring slot comes from the slot of the call before it -- dst[i] = concat(halo, data)_src[i + N],
+// i < H, src != dst (N = samples the previous call appended to src).
+struct CarryDesc {
+  const unsigned long long *src;
+  unsigned long long *dst;
+  long long stride;
+  int H, N;
+};
+struct CarryTable { CarryDesc d[4]; int n; };
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_carry_halo(CarryTable tab) {
+  const CarryDesc d = tab.d[blockIdx.x];
+  const unsigned long long *a = d.src + (long long)blockIdx.y * d.stride;
+  unsigned long long *b = d.dst + (long long)blockIdx.y * d.stride;
+  for (int i = threadIdx.x; i < d.H; i += BLOCK) b[i] = a[i + d.N];
+}
+
 // K_A's input halo lives in its own buffer because the caller owns the input:
 // newhalo[i] = concat(halo, iq[0..N))[i + N].
 template <int BLOCK, int FMT = 0>
@@ -1528,6 +1545,13 @@ struct FusedPart {
   int blk[2];            // block of the samples before / after the cut (-1: none)
   float sum[2][3];       // sum d, sum d^2 (discriminator output), sum |x|^2 (IF) of each piece
 };
+
+// Pipelined chain with the fused front end: the discriminator's carried phase (m_save_value) belongs to the front-end
+// stage and is committed on its stream (k_stats, which does it for the in-order chain, runs a stage later).
+__global__ void k_disc_commit(StreamState *st, int n_streams) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n_streams && st[s].disc_save_valid) { st[s].disc_save = st[s].disc_save_next; st[s].disc_save_valid = 0; }
+}
 
 // one wave per stream: 64 block results per load, the EMA chain runs on SGPR broadcasts.  part != nullptr: the block
 // values are summed here from the fused front end's pieces (index order: deterministic) instead of read from the
