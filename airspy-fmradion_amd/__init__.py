@@ -29,7 +29,7 @@ EXPORTS = [
     "fmr_create", "fmr_destroy", "fmr_last_error", "fmr_version", "fmr_resampler_info", "fmr_process",
     "fmr_process_blocks", "fmr_process_blocks_device", "fmr_synchronize", "fmr_resample", "fmr_get_status",
     "fmr_get_pps_events", "fmr_get_multipath_coefficients", "fmr_debug_read", "fmr_get_kernel_times",
-    "fmr_probe_read_bandwidth",
+    "fmr_probe_read_bandwidth", "fmr_get_kernel_trace",
     "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert", "fmr_design_taps", "fmr_design_taps_class",
     "fmr_host_alloc", "fmr_host_free",
 ]
@@ -318,6 +318,18 @@ class Chain:
     def enable_kernel_timing(self, mode=1):
         """0 off, 1 every kernel of the last call, 2 the dominant kernel only (accumulated over calls)."""
         lib().fmr_enable_kernel_timing(self.h, int(mode))
+
+    def kernel_trace(self, cap=1 << 16):
+        """After enable_kernel_timing(3): [(name, stream, start_ms, end_ms)] of every instrumented kernel since then."""
+        names = (C.c_char_p * cap)()
+        st = (C.c_int * cap)()
+        t0 = (C.c_float * cap)()
+        t1 = (C.c_float * cap)()
+        L = lib()
+        L.fmr_get_kernel_trace.restype = C.c_int
+        L.fmr_get_kernel_trace.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+        n = self._chk(L.fmr_get_kernel_trace(self.h, names, st, t0, t1, cap))
+        return [(names[i].decode(), st[i], t0[i], t1[i]) for i in range(min(n, cap))]
 
     def kernel_times(self, cap=4096):
         names = (C.c_char_p * cap)()

@@ -99,6 +99,13 @@ struct EnvKnobs {
   int fe_gate = 1;              // FMR_FE_GATE=0/1/2  what the front end of call N+1 waits for: nothing / the PLL of call N / the tail of call N
   int prio = 1;                 // FMR_PRIO=0/1       stream priorities: decoder high, front end normal, audio tail low
   int fe_mask = 0;              // FMR_FE_MASK=n      front-end stream restricted to n CUs (hipExtStreamCreateWithCUMask; 0: no mask)
+  int pll_iters = 0;            // FMR_PLL_ITERS=n    measurement only: PLL Newton rounds enqueued per call
+  int spare_aside = 0;          // FMR_SPARE_ASIDE=0/1 pipelined chain: the PLL's spare Newton rounds on the side stream (1) or the decoder stream (0)
+  int fe_stream = 1;            // FMR_FE_STREAM=0/1  pipelined chain: the front end on a stream of its own (0) or on the decoder stream (1)
+  int tail_defer = 1;           // FMR_TAIL_DEFER=0/1 pipelined chain: a call's tail stage is enqueued behind the next call's front end (1)
+                                //                    or at once, behind its own PLL stage (0)
+  int agc_stream = 0;           // FMR_AGC_STREAM=0/1/2 pipelined chain: the IF AGC on a stream of its own / on the side stream behind the
+                                //                    statistics / on the front-end stream behind the front end of its own call
   bool debug_taps = false;      // FMR_DEBUG_TAPS=1   keep intermediate signals readable through fmr_debug_read
   bool host_prof = false;       // FMR_HOST_PROF=1    host enqueue time per call on stderr
   bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end (tests: fused vs three-kernel property test)
@@ -111,7 +118,7 @@ struct EnvKnobs {
     serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS");
     auto num = [](const char *n, int dflt) { const char *e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
     pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0); fe_gate = num("FMR_FE_GATE", 1);
-    prio = num("FMR_PRIO", 1); fe_mask = num("FMR_FE_MASK", 0);
+    prio = num("FMR_PRIO", 1); fe_mask = num("FMR_FE_MASK", 0); agc_stream = num("FMR_AGC_STREAM", 0); tail_defer = num("FMR_TAIL_DEFER", 1); fe_stream = num("FMR_FE_STREAM", 1); spare_aside = num("FMR_SPARE_ASIDE", 0); pll_iters = num("FMR_PLL_ITERS", 0);
     host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED"); pll_v1 = set("FMR_PLL_V1");
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
   }
@@ -169,6 +176,7 @@ struct fmr_chain {
   bool disc_commit_on_side = false;      // the last decoded call's discriminator phase is committed by its k_stats (side stream)
   hipEvent_t ev_tail = nullptr;
   int sync_all() {                       // every stream of the chain is idle afterwards
+    if (int rc = flush_tail(nullptr)) return rc;
     for (hipStream_t st : {fe, stream, side, side2, tail})
       if (st) HIPCHK(hipStreamSynchronize(st));
     return FMR_OK;
@@ -265,6 +273,9 @@ struct fmr_chain {
   int timing = 0;                       // 0 off, 1 every kernel (diagnostics), 2 the dominant kernel only
   std::vector<KernelTime> dom_times;    // mode 2: ifr_decim events accumulated over calls until queried
   std::vector<KernelTime> ktimes;
+  std::vector<KernelTime> trace;        // mode 3
+  std::vector<int> trace_stream;        //   0 decoder, 1 side, 2 side2, 3 front end, 4 tail
+  hipEvent_t trace_base = nullptr;
 
   ~fmr_chain() {
 #ifdef FMR_PLL_TRACE
@@ -275,6 +286,7 @@ struct fmr_chain {
       if (FILE *f = fopen(getenv("FMR_PLL_TRACE_OUT"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
 #endif
+    if (stream) (void)flush_tail(nullptr);
     for (hipStream_t st : {fe, stream, side, side2, tail}) if (st) (void)hipStreamSynchronize(st);
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     for (auto &k : dom_times) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
@@ -292,6 +304,8 @@ struct fmr_chain {
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     if (h_marks) (void)hipHostFree(h_marks);
     for (hipEvent_t e : {ev_disc, ev_pll, ev_stats, ev_fin, ev_if}) if (e) (void)hipEventDestroy(e);
+    if (side2 == side || side2 == fe || side2 == tail) side2 = nullptr;      // (pipelined chain: the AGC may share a stream)
+    if (fe == stream) fe = nullptr;
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (host_prof && hp_calls)
       fprintf(stderr, "[fmr host prof] calls %lld  front-end %.1f us  tables %.1f us  decoder %.1f us per call\n", hp_calls,
@@ -328,6 +342,18 @@ struct fmr_chain {
       launch();
       (void)hipEventRecord(kt.b, st);
       dom_times.push_back(kt);
+      return;
+    }
+    if (timing == 3) {      // trace: every instrumented kernel of every call since the mode was switched on, with its stream
+      if (!trace_base) { (void)hipEventCreate(&trace_base); (void)hipEventRecord(trace_base, st); }
+      KernelTime kt{name, nullptr, nullptr};
+      (void)hipEventCreate(&kt.a);
+      (void)hipEventCreate(&kt.b);
+      (void)hipEventRecord(kt.a, st);
+      launch();
+      (void)hipEventRecord(kt.b, st);
+      trace.push_back(kt);
+      trace_stream.push_back(st == stream ? 0 : st == side ? 1 : st == fe ? 3 : st == side2 ? 2 : 4);
       return;
     }
     if (timing != 1) { launch(); return; }
@@ -404,6 +430,8 @@ struct fmr_chain {
     bool agc_deferred{};
     std::function<int(hipEvent_t)> enqueue_agc{};
     bool done = false;                 // the front end found nothing to decode
+    bool pll_tail_on_side = false;     // the PLL's spare rounds ran on the side stream: L-R is final at ev_fin, not at ev_pll
+    std::function<void()> fe_post{};   // pipelined chain: the front-end stage's end-of-call kernel, when it is still to be launched
     long long count_mid_call{};        // stage-A outputs of this call
     // this call's slot of the rings the stages hand each other (plain chain: the one buffer of each kind)
     double *base = nullptr, *raw = nullptr;
@@ -413,6 +441,25 @@ struct fmr_chain {
       if (H > 0 && N > 0) ht.d[ht.n++] = HaloDesc{(unsigned long long *)buf, stride_e, H, (int)N};
     }
   };
+  // what the audio tail of one call needs, by value: in the pipelined chain the tail stage is enqueued a call later
+  struct TailCtx {
+    double *base = nullptr, *raw = nullptr;
+    int *stereo_blk = nullptr;
+    long long N_if{}, N_au{}, a_top0{}, amA_prev{}, akB_prev{}, astride{};
+    int nb{}, count_am{}, de_tout{}, dc_nc{}, nch{};
+    bool de_fused{}, fin_on_side{}, fin_covers_all{}, agc_on_side{}, mono_enqueued{}, raw_at_fin{};
+    BlockTab bt{};
+    double *d_aud = nullptr;
+    DcCoef dk{};
+    HaloTable ht{};
+    unsigned long long seq{};
+  };
+  static constexpr int kDeBlock = 256;
+  TailCtx tail_job{};
+  bool tail_pending = false;
+  void tail_channels(const TailCtx &t, hipStream_t st, int ch_base, int nch_l);
+  int tail_stage(const TailCtx &t, hipStream_t ts);
+  int flush_tail(hipEvent_t gate);
   int run_front_end(CallCtx &k);
   int finish_front_end_stage(CallCtx &k);
   int run_tables(CallCtx &k);
@@ -451,10 +498,16 @@ int fmr_chain::init(const fmr_config *c) {
   if (c->device < 0 || c->device >= ndev) { set_err("device %d out of range (%d devices)", c->device, ndev); return FMR_ERR_BAD_ARG; }
   HIPCHK(hipSetDevice(c->device));
   // The stages of consecutive calls run beside each other for FM chains with the resampler (the default; FMR_PIPELINE=0:
-  // one in-order chain per call).  The decoder's streams then get the high priority -- their kernels are short, dependent
-  // and latency-bound --, the front end the normal one and the audio tail the low one: what the dispatcher has to choose
-  // between is a front end that holds every CU for a quarter of a millisecond and kernels that need a few wave slots.
-  // (Streams of different priorities also draw from different pools of hardware queues: five streams do not share one.)
+  // one in-order chain per call).  Streams:
+  //   stream  the critical chain: front end of call N, PLL of call N, front end of call N+1 ... -- both hold the whole chip
+  //           (152 KB of LDS per CU; 1258 one-wave workgroups), so they alternate anyway, and on ONE queue the hand-off
+  //           between them is a packet boundary, not an event travelling between two queues (~50 us each way, measured)
+  //   side    tables, statistics, lock logic          side2  the IF AGC          tail  the audio tail, a call behind
+  // Four streams, four hardware queues: a GPU pipe serves one queue at a time and HIP hands a process four; a fifth busy
+  // stream shares a queue (or, with more queues allowed, a pipe) with another and the two take turns (measured: slower
+  // than the in-order chain).  With priorities on, the decoder's streams are high, the AGC normal, the tail low -- streams
+  // of different priorities also draw from different queue pools, so a host that owns a stream of its own (torch's) does
+  // not push two of ours onto one queue.
   pipelined = mode == FMR_MODE_FM && c->enable_resampler != 0 && !env.serial && env.pipeline != 0;
   {
     int pr_low = 0, pr_high = 0;
@@ -467,19 +520,32 @@ int fmr_chain::init(const fmr_config *c) {
     };
     HIPCHK(mk(&stream, 1));
     HIPCHK(mk(&side, 1));
-    HIPCHK(mk(&side2, 1));
     if (pipelined) {
-      if (env.fe_mask > 0) {
-        // bit i of the mask is CU (i / 8) of XCD (i % 8) on this part: the first n bits spread over the eight XCDs
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < env.fe_mask && i < 256; i++) mask[i / 32] |= 1u << (i % 32);
-        HIPCHK(hipExtStreamCreateWithCUMask(&fe, 8, mask));
+      if (env.fe_stream == 0) {           // (measurement: the front end on a stream of its own)
+        if (env.fe_mask > 0) {
+          // bit i of the mask is CU (i / 8) of XCD (i % 8) on this part: the first n bits spread over the eight XCDs
+          uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int i = 0; i < env.fe_mask && i < 256; i++) mask[i / 32] |= 1u << (i % 32);
+          HIPCHK(hipExtStreamCreateWithCUMask(&fe, 8, mask));
+        } else {
+          HIPCHK(mk(&fe, 0));
+        }
       } else {
-        HIPCHK(mk(&fe, 0));
+        fe = stream;
       }
       HIPCHK(mk(&tail, -1));
+      // the AGC needs this call's IF samples and nothing else: its own stream (0), the side stream behind the statistics
+      // (1), behind its own call's front end on a separate front-end stream (2), or the tail stream in front of its own
+      // call's tail (3)
+      const int as = (env.agc_stream == 2 && fe == stream) ? 0 : env.agc_stream;
+      if (as == 1) side2 = side;
+      else if (as == 2) side2 = fe;
+      else if (as == 3) side2 = tail;
+      else HIPCHK(mk(&side2, 0));
       HIPCHK(hipEventCreateWithFlags(&ev_tail, hipEventDisableTiming));
       for (int q = 0; q < kPipe; q++) HIPCHK(hipEventCreateWithFlags(&ev_fe[q], hipEventDisableTiming));
+    } else {
+      HIPCHK(mk(&side2, 1));
     }
   }
   HIPCHK(hipEventCreateWithFlags(&ev_agc, hipEventDisableTiming));
@@ -968,16 +1034,10 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   if (int rc = run_if_stage(k)) return rc;
   if (int rc = (mode == FMR_MODE_FM) ? run_fm(k) : (mode == FMR_MODE_NBFM) ? run_nbfm(k) : run_am(k)) return rc;
   HaloTable &ht = k.ht;
-  hipStream_t last = pipelined ? tail : stream;       // the stream that carries the end of the call
-  if (ht.n) {
-    timed_on(last, "shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, last, ht); });
+  if (ht.n) {      // (pipelined chain: the tail stage has taken the table with it, flush_tail)
+    timed("shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(ht.n, S), dim3(256), 0, stream, ht); });
   }
-  if (pipelined) {
-    hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, tail, &h_marks[1], pipe_seq);
-    HIPCHK(hipEventRecord(ev_tail, tail));
-    ev_tail_live = true;
-    ring_prev = k.par; ring_prev_n = k.N_if;
-  }
+  if (pipelined) { ring_prev = k.par; ring_prev_n = k.N_if; }
   HIPCHK(hipGetLastError());
   return FMR_OK;
 }
@@ -1018,7 +1078,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
       // carries its halos over, and that kernel is only ordered before the tail of call N+1)
       if (int rcw = wait_mark(&h_marks[1], pipe_seq > (unsigned long long)(kPipe - 1) ? pipe_seq - (kPipe - 1) : 0)) return rcw;
       // where in the previous call's chain this front end may start (FMR_FE_GATE; scheduling only, no data dependence)
-      if (env.fe_gate == 1 && ev_pll_live) HIPCHK(hipStreamWaitEvent(fe, ev_pll, 0));
+      if (fe != stream && env.fe_gate == 1 && ev_pll_live) HIPCHK(hipStreamWaitEvent(fe, ev_pll, 0));
       if (env.fe_gate == 2 && ev_tail_live) HIPCHK(hipStreamWaitEvent(fe, ev_tail, 0));
     }
     ifbuf = if_slot(par);
@@ -1192,7 +1252,9 @@ int fmr_chain::finish_front_end_stage(CallCtx &k) {
   }
   if (has_dec && k.N_if > 0) {
     HIPCHK(hipEventRecord(ev_fe[k.par], fe));
-    HIPCHK(hipStreamWaitEvent(stream, ev_fe[k.par], 0));
+    if (fe != stream) HIPCHK(hipStreamWaitEvent(stream, ev_fe[k.par], 0));
+    // the previous call's tail stage: behind this front end, beside this call's PLL stage
+    if (int rc = flush_tail(ev_fe[k.par])) return rc;
   }
   return FMR_OK;
 }
@@ -1253,7 +1315,12 @@ int fmr_chain::run_tables(CallCtx &k) {
     const long long P_first = fused_geom.kB_prev / 48, P_last = (fused_geom.kB_prev + N_if - 1) / 48;
     fused_T_first = P_first / 8;
     fused_n_tiles = (int)(P_last / 8 - fused_T_first + 1);
-    const int fe_cus = (pipelined && env.fe_cus > 0) ? std::min(env.fe_cus, n_cu) : n_cu;
+    // Pipelined chain: the front end leaves one CU of every XCD free.  A workgroup is dispatched inside the XCD its index
+    // maps to, and the kernels that run beside the front end -- lock logic (32 KB of LDS), the DC block's node pass (213
+    // VGPRs), the spare PLL rounds -- do not fit beside a 152 KB workgroup: on an XCD the front end fills they wait for
+    // it to end (measured: the lock logic 250 instead of 55 us, and the next PLL pass behind it).
+    const int fe_dflt = pipelined ? std::max(8, n_cu - 8) : n_cu;
+    const int fe_cus = (pipelined && env.fe_cus > 0) ? std::min(env.fe_cus, n_cu) : fe_dflt;
     const int wg_per_stream = std::max(1, std::min(kMaxFusedWg, fe_cus / S));
     fused_tiles_per_wg = (fused_n_tiles + wg_per_stream - 1) / wg_per_stream;
     fused_grid = (fused_n_tiles + fused_tiles_per_wg - 1) / fused_tiles_per_wg;
@@ -1309,8 +1376,12 @@ int fmr_chain::run_tables(CallCtx &k) {
     if (fir_enable) ctab.d[ctab.n++] = CarryDesc{(const unsigned long long *)if_slot(ring_prev), (unsigned long long *)ifbuf, H_if + (long long)max_if, H_if, np};
     hipLaunchKernelGGL(k_carry_halo<256>, dim3(ctab.n, S), dim3(256), 0, side, ctab);
   }
-  HIPCHK(hipEventRecord(ev_tab, side));
-  HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
+  // the decoder waits for the tables.  In the pipelined chain the front end shares its stream and must not: the wait is
+  // enqueued behind the front end's launch (below)
+  if (!pipelined) {
+    HIPCHK(hipEventRecord(ev_tab, side));
+    HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
+  }
   bt = BlockTab{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
               d_tab_slot + 4 * max_blocks, nb};
   if_stride = H_if + (long long)max_if;
@@ -1364,12 +1435,24 @@ int fmr_chain::run_tables(CallCtx &k) {
     });
     fused_kb_ref = a.kb_ref;
     if (pipelined) {
-      // what the front-end stage carries into its next call: the discriminator's last phase, the input history, the
-      // stage-B history -- all on its own stream
-      if (k.fused_disc) hipLaunchKernelGGL(k_disc_commit, dim3((S + 63) / 64), dim3(64), 0, fe, d_state.p, S);
-      hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, fe, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
-      if (int rcf = finish_front_end_stage(k)) return rcf;
+      // The PLL stage starts from here.  What the front-end stage carries into its next call -- the input history, the
+      // stage-B history, the discriminator's last phase -- is one small kernel on its stream; when that stream is the
+      // decoder's it is launched behind the PLL's first pass (run_fm_pll), not between the front end and that pass.
+      HIPCHK(hipEventRecord(ev_fe[k.par], fe));
+      if (fe != stream) HIPCHK(hipStreamWaitEvent(stream, ev_fe[k.par], 0));
+      const int commit = (int)k.fused_disc, count_mid = fused_geom.count_mid;
+      k.fe_post = [=] {
+        hipLaunchKernelGGL(k_fe_post<256>, dim3(3, S), dim3(256), 0, fe, d_in_halo.p, H_in, d_iq, (long long)stride, N_in,
+                           d_mid.p, (long long)(H_mid + max_mid), H_mid, count_mid, d_state.p, commit);
+      };
+      if (fe != stream) { k.fe_post(); k.fe_post = nullptr; }
+      // the previous call's tail stage: behind this front end, beside this call's PLL stage
+      if (int rc = flush_tail(ev_fe[k.par])) return rc;
     }
+  }
+  if (pipelined) {
+    HIPCHK(hipEventRecord(ev_tab, side));
+    HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
   }
   return FMR_OK;
 }
@@ -1500,13 +1583,21 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
     timed("pll", [&] {
       const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
       const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
-      const int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
+      int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
+      if (env.pll_iters > 0) pll_iters = env.pll_iters;                   // (measurement only)
+      // Pipelined chain: a call in lock accepts its second pass, and the kernels of the spare rounds -- they find the
+      // converged flag set and return, seven dependent launches all the same -- move off the critical stream: from the
+      // second node pass on the rounds run on the side stream, in front of the lock logic that waits for them anyway,
+      // while the decoder stream goes on with the next call's front end.  (A call that does need its third pass then
+      // integrates it beside that front end, on the CUs it leaves free: slower, and correct.)
+      const bool spare_aside = pipelined && !env.pll_v1 && env.spare_aside && pll_iters > 2;
+      hipStream_t ps = stream;
       for (int it = 0; it < pll_iters; it++) {
         // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
         // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
         PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
         auto shoot = [&](auto kern) {
-          hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, stream, k.base, base_stride, H_b, ct,
+          hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, ps, k.base, base_stride, H_b, ct,
                              k.raw, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
                              d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
                              pll_rtol, (int)(it > 0));
@@ -1515,6 +1606,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
         const bool wout = it > 0 || env.pll_v1 || nck <= 2;
         if (it < pll_jac_rounds) { if (wout) shoot(k_pll_shoot<true, true>); else shoot(k_pll_shoot<true, false>); }
         else shoot(k_pll_shoot<false, true>);
+        if (it == 0 && k.fe_post) { k.fe_post(); k.fe_post = nullptr; }
         if (it == 0 && agc_deferred) {
           // side2: the AGC and the mono audio tail beside the PLL.  Gated on an event that exists already -- the
           // front end's (ev_disc) -- because a marker of its own on this stream costs ~10 us between the first pass
@@ -1535,11 +1627,16 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
           hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
                              (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
         if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
+        if (spare_aside && it == 1) {
+          (void)hipEventRecord(ev_pll, stream);
+          (void)hipStreamWaitEvent(side, ev_pll, 0);
+          ps = side;
+        }
         if (!env.pll_v1) {
-          hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
+          hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, ps, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
                              d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p, d_flags.p, d_pll_sync.p,
                              d_pll_tick2.p);
-          hipLaunchKernelGGL(k_pll_down, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
+          hipLaunchKernelGGL(k_pll_down, dim3(ngrp, S), dim3(64), 0, ps, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
                              d_pll_pre.p, d_pll_dstart2.p, ngrp2, d_flags.p, pllc.minfreq, pllc.maxfreq,
                              d_pll_sync.p);
           continue;
@@ -1555,15 +1652,18 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
         hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                            nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
       }
-      hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, stream, k.base, base_stride, H_b, bt,
+      hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, ps, k.base, base_stride, H_b, bt,
                          k.raw, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, k.stereo_blk, d_state.p,
                          S, d_flags.p);
+      k.pll_tail_on_side = (ps == side);
     });
     if (rc_agc) return rc_agc;
     HIPCHK(hipGetLastError());    // a launch of the rounds above that could not be enqueued
     // lock logic / PPS / state commit beside the audio chain (needed again only by fm_out)
-    HIPCHK(hipEventRecord(ev_pll, stream));
-    HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
+    if (!k.pll_tail_on_side) {
+      HIPCHK(hipEventRecord(ev_pll, stream));
+      HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
+    }
     timed_on(side, "pll_finish", [&] {
       hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, side, bt, ct, d_pll_G.p,
                          d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
@@ -1637,155 +1737,202 @@ int fmr_chain::run_fm(CallCtx &k) {
   HIPCHK(hipEventRecord(ev_stats, side));
   disc_commit_on_side = !(pipelined && k.fused_disc);
   bool fin_on_side = false, fin_covers_all = false;
-  const int nch = stereo ? 2 : 1;
   // ---------------------------------------------------- audio resampler + tail
-  const int count_am = (int)(arsc.mA - amA_prev);
+  TailCtx t{};
+  t.base = k.base; t.raw = k.raw; t.stereo_blk = k.stereo_blk; t.N_if = N_if; t.N_au = N_au; t.nb = nb; t.bt = bt;
+  t.d_aud = d_aud; t.astride = (long long)astride; t.amA_prev = amA_prev; t.akB_prev = akB_prev;
+  t.nch = stereo ? 2 : 1;
+  t.count_am = (int)(arsc.mA - amA_prev);
+  if ((size_t)t.count_am > max_amid || (size_t)N_au > max_au) { set_err("internal audio capacity exceeded"); return FMR_ERR_CAPACITY; }
+  t.a_top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
+  // fused de-emphasis + stage A: the tile (warm-up + (TOUT-1) D + NA samples) must fit BLOCK * LPL LDS slots;
+  // at most 4 * DE_BLOCK outputs per tile: every lane then owns exactly one run of 4 outputs in the FIR phase
+  t.de_tout = std::min(4 * kDeBlock, ((kDeBlock * FMR_DE_LPL - FMR_DE_WARMUP - ars.NA - ars.D) / ars.D) & ~3);
+  t.de_fused = !serial_mode && t.de_tout >= 64;
+  t.dc_nc = (int)((N_au + C_DC - 1) / C_DC);
+  t.dk.b0 = dcblock.b0; t.dk.b1 = dcblock.b1; t.dk.b2 = dcblock.b2; t.dk.a1 = dcblock.a1; t.dk.a2 = dcblock.a2;
+  for (int j = 0; j < 4; j++) t.dk.ac[j] = dc_ac[j];
+  for (int lv = 0; lv < 6; lv++) for (int j = 0; j < 4; j++) t.dk.agp[lv][j] = dc_agp[lv][j];
+  const long long base_stride_ = base_stride;
   const long long am_stride = H_am + (long long)max_amid;
   const long long a1_stride = H_pc + (long long)max_au;
-  if ((size_t)count_am > max_amid || (size_t)N_au > max_au) { set_err("internal audio capacity exceeded"); return FMR_ERR_CAPACITY; }
-  const long long a_top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
-  // fused de-emphasis + stage A: the tile (warm-up + (TOUT-1) D + NA samples) must fit BLOCK * LPL LDS slots
-  constexpr int DE_BLOCK = 256, DE_SLOTS = DE_BLOCK * FMR_DE_LPL;
-  // at most 4 * DE_BLOCK outputs per tile: every lane then owns exactly one run of 4 outputs in the FIR phase
-  const int de_tout = std::min(4 * DE_BLOCK, ((DE_SLOTS - FMR_DE_WARMUP - ars.NA - ars.D) / ars.D) & ~3);
-  const bool de_fused = !serial_mode && de_tout >= 64;
-  const int dc_nc = (int)((N_au + C_DC - 1) / C_DC);
-  DcCoef dk{};
-  dk.b0 = dcblock.b0; dk.b1 = dcblock.b1; dk.b2 = dcblock.b2; dk.a1 = dcblock.a1; dk.a2 = dcblock.a2;
-  for (int j = 0; j < 4; j++) dk.ac[j] = dc_ac[j];
-  for (int lv = 0; lv < 6; lv++) for (int j = 0; j < 4; j++) dk.agp[lv][j] = dc_agp[lv][j];
-  // Per-channel part of the audio tail (de-emphasis + audio resampler + pilot cut + DC-block pass 1) for channels
-  // ch_base .. ch_base + nch_l - 1.  Channel 0 (mono = L+R) does not depend on the PLL: with stereo on it runs on
-  // the AGC stream while the PLL iterates, and only L-R stays behind the PLL on the decoder stream.
-  auto enqueue_tail_channels = [&](hipStream_t st, int ch_base, int nch_l) {
-    if (de_fused) {
-      if (count_am > 0) {
-        timed_on(st, "deemph_decim", [&] {
-          const int tiles = (count_am + de_tout - 1) / de_tout;
-          const size_t lds = sizeof(double) * (size_t)(DE_SLOTS + DE_SLOTS / 16 + 1);
-          auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(tiles, S, nch_l), dim3(DE_BLOCK), lds, st, k.base, k.raw, base_stride, H_b,
-                               (int)N_if, deemph.b0, deemph.a1, de_scan, 1, (int)(stereo && !pilot_shift), d_ahA.p,
-                               ars.NA, ars.D, a_top0, count_am, de_tout, d_am0.p, d_am1.p, am_stride, H_am,
-                               debug_taps ? d_base_de.p : (double *)nullptr,
-                               debug_taps ? d_raw_de.p : (double *)nullptr, de_stride, H_a, ch_base);
-          };
-          if (ars.NA == 59 && ars.D == 3) go(k_deemph_decim<DE_BLOCK, 59, 3>);     // 384 kHz -> 48 kHz
-          else go(k_deemph_decim<DE_BLOCK, 0, 0>);
-        });
-      }
-    } else {
-      // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
-      timed_on(st, "deemph", [&] {
-        const int nt = (int)((N_if + C_DE - 1) / C_DE);
-        hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch_l), dim3(64), 0, st, k.base, k.raw,
-                           base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
-                           (int)(stereo && !pilot_shift));
-      });
-      if (count_am > 0) {
-        timed_on(st, "aud_decim", [&] {
-          hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch_l), dim3(128), 0, st, d_base_de.p,
-                             d_raw_de.p, de_stride, H_a, d_ahA.p, ars.NA, ars.D, a_top0, count_am, d_am0.p, d_am1.p,
-                             am_stride, H_am);
-        });
-      }
-    }
-    if (N_au > 0) {
-      timed_on(st, "aud_poly", [&] {
-        if (ars.LB == 3 && ars.MB == 8) {
-          // period form: one lane per period (3 outputs), taps through the scalar cache
-          constexpr int BLP = 256;
-          const long long P_first = akB_prev / 3, P_last = (akB_prev + N_au - 1) / 3;
-          const int tiles = (int)((P_last - P_first) / BLP + 1);
-          const int lx = (BLP - 1) * (int)ars.MB + (int)((2 * ars.MB) / 3) + ars.TB;
-          int ni_pad = (lx + (int)ars.MB - 1) / (int)ars.MB + 1;
-          if ((ni_pad & 1) == 0) ni_pad++;
-          hipLaunchKernelGGL((k_aud_poly2<BLP, 3, 8>), dim3(tiles, S, nch_l), dim3(BLP), sizeof(double) * (size_t)ars.MB * ni_pad,
-                             st, d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB,
-                             akB_prev, (int)N_au, d_a10.p, d_a11.p, a1_stride, H_pc, ni_pad, H_am + count_am, ch_base);
-        } else {
-          hipLaunchKernelGGL(k_aud_poly<128>, dim3((unsigned)((N_au + 127) / 128), S, nch_l), dim3(128), 0, st,
-                             d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB, (unsigned)ars.LB,
-                             (unsigned)ars.MB, (unsigned long long)akB_prev * ars.MB, (int)N_au, d_a10.p, d_a11.p,
-                             a1_stride, H_pc);
-        }
-      });
-      timed_on(st, "pilotcut", [&] {
-        if (n_pilotcut <= FMR_PCUT_MAXTAPS)
-          hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, nch_l), dim3(320), 0, st, d_a10.p, d_a11.p,
-                             a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au, 1.0, ch_base);
-        else
-          hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch_l), dim3(128), 0, st, d_a10.p, d_a11.p, a1_stride, H_pc,
-                             bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
-      });
-    }
-    if (N_au > 0 && !serial_mode)
-      timed_on(st, "dc_pass1", [&] {
-        hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch_l), dim3(64), 0, st, d_pc0.p, d_pc1.p,
-                           (long long)max_au, (int)N_au, dk, d_dc_G.p, dc_nc, ch_base);
-      });
-  };
-  // In the pipelined chain both channels belong to the tail STAGE (its own stream, a call behind the PLL stage): the mono
-  // channel's buffers are still being read by the previous call's DC block and mux while this call's PLL iterates.
-  const bool split_mono = stereo && !serial_mode && !pipelined && de_fused && (ars.LB == 3 && ars.MB == 8) &&
+  // Channel 0 (mono = L+R) does not depend on the PLL: in the in-order chain with stereo on it runs on the AGC stream while
+  // the PLL iterates, and only L-R stays behind the PLL on the decoder stream.  In the pipelined chain both channels belong
+  // to the tail STAGE (its own stream, a call behind the PLL stage): the mono channel's buffers are still being read by the
+  // previous call's DC block and mux while this call's PLL iterates.
+  const bool split_mono = stereo && !serial_mode && !pipelined && t.de_fused && (ars.LB == 3 && ars.MB == 8) &&
                           n_pilotcut <= FMR_PCUT_MAXTAPS;
   bool mono_enqueued = false;
   if (stereo) {
-    if (int rcp = run_fm_pll(k, base_stride, split_mono, enqueue_tail_channels, mono_enqueued, fin_on_side, fin_covers_all)) return rcp;
+    auto tail_fn = [&](hipStream_t st, int ch_base, int nch_l) { tail_channels(t, st, ch_base, nch_l); };
+    if (int rcp = run_fm_pll(k, base_stride_, split_mono, tail_fn, mono_enqueued, fin_on_side, fin_covers_all)) return rcp;
   }
   if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr)) return rca; }   // PLL path not taken
-  hipStream_t ts = stream;
+  if (k.fe_post) { k.fe_post(); k.fe_post = nullptr; }
+  t.fin_on_side = fin_on_side; t.fin_covers_all = fin_covers_all; t.agc_on_side = agc_on_side; t.mono_enqueued = mono_enqueued;
+  t.raw_at_fin = k.pll_tail_on_side;
+  if (!pipelined) {
+    if (fir_enable) add_halo(ifbuf, if_stride, H_if, N_if);
+    add_halo(k.base, base_stride, H_b, N_if);
+    if (stereo) add_halo(k.raw, base_stride, H_b, N_if);
+  }       // (pipelined: the halos of the ring slots are carried over at the head of the next call, run_tables)
+  if (!t.de_fused || debug_taps) {     // (the fused de-emphasis keeps the 384 kHz signal in LDS: these are taps then)
+    add_halo(d_base_de.p, de_stride, H_a, N_if);
+    if (stereo) add_halo(d_raw_de.p, de_stride, H_a, N_if);
+  }
+  add_halo(d_am0.p, am_stride, H_am, t.count_am);
+  if (stereo) add_halo(d_am1.p, am_stride, H_am, t.count_am);
+  add_halo(d_a10.p, a1_stride, H_pc, N_au);
+  if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
+  if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
   if (pipelined) {
     // end of the PLL stage on the decoder stream: the next call's front end may be gated on it (FMR_FE_GATE), the tail
-    // of this call starts from it
+    // of this call starts from it.  The tail stage itself is enqueued behind the NEXT call's front end (or by whatever
+    // synchronises the chain first): it then runs beside that call's PLL stage and leaves the front end the whole chip.
     if (!stereo) HIPCHK(hipEventRecord(ev_pll, stream));
     ev_pll_live = true;
-    ts = tail;
-    HIPCHK(hipStreamWaitEvent(tail, ev_pll, 0));
+    t.ht = k.ht; k.ht.n = 0;
+    t.seq = pipe_seq;
+    tail_job = t;
+    tail_pending = true;
+    if (!env.tail_defer) return flush_tail(nullptr);
+    return FMR_OK;
   }
-  if (mono_enqueued) enqueue_tail_channels(ts, 1, 1);
-  else enqueue_tail_channels(ts, 0, nch);
-  if (mono_enqueued) HIPCHK(hipStreamWaitEvent(ts, ev_mono, 0));   // DC-block node pass needs both channels
+  return tail_stage(t, stream);
+}
+
+// Per-channel part of the audio tail (de-emphasis + audio resampler + pilot cut + DC-block pass 1) for channels
+// ch_base .. ch_base + nch_l - 1 on stream st.
+void fmr_chain::tail_channels(const TailCtx &t, hipStream_t st, int ch_base, int nch_l) {
+  const long long base_stride = H_b + (long long)max_if, de_stride = H_a + (long long)max_if;
+  const long long am_stride = H_am + (long long)max_amid, a1_stride = H_pc + (long long)max_au;
+  const int count_am = t.count_am, de_tout = t.de_tout, dc_nc = t.dc_nc;
+  const long long N_if = t.N_if, N_au = t.N_au, a_top0 = t.a_top0, amA_prev = t.amA_prev, akB_prev = t.akB_prev;
+  const BlockTab &bt = t.bt;
+  const int nb = t.nb;
+  constexpr int DE_BLOCK = kDeBlock, DE_SLOTS = DE_BLOCK * FMR_DE_LPL;
+  if (t.de_fused) {
+    if (count_am > 0) {
+      timed_on(st, "deemph_decim", [&] {
+        const int tiles = (count_am + de_tout - 1) / de_tout;
+        const size_t lds = sizeof(double) * (size_t)(DE_SLOTS + DE_SLOTS / 16 + 1);
+        auto go = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3(tiles, S, nch_l), dim3(DE_BLOCK), lds, st, t.base, t.raw, base_stride, H_b,
+                             (int)N_if, deemph.b0, deemph.a1, de_scan, 1, (int)(stereo && !pilot_shift), d_ahA.p,
+                             ars.NA, ars.D, a_top0, count_am, de_tout, d_am0.p, d_am1.p, am_stride, H_am,
+                             debug_taps ? d_base_de.p : (double *)nullptr,
+                             debug_taps ? d_raw_de.p : (double *)nullptr, de_stride, H_a, ch_base);
+        };
+        if (ars.NA == 59 && ars.D == 3) go(k_deemph_decim<DE_BLOCK, 59, 3>);     // 384 kHz -> 48 kHz
+        else go(k_deemph_decim<DE_BLOCK, 0, 0>);
+      });
+    }
+  } else {
+    // ---- de-emphasis by warm-up, out of place: base/raw -> base_de/raw_de
+    timed_on(st, "deemph", [&] {
+      const int nt = (int)((N_if + C_DE - 1) / C_DE);
+      hipLaunchKernelGGL(k_deemph_par<C_DE>, dim3((nt + 63) / 64, S, nch_l), dim3(64), 0, st, t.base, t.raw,
+                         base_stride, H_b, d_base_de.p, d_raw_de.p, de_stride, H_a, (int)N_if, deemph.b0, deemph.a1, 1,
+                         (int)(stereo && !pilot_shift));
+    });
+    if (count_am > 0) {
+      timed_on(st, "aud_decim", [&] {
+        hipLaunchKernelGGL(k_aud_decim<128>, dim3((count_am + 127) / 128, S, nch_l), dim3(128), 0, st, d_base_de.p,
+                           d_raw_de.p, de_stride, H_a, d_ahA.p, ars.NA, ars.D, a_top0, count_am, d_am0.p, d_am1.p,
+                           am_stride, H_am);
+      });
+    }
+  }
   if (N_au > 0) {
-    if (fin_on_side && serial_mode) HIPCHK(hipStreamWaitEvent(ts, ev_fin, 0));
+    timed_on(st, "aud_poly", [&] {
+      if (ars.LB == 3 && ars.MB == 8) {
+        // period form: one lane per period (3 outputs), taps through the scalar cache
+        constexpr int BLP = 256;
+        const long long P_first = akB_prev / 3, P_last = (akB_prev + N_au - 1) / 3;
+        const int tiles = (int)((P_last - P_first) / BLP + 1);
+        const int lx = (BLP - 1) * (int)ars.MB + (int)((2 * ars.MB) / 3) + ars.TB;
+        int ni_pad = (lx + (int)ars.MB - 1) / (int)ars.MB + 1;
+        if ((ni_pad & 1) == 0) ni_pad++;
+        hipLaunchKernelGGL((k_aud_poly2<BLP, 3, 8>), dim3(tiles, S, nch_l), dim3(BLP), sizeof(double) * (size_t)ars.MB * ni_pad,
+                           st, d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB,
+                           akB_prev, (int)N_au, d_a10.p, d_a11.p, a1_stride, H_pc, ni_pad, H_am + count_am, ch_base);
+      } else {
+        hipLaunchKernelGGL(k_aud_poly<128>, dim3((unsigned)((N_au + 127) / 128), S, nch_l), dim3(128), 0, st,
+                           d_am0.p, d_am1.p, am_stride, amA_prev - H_am, d_ahB.p, ars.TB, (unsigned)ars.LB,
+                           (unsigned)ars.MB, (unsigned long long)akB_prev * ars.MB, (int)N_au, d_a10.p, d_a11.p,
+                           a1_stride, H_pc);
+      }
+    });
+    timed_on(st, "pilotcut", [&] {
+      if (n_pilotcut <= FMR_PCUT_MAXTAPS)
+        hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, nch_l), dim3(320), 0, st, d_a10.p, d_a11.p,
+                           a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au, 1.0, ch_base);
+      else
+        hipLaunchKernelGGL(k_pilotcut<128>, dim3(nb, S, nch_l), dim3(128), 0, st, d_a10.p, d_a11.p, a1_stride, H_pc,
+                           bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au);
+    });
+  }
+  if (N_au > 0 && !serial_mode)
+    timed_on(st, "dc_pass1", [&] {
+      hipLaunchKernelGGL(k_dc_pass1<C_DC>, dim3((dc_nc + 63) / 64, S, nch_l), dim3(64), 0, st, d_pc0.p, d_pc1.p,
+                         (long long)max_au, (int)N_au, t.dk, d_dc_G.p, dc_nc, ch_base);
+    });
+}
+
+// The audio tail of one call on stream ts: the channels the PLL stage has not already run beside itself, the DC block's
+// node pass, the output mux, and the joins with what ran beside the decoder stream (statistics, AGC, lock logic).
+int fmr_chain::tail_stage(const TailCtx &t, hipStream_t ts) {
+  const int nch = t.nch, dc_nc = t.dc_nc;
+  const long long N_au = t.N_au;
+  if (t.mono_enqueued) tail_channels(t, ts, 1, 1);
+  else tail_channels(t, ts, 0, nch);
+  if (t.mono_enqueued) HIPCHK(hipStreamWaitEvent(ts, ev_mono, 0));   // DC-block node pass needs both channels
+  if (N_au > 0) {
+    if (t.fin_on_side && serial_mode) HIPCHK(hipStreamWaitEvent(ts, ev_fin, 0));
     if (serial_mode) {
-      timed("fm_out", [&] {
-        hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, stream, d_pc0.p, d_pc1.p, (long long)max_au, bt, (int)N_au,
+      timed_on(ts, "fm_out", [&] {
+        hipLaunchKernelGGL(k_fm_out, dim3(S), dim3(64), 0, ts, d_pc0.p, d_pc1.p, (long long)max_au, t.bt, (int)N_au,
                            dcblock.b0, dcblock.b1, dcblock.b2, dcblock.a1, dcblock.a2, (int)stereo, (int)pilot_shift,
-                           k.stereo_blk, d_aud, (long long)astride, d_state.p);
+                           t.stereo_blk, t.d_aud, t.astride, d_state.p);
       });
     } else {
       // ---- DC block by linear multiple shooting + output mux
       timed_on(ts, "fm_out", [&] {
         const int dc_nw = std::max(1, std::min(FMR_DC_MAXW, (dc_nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
-        hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, ts, d_dc_G.p, d_dc_start.p, dc_nc, dk,
+        hipLaunchKernelGGL(k_dc_nodes, dim3(S * nch), dim3(64 * dc_nw), 0, ts, d_dc_G.p, d_dc_start.p, dc_nc, t.dk,
                            d_state.p, S, nch);
-        if (fin_on_side) (void)hipStreamWaitEvent(ts, ev_fin, 0);   // only the mux needs the lock flags
+        if (t.fin_on_side) (void)hipStreamWaitEvent(ts, ev_fin, 0);   // only the mux needs the lock flags
         hipLaunchKernelGGL(k_dc_pass2_mux<C_DC>, dim3((dc_nc + 63) / 64, S), dim3(64), 0, ts, d_pc0.p, d_pc1.p,
-                           (long long)max_au, bt, (int)N_au, dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,
-                           k.stereo_blk, d_aud, (long long)astride, d_state.p);
+                           (long long)max_au, t.bt, (int)N_au, t.dk, d_dc_start.p, dc_nc, (int)stereo, (int)pilot_shift,
+                           t.stereo_blk, t.d_aud, t.astride, d_state.p);
       });
     }
   }
-  if (!pipelined) {      // (pipelined: the halos of the ring slots are carried over at the head of the next call, run_tables)
-    if (fir_enable) add_halo(ifbuf, if_stride, H_if, N_if);
-    add_halo(k.base, base_stride, H_b, N_if);
-    if (stereo) add_halo(k.raw, base_stride, H_b, N_if);
-  }
-  if (!de_fused || debug_taps) {     // (the fused de-emphasis keeps the 384 kHz signal in LDS: these are taps then)
-    add_halo(d_base_de.p, de_stride, H_a, N_if);
-    if (stereo) add_halo(d_raw_de.p, de_stride, H_a, N_if);
-  }
-  add_halo(d_am0.p, am_stride, H_am, count_am);
-  if (stereo) add_halo(d_am1.p, am_stride, H_am, count_am);
-  add_halo(d_a10.p, a1_stride, H_pc, N_au);
-  if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
-  if (!(fin_covers_all && N_au > 0)) {        // (otherwise the wait before the output mux covered all three)
+  if (!(t.fin_covers_all && N_au > 0)) {        // (otherwise the wait before the output mux covered all three)
     HIPCHK(hipStreamWaitEvent(ts, ev_stats, 0));
-    if (agc_on_side) HIPCHK(hipStreamWaitEvent(ts, ev_agc, 0));
-    if (fin_on_side) HIPCHK(hipStreamWaitEvent(ts, ev_fin, 0));
+    if (t.agc_on_side) HIPCHK(hipStreamWaitEvent(ts, ev_agc, 0));
+    if (t.fin_on_side) HIPCHK(hipStreamWaitEvent(ts, ev_fin, 0));
   }
-  if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
+  return FMR_OK;
+}
+
+// Pipelined chain: enqueue the tail stage of the last decoded call on the tail stream, behind `gate` (the front end of
+// the call that follows it; null: nothing to wait for but the call's own PLL stage).
+int fmr_chain::flush_tail(hipEvent_t gate) {
+  if (!tail_pending) return FMR_OK;
+  tail_pending = false;
+  const TailCtx &t = tail_job;
+  HIPCHK(hipStreamWaitEvent(tail, ev_pll, 0));
+  if (t.raw_at_fin) HIPCHK(hipStreamWaitEvent(tail, ev_fin, 0));
+  if (gate) HIPCHK(hipStreamWaitEvent(tail, gate, 0));
+  if (int rc = tail_stage(t, tail)) return rc;
+  if (t.ht.n) {
+    timed_on(tail, "shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(t.ht.n, S), dim3(256), 0, tail, t.ht); });
+  }
+  hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, tail, &h_marks[1], t.seq);
+  HIPCHK(hipEventRecord(ev_tail, tail));
+  ev_tail_live = true;
+  HIPCHK(hipGetLastError());
   return FMR_OK;
 }
 
@@ -2002,6 +2149,7 @@ int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, cons
   size_t total = 0;
   for (int b = 0; b < n_blocks; b++) { total += alen[b]; if (audio_len) audio_len[b] = alen[b]; }
   if (total > audio_stride && c->S > 1) { set_err("audio_stride too small"); return FMR_ERR_CAPACITY; }
+  if (int rcf = c->flush_tail(nullptr)) return rcf;      // (pipelined chain: this call's tail stage, now)
   if (total && audio) {
     if (total > audio_stride) { set_err("audio capacity too small"); return FMR_ERR_CAPACITY; }
     HIPCHK(hipMemcpy2DAsync(audio, sizeof(double) * audio_stride, c->d_audio.p, sizeof(double) * dstride,
@@ -2179,6 +2327,23 @@ int fmr_probe_read_bandwidth(int device, const void *d_buf, size_t bytes, int re
 }
 
 void fmr_enable_kernel_timing(fmr_chain *c, int enable) { if (c) c->timing = enable; }
+
+int fmr_get_kernel_trace(fmr_chain *c, const char **names, int *streams, float *start_ms, float *end_ms, int cap) {
+  if (!c) return FMR_ERR_BAD_ARG;
+  if (int rc = c->sync_all()) return rc;
+  int n = 0;
+  for (size_t i = 0; i < c->trace.size(); i++) {
+    float t0 = 0.f, t1 = 0.f;
+    (void)hipEventElapsedTime(&t0, c->trace_base, c->trace[i].a);
+    (void)hipEventElapsedTime(&t1, c->trace_base, c->trace[i].b);
+    if (n < cap) { names[n] = c->trace[i].name; streams[n] = c->trace_stream[i]; start_ms[n] = t0; end_ms[n] = t1; }
+    n++;
+    (void)hipEventDestroy(c->trace[i].a); (void)hipEventDestroy(c->trace[i].b);
+  }
+  c->trace.clear(); c->trace_stream.clear();
+  if (c->trace_base) { (void)hipEventDestroy(c->trace_base); c->trace_base = nullptr; }
+  return n;
+}
 
 int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap) {
   if (!c) return FMR_ERR_BAD_ARG;

@@ -1553,6 +1553,36 @@ __global__ void k_disc_commit(StreamState *st, int n_streams) {
   if (s < n_streams && st[s].disc_save_valid) { st[s].disc_save = st[s].disc_save_next; st[s].disc_save_valid = 0; }
 }
 
+// Pipelined chain, everything the front-end stage carries into its next call in ONE launch (a launch on the critical stream
+// costs a few microseconds whatever it does): blockIdx.x = 0 the input history (k_update_in_halo, cf32), 1 the stage-B
+// history (k_shift_halo of d_mid), 2 the discriminator's phase (k_disc_commit; commit = 0: the statistics kernel does it).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fe_post(float2 *__restrict__ in_halo, int H_in, const float2 *__restrict__ iq,
+                                                    long long iq_stride, long long N_in, float2 *__restrict__ mid,
+                                                    long long mid_stride, int H_mid, int N_mid, StreamState *st, int commit) {
+  const int s = blockIdx.y;
+  if (blockIdx.x == 2) {
+    if (commit && threadIdx.x == 0 && st[s].disc_save_valid) { st[s].disc_save = st[s].disc_save_next; st[s].disc_save_valid = 0; }
+    return;
+  }
+  float2 *h = blockIdx.x == 0 ? in_halo + (long long)s * H_in : mid + (long long)s * mid_stride;
+  const int H = blockIdx.x == 0 ? H_in : H_mid;
+  const long long N = blockIdx.x == 0 ? N_in : (long long)N_mid;
+  if (N <= 0) return;
+  const float2 *xs = iq + (long long)s * iq_stride;
+  for (int c = 0; c < H; c += BLOCK) {       // newhalo[i] = concat(halo, data)[i + N]
+    const int i = c + threadIdx.x;
+    float2 v = make_float2(0.f, 0.f);
+    if (i < H) {
+      const long long j = (long long)i + N;
+      v = (blockIdx.x == 1 || j < H) ? h[j] : xs[j - H];
+    }
+    __syncthreads();
+    if (i < H) h[i] = v;
+    __syncthreads();
+  }
+}
+
 // one wave per stream: 64 block results per load, the EMA chain runs on SGPR broadcasts.  part != nullptr: the block
 // values are summed here from the fused front end's pieces (index order: deterministic) instead of read from the
 // per-block arrays k_disc writes -- mean / rms of the discriminator output (Utility.h:135-152) and the IF RMS

@@ -1604,18 +1604,20 @@ __global__ __launch_bounds__(64) void k_pll_finish(
   const int s = blockIdx.x;
   const int lane = threadIdx.x;
   if (!fl[s].pll_converged || fl[s].pll_fallback) return;
-  constexpr int kFlagBuf = 4096;
+  // 8 KB of LDS in all: in the pipelined chain this kernel runs beside the next call's front end, whose workgroup leaves
+  // 11 KB of a CU's LDS free (with 32 KB it waited for the front end to end, and the next PLL pass behind it)
+  constexpr int kFlagBuf = 1024;
   __shared__ int sflag[kFlagBuf];
   StreamState &S = st[s];
   int lock_cnt = S.lock_cnt, pilot_periods = S.pilot_periods;
   unsigned long long pps_cnt = S.pps_cnt, sample_cnt = S.sample_cnt;
   int n_pps = 0;
   long long wr = 0, ns = 0;
-  // The per-block values come in through LDS, 1024 blocks per stage with all of a lane's loads in flight at once: the
+  // The per-block values come in through LDS, 256 blocks per stage with all of a lane's loads in flight at once: the
   // walk is a chain of cross-lane steps that takes well under a memory latency per batch of 64 blocks, so with the
   // loads inside it -- or one batch ahead of it, as in round 2 -- every batch waited for memory (0.12 / 0.09 ms for
   // 2048 blocks).
-  constexpr int kStage = 1024;
+  constexpr int kStage = 256;
   __shared__ int s_n[kStage], s_w[kStage];
   __shared__ double s_level[kStage];
   for (int b0 = 0; b0 < bt.nb; b0 += 64) {
