@@ -95,17 +95,8 @@ struct EnvKnobs {
   int pipeline = -1;            // FMR_PIPELINE=0/1   the three stages of a call (front end | PLL | audio tail) of consecutive calls
                                 //                    beside each other (1, the default for FM chains with the resampler) or one
                                 //                    in-order chain per call (0: the form the tests compare the product with)
-  int fe_cus = 0;               // FMR_FE_CUS=n       workgroups (= CUs) the persistent front-end kernel takes (0: all)
-  int fe_gate = 1;              // FMR_FE_GATE=0/1/2  what the front end of call N+1 waits for: nothing / the PLL of call N / the tail of call N
-  int prio = 1;                 // FMR_PRIO=0/1       stream priorities: decoder high, front end normal, audio tail low
-  int fe_mask = 0;              // FMR_FE_MASK=n      front-end stream restricted to n CUs (hipExtStreamCreateWithCUMask; 0: no mask)
-  int pll_iters = 0;            // FMR_PLL_ITERS=n    measurement only: PLL Newton rounds enqueued per call
-  int spare_aside = 0;          // FMR_SPARE_ASIDE=0/1 pipelined chain: the PLL's spare Newton rounds on the side stream (1) or the decoder stream (0)
-  int fe_stream = 1;            // FMR_FE_STREAM=0/1  pipelined chain: the front end on a stream of its own (0) or on the decoder stream (1)
-  int tail_defer = 1;           // FMR_TAIL_DEFER=0/1 pipelined chain: a call's tail stage is enqueued behind the next call's front end (1)
-                                //                    or at once, behind its own PLL stage (0)
-  int agc_stream = 0;           // FMR_AGC_STREAM=0/1/2 pipelined chain: the IF AGC on a stream of its own / on the side stream behind the
-                                //                    statistics / on the front-end stream behind the front end of its own call
+  int fe_cus = 0;               // FMR_FE_CUS=n       pipelined chain: workgroups (= CUs) the persistent front-end kernel takes
+                                //                    (0: all but one per XCD)
   bool debug_taps = false;      // FMR_DEBUG_TAPS=1   keep intermediate signals readable through fmr_debug_read
   bool host_prof = false;       // FMR_HOST_PROF=1    host enqueue time per call on stderr
   bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end (tests: fused vs three-kernel property test)
@@ -117,8 +108,7 @@ struct EnvKnobs {
   void load() {
     serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS");
     auto num = [](const char *n, int dflt) { const char *e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
-    pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0); fe_gate = num("FMR_FE_GATE", 1);
-    prio = num("FMR_PRIO", 1); fe_mask = num("FMR_FE_MASK", 0); agc_stream = num("FMR_AGC_STREAM", 0); tail_defer = num("FMR_TAIL_DEFER", 1); fe_stream = num("FMR_FE_STREAM", 1); spare_aside = num("FMR_SPARE_ASIDE", 0); pll_iters = num("FMR_PLL_ITERS", 0);
+    pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0);
     host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED"); pll_v1 = set("FMR_PLL_V1");
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
   }
@@ -134,6 +124,7 @@ struct fmr_chain {
   // side stream: per-block bookkeeping (statistics EMAs, PLL lock logic / PPS) runs beside the
   // audio chain instead of in front of it
   bool dec_valid = true;
+  bool gain_valid = true;               // the per-sample AGC gains of the last call are in d_gain (fmr_debug_read 4)
   bool debug_taps = false;               // FMR_DEBUG_TAPS=1: keep the de-emphasised 384 kHz signal readable (fmr_debug_read 2,3)
   DeScan de_scan{};
   DevBuf<double> d_de_pow;
@@ -155,7 +146,7 @@ struct fmr_chain {
   // of kPipe slots (IF samples, MPX, L-R, partial sums, per-block lock flags); a slot is refilled once the tail of the
   // call that used it kPipe calls ago has finished (h_marks[1], polled by the host).  Everything a stage carries from
   // call to call (halos, StreamState fields) is written by that stage only.
-  hipStream_t fe = nullptr, tail = nullptr;
+  hipStream_t tail = nullptr;
   bool pipelined = false;
   static constexpr int kPipe = 4;        // ring slots
   unsigned long long pipe_seq = 0;       // decoded calls issued (slot = pipe_seq % kPipe)
@@ -172,12 +163,10 @@ struct fmr_chain {
   int *stereo_slot(int q) { return q ? d_stereo_pp[q].p : d_stereo_blk.p; }
   float2 *last_if = nullptr;
   hipEvent_t ev_fe[kPipe] = {};
-  bool ev_pll_live = false, ev_tail_live = false;
   bool disc_commit_on_side = false;      // the last decoded call's discriminator phase is committed by its k_stats (side stream)
-  hipEvent_t ev_tail = nullptr;
   int sync_all() {                       // every stream of the chain is idle afterwards
     if (int rc = flush_tail(nullptr)) return rc;
-    for (hipStream_t st : {fe, stream, side, side2, tail})
+    for (hipStream_t st : {stream, side, side2, tail})
       if (st) HIPCHK(hipStreamSynchronize(st));
     return FMR_OK;
   }
@@ -287,7 +276,7 @@ struct fmr_chain {
     }
 #endif
     if (stream) (void)flush_tail(nullptr);
-    for (hipStream_t st : {fe, stream, side, side2, tail}) if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {stream, side, side2, tail}) if (st) (void)hipStreamSynchronize(st);
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     for (auto &k : dom_times) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     d_in.release(); d_in_halo.release(); d_mid.release(); d_if.release(); d_fir.release();
@@ -304,17 +293,14 @@ struct fmr_chain {
     if (h_tab_all) (void)hipHostFree(h_tab_all);
     if (h_marks) (void)hipHostFree(h_marks);
     for (hipEvent_t e : {ev_disc, ev_pll, ev_stats, ev_fin, ev_if}) if (e) (void)hipEventDestroy(e);
-    if (side2 == side || side2 == fe || side2 == tail) side2 = nullptr;      // (pipelined chain: the AGC may share a stream)
-    if (fe == stream) fe = nullptr;
+    if (side2 == side) side2 = nullptr;      // (pipelined chain: the AGC runs on the side stream)
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (host_prof && hp_calls)
       fprintf(stderr, "[fmr host prof] calls %lld  front-end %.1f us  tables %.1f us  decoder %.1f us per call\n", hp_calls,
               hp_fe / hp_calls, hp_tab / hp_calls, hp_dec / hp_calls);
     if (side2 && side2 != side) { (void)hipStreamSynchronize(side2); (void)hipStreamDestroy(side2); }
-    if (fe) (void)hipStreamDestroy(fe);
     if (tail) (void)hipStreamDestroy(tail);
     for (auto &e : ev_fe) if (e) (void)hipEventDestroy(e);
-    if (ev_tail) (void)hipEventDestroy(ev_tail);
     for (auto &b : d_if_pp) b.release();
     for (auto &b : d_base_pp) b.release();
     for (auto &b : d_raw_pp) b.release();
@@ -353,7 +339,7 @@ struct fmr_chain {
       launch();
       (void)hipEventRecord(kt.b, st);
       trace.push_back(kt);
-      trace_stream.push_back(st == stream ? 0 : st == side ? 1 : st == fe ? 3 : st == side2 ? 2 : 4);
+      trace_stream.push_back(st == stream ? 0 : st == side ? 1 : st == side2 ? 2 : 4);
       return;
     }
     if (timing != 1) { launch(); return; }
@@ -430,7 +416,7 @@ struct fmr_chain {
     bool agc_deferred{};
     std::function<int(hipEvent_t)> enqueue_agc{};
     bool done = false;                 // the front end found nothing to decode
-    bool pll_tail_on_side = false;     // the PLL's spare rounds ran on the side stream: L-R is final at ev_fin, not at ev_pll
+    hipEvent_t ev_mpx = nullptr;       // recorded where this call's MPX (discriminator output) is complete
     std::function<void()> fe_post{};   // pipelined chain: the front-end stage's end-of-call kernel, when it is still to be launched
     long long count_mid_call{};        // stage-A outputs of this call
     // this call's slot of the rings the stages hand each other (plain chain: the one buffer of each kind)
@@ -447,7 +433,7 @@ struct fmr_chain {
     int *stereo_blk = nullptr;
     long long N_if{}, N_au{}, a_top0{}, amA_prev{}, akB_prev{}, astride{};
     int nb{}, count_am{}, de_tout{}, dc_nc{}, nch{};
-    bool de_fused{}, fin_on_side{}, fin_covers_all{}, agc_on_side{}, mono_enqueued{}, raw_at_fin{};
+    bool de_fused{}, fin_on_side{}, fin_covers_all{}, agc_on_side{}, mono_enqueued{};
     BlockTab bt{};
     double *d_aud = nullptr;
     DcCoef dk{};
@@ -498,55 +484,24 @@ int fmr_chain::init(const fmr_config *c) {
   if (c->device < 0 || c->device >= ndev) { set_err("device %d out of range (%d devices)", c->device, ndev); return FMR_ERR_BAD_ARG; }
   HIPCHK(hipSetDevice(c->device));
   // The stages of consecutive calls run beside each other for FM chains with the resampler (the default; FMR_PIPELINE=0:
-  // one in-order chain per call).  Streams:
+  // one in-order chain per call).  THREE streams ("Three stages in flight"):
   //   stream  the critical chain: front end of call N, PLL of call N, front end of call N+1 ... -- both hold the whole chip
   //           (152 KB of LDS per CU; 1258 one-wave workgroups), so they alternate anyway, and on ONE queue the hand-off
   //           between them is a packet boundary, not an event travelling between two queues (~50 us each way, measured)
-  //   side    tables, statistics, lock logic          side2  the IF AGC          tail  the audio tail, a call behind
-  // Four streams, four hardware queues: a GPU pipe serves one queue at a time and HIP hands a process four; a fifth busy
-  // stream shares a queue (or, with more queues allowed, a pipe) with another and the two take turns (measured: slower
-  // than the in-order chain).  With priorities on, the decoder's streams are high, the AGC normal, the tail low -- streams
-  // of different priorities also draw from different queue pools, so a host that owns a stream of its own (torch's) does
-  // not push two of ours onto one queue.
+  //   side    tables, statistics, the IF AGC, lock logic
+  //   tail    the audio tail, a call behind
+  // Three, because a process gets four hardware queues from HIP, the host application's own stream included, and more
+  // busy queues than that take turns on a pipe in slices of 3.55 ms (measured with four and five busy queues, with and
+  // without stream priorities: one process in two then runs at 4-36 ms per step).
   pipelined = mode == FMR_MODE_FM && c->enable_resampler != 0 && !env.serial && env.pipeline != 0;
-  {
-    int pr_low = 0, pr_high = 0;
-    (void)hipDeviceGetStreamPriorityRange(&pr_low, &pr_high);
-    const bool use_prio = pipelined && env.prio && pr_low != pr_high;
-    auto mk = [&](hipStream_t *st, int level) -> hipError_t {     // level: +1 high, 0 normal, -1 low
-      if (!use_prio) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-      const int pr = level > 0 ? pr_high : level < 0 ? pr_low : (pr_low + pr_high) / 2;
-      return hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr);
-    };
-    HIPCHK(mk(&stream, 1));
-    HIPCHK(mk(&side, 1));
-    if (pipelined) {
-      if (env.fe_stream == 0) {           // (measurement: the front end on a stream of its own)
-        if (env.fe_mask > 0) {
-          // bit i of the mask is CU (i / 8) of XCD (i % 8) on this part: the first n bits spread over the eight XCDs
-          uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          for (int i = 0; i < env.fe_mask && i < 256; i++) mask[i / 32] |= 1u << (i % 32);
-          HIPCHK(hipExtStreamCreateWithCUMask(&fe, 8, mask));
-        } else {
-          HIPCHK(mk(&fe, 0));
-        }
-      } else {
-        fe = stream;
-      }
-      HIPCHK(mk(&tail, -1));
-      // the AGC needs this call's IF samples and nothing else: its own stream (0), the side stream behind the statistics
-      // (1), behind its own call's front end on a separate front-end stream (2), or the tail stream in front of its own
-      // call's tail (3)
-      const int as = (env.agc_stream == 2 && fe == stream) ? 0 : env.agc_stream;
-      if (as == 1) side2 = side;
-      else if (as == 2) side2 = fe;
-      else if (as == 3) side2 = tail;
-      else HIPCHK(mk(&side2, 0));
-      HIPCHK(hipEventCreateWithFlags(&ev_tail, hipEventDisableTiming));
-      for (int q = 0; q < kPipe; q++) HIPCHK(hipEventCreateWithFlags(&ev_fe[q], hipEventDisableTiming));
-    } else {
-      HIPCHK(mk(&side2, 1));
-    }
+  HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  if (pipelined) {
+    side2 = side;
+    HIPCHK(hipStreamCreateWithFlags(&tail, hipStreamNonBlocking));
+    for (int q = 0; q < kPipe; q++) HIPCHK(hipEventCreateWithFlags(&ev_fe[q], hipEventDisableTiming));
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
   }
   HIPCHK(hipEventCreateWithFlags(&ev_agc, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ev_tab, hipEventDisableTiming));
@@ -732,7 +687,11 @@ int fmr_chain::init(const fmr_config *c) {
   max_ck = max_if / C_PLL_MIN + (size_t)max_blocks + 2;
   tab_ints = 5 * (size_t)max_blocks + 3 * max_ck + (size_t)max_blocks + 1 + kMaxFusedWg;   // tail: first block of each fused workgroup
   HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * tab_ints));
-  HIPCHK(hipHostMalloc((void **)&h_marks, 2 * sizeof(unsigned long long)));
+  // The marks are written by one-thread kernels and polled by the host while more work is queued behind them: COHERENT
+  // (fine-grained) host memory, so that the store leaves the GPU when it is made.  With the default flags the line may sit
+  // in the GPU's L2 until some later system-scope release writes it back, and a host that waits for a mark sees it
+  // milliseconds late (measured: one process in two ran at 4-36 ms per step, in multiples of 3.55 ms).
+  HIPCHK(hipHostMalloc((void **)&h_marks, 2 * sizeof(unsigned long long), hipHostMallocCoherent));
   h_marks[0] = h_marks[1] = 0;
   if ((rc = d_tab.alloc((size_t)kTabSlots * tab_ints))) return rc;
   h_flags.assign(S, IterFlags{});
@@ -1055,7 +1014,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
   use_fused = false;
   k.fused_disc = false;
   fused_geom = FusedGeom{};
-  hipStream_t fes = pipelined ? fe : stream;
+  hipStream_t fes = stream;      // (pipelined chain too: the front end alternates with the PLL stage on the decoder stream)
   par = 0;
   if (has_rs) {
     const long long mA_prev = rsc.mA, kB_prev = rsc.kB, n_prev = rsc.n_in;
@@ -1077,9 +1036,6 @@ int fmr_chain::run_front_end(CallCtx &k) {
       // (one slot less than the ring holds: the slot of call N is still read at the head of call N+1, by the kernel that
       // carries its halos over, and that kernel is only ordered before the tail of call N+1)
       if (int rcw = wait_mark(&h_marks[1], pipe_seq > (unsigned long long)(kPipe - 1) ? pipe_seq - (kPipe - 1) : 0)) return rcw;
-      // where in the previous call's chain this front end may start (FMR_FE_GATE; scheduling only, no data dependence)
-      if (fe != stream && env.fe_gate == 1 && ev_pll_live) HIPCHK(hipStreamWaitEvent(fe, ev_pll, 0));
-      if (env.fe_gate == 2 && ev_tail_live) HIPCHK(hipStreamWaitEvent(fe, ev_tail, 0));
     }
     ifbuf = if_slot(par);
     last_if = ifbuf;
@@ -1248,11 +1204,10 @@ int fmr_chain::finish_front_end_stage(CallCtx &k) {
     HaloTable hm{};
     hm.d[0] = HaloDesc{(unsigned long long *)d_mid.p, H_mid + (long long)max_mid, H_mid, (int)k.count_mid_call};
     hm.n = 1;
-    hipLaunchKernelGGL(k_shift_halo<256>, dim3(1, S), dim3(256), 0, fe, hm);
+    hipLaunchKernelGGL(k_shift_halo<256>, dim3(1, S), dim3(256), 0, stream, hm);
   }
   if (has_dec && k.N_if > 0) {
-    HIPCHK(hipEventRecord(ev_fe[k.par], fe));
-    if (fe != stream) HIPCHK(hipStreamWaitEvent(stream, ev_fe[k.par], 0));
+    HIPCHK(hipEventRecord(ev_fe[k.par], stream));
     // the previous call's tail stage: behind this front end, beside this call's PLL stage
     if (int rc = flush_tail(ev_fe[k.par])) return rc;
   }
@@ -1335,12 +1290,13 @@ int fmr_chain::run_tables(CallCtx &k) {
     // the kernel's own tables: first block of every workgroup and, when the front end runs a call ahead of the decoder,
     // the block table too (the side stream's copy of it sits behind the previous call's lock logic; both copies write
     // the same values)
-    hipStream_t ts = pipelined ? fe : side;
-    hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((fused_grid + 255) / 256)), dim3(256), 0, ts,
-                       (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), fused_grid);
     if (pipelined)
-      hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((2 * (size_t)max_blocks + 255) / 256)), dim3(256), 0, fe,
-                         (const int *)h_tab, d_tab_slot, 2 * max_blocks);
+      hipLaunchKernelGGL(k_copy_ints2, dim3((unsigned)((fused_grid + 2 * (size_t)max_blocks + 255) / 256)), dim3(256), 0, stream,
+                         (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), fused_grid, (const int *)h_tab, d_tab_slot,
+                         2 * max_blocks);
+    else
+      hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((fused_grid + 255) / 256)), dim3(256), 0, side,
+                         (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), fused_grid);
   }
   int *d_first = d_tab_slot + 5 * (size_t)max_blocks;
   int *d_ck = d_tab_slot + head_ints;
@@ -1425,10 +1381,10 @@ int fmr_chain::run_tables(CallCtx &k) {
     }
     if ((size_t)a.n_tiles * 3 * S > d_fused_part.n) { set_err("internal capacity exceeded (fused tiles)"); return FMR_ERR_CAPACITY; }
     constexpr size_t kLds = FusedShape<D, NA>::LDS_BYTES;
-    hipStream_t fes = pipelined ? fe : stream;
+    hipStream_t fes = stream;
     // the discriminator's carried phase: when the previous call ran the discriminator in its decoder stage (a call too
     // short for the fused kernel), its phase is committed by that call's statistics kernel on the side stream
-    if (pipelined && k.fused_disc && disc_commit_on_side) HIPCHK(hipStreamWaitEvent(fe, ev_stats, 0));
+    if (pipelined && k.fused_disc && disc_commit_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
     timed_on(fes, "ifr_fused", [&] {
       if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, a);
       else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, a);
@@ -1438,14 +1394,12 @@ int fmr_chain::run_tables(CallCtx &k) {
       // The PLL stage starts from here.  What the front-end stage carries into its next call -- the input history, the
       // stage-B history, the discriminator's last phase -- is one small kernel on its stream; when that stream is the
       // decoder's it is launched behind the PLL's first pass (run_fm_pll), not between the front end and that pass.
-      HIPCHK(hipEventRecord(ev_fe[k.par], fe));
-      if (fe != stream) HIPCHK(hipStreamWaitEvent(stream, ev_fe[k.par], 0));
+      HIPCHK(hipEventRecord(ev_fe[k.par], stream));
       const int commit = (int)k.fused_disc, count_mid = fused_geom.count_mid;
       k.fe_post = [=] {
-        hipLaunchKernelGGL(k_fe_post<256>, dim3(3, S), dim3(256), 0, fe, d_in_halo.p, H_in, d_iq, (long long)stride, N_in,
+        hipLaunchKernelGGL(k_fe_post<256>, dim3(3, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq, (long long)stride, N_in,
                            d_mid.p, (long long)(H_mid + max_mid), H_mid, count_mid, d_state.p, commit);
       };
-      if (fe != stream) { k.fe_post(); k.fe_post = nullptr; }
       // the previous call's tail stage: behind this front end, beside this call's PLL stage
       if (int rc = flush_tail(ev_fe[k.par])) return rc;
     }
@@ -1546,21 +1500,25 @@ int fmr_chain::run_if_stage(CallCtx &k) {
       }
     }
     const int agc_nw = std::max(1, std::min(16, (agc_nc + 64 * FMR_AGC_PER_LANE - 1) / (64 * FMR_AGC_PER_LANE)));
+    // FM without the equaliser: the discriminator does not see the gains (atan2 is invariant to them) -- the recurrence is
+    // solved for its state only, and its 4 bytes per IF sample stay out of HBM unless the debug tap asks for them
+    float *const gain_out = (agc_aside && !debug_taps) ? (float *)nullptr : d_gain.p;
     timed_on(as, "if_agc", [&] {
       for (int it = 0; it < agc_iters; it++) {
         hipLaunchKernelGGL(k_agc_shoot<C_AGC>, dim3((agc_nc + 63) / 64, S), dim3(64), 0, as, xin, x_stride, x_off,
-                           (int)N_if, d_gain.p, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
+                           (int)N_if, gain_out, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            agc_init, agc_max, agc_rate, d_flags.p);
         hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64 * agc_nw), 0, as, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
-                           d_state.p, d_flags.p, (int)(mode == FMR_MODE_FM || mode == FMR_MODE_NBFM));
+                           d_state.p, d_flags.p, (mode == FMR_MODE_FM || mode == FMR_MODE_NBFM) ? (gain_out ? 1 : 2) : 0);
       }
       hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,
-                         d_gain.p, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
+                         gain_out, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
     });
     if (agc_aside) { HIPCHK(hipEventRecord(ev_agc, side2)); ev_agc_live = true; }
     return FMR_OK;
     };
     if (agc_aside) { disc_gain = nullptr; agc_on_side = true; }
+    gain_valid = !(agc_aside && !debug_taps);
     if (!agc_deferred) { if (int rca = enqueue_agc(nullptr)) return rca; }
   }
   return FMR_OK;
@@ -1580,27 +1538,24 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
   } else {
     // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
     int rc_agc = FMR_OK;          // a failure inside the lambda must leave run_fm_pll, not only the lambda
+    // (trace mode: every kernel of the group carries its own event pair)
+    auto sub = [&](hipStream_t st, const char *name, auto &&launch) { if (timing == 3) timed_on(st, name, launch); else launch(); };
     timed("pll", [&] {
       const int ngrp = (nck + FMR_NODE_GRP - 1) / FMR_NODE_GRP;
       const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
-      int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
-      if (env.pll_iters > 0) pll_iters = env.pll_iters;                   // (measurement only)
-      // Pipelined chain: a call in lock accepts its second pass, and the kernels of the spare rounds -- they find the
-      // converged flag set and return, seven dependent launches all the same -- move off the critical stream: from the
-      // second node pass on the rounds run on the side stream, in front of the lock logic that waits for them anyway,
-      // while the decoder stream goes on with the next call's front end.  (A call that does need its third pass then
-      // integrates it beside that front end, on the CUs it leaves free: slower, and correct.)
-      const bool spare_aside = pipelined && !env.pll_v1 && env.spare_aside && pll_iters > 2;
+      const int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
       hipStream_t ps = stream;
       for (int it = 0; it < pll_iters; it++) {
         // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
         // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
         PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
         auto shoot = [&](auto kern) {
+          sub(ps, it == 0 ? "pll_shoot_jac" : "pll_shoot", [&] {
           hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, ps, k.base, base_stride, H_b, ct,
                              k.raw, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
                              d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
                              pll_rtol, (int)(it > 0));
+          });
         };
         // the first round writes no L-R samples unless it can be the accepted one (a call of one or two chunks)
         const bool wout = it > 0 || env.pll_v1 || nck <= 2;
@@ -1612,7 +1567,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
           // front end's (ev_disc) -- because a marker of its own on this stream costs ~10 us between the first pass
           // and the node pass.
           agc_deferred = false;
-          hipEvent_t gate = ev_disc;
+          hipEvent_t gate = k.ev_mpx;
           if (!gate) { (void)hipEventRecord(ev_if, stream); gate = ev_if; }
           auto mono_aside = [&] {
             (void)hipStreamWaitEvent(side2, gate, 0);
@@ -1627,18 +1582,17 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
           hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
                              (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
         if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
-        if (spare_aside && it == 1) {
-          (void)hipEventRecord(ev_pll, stream);
-          (void)hipStreamWaitEvent(side, ev_pll, 0);
-          ps = side;
-        }
         if (!env.pll_v1) {
+          sub(ps, "pll_up", [&] {
           hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, ps, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
                              d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p, d_flags.p, d_pll_sync.p,
                              d_pll_tick2.p);
+          });
+          sub(ps, "pll_down", [&] {
           hipLaunchKernelGGL(k_pll_down, dim3(ngrp, S), dim3(64), 0, ps, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
                              d_pll_pre.p, d_pll_dstart2.p, ngrp2, d_flags.p, pllc.minfreq, pllc.maxfreq,
                              d_pll_sync.p);
+          });
           continue;
         }
         hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
@@ -1655,15 +1609,12 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
       hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, ps, k.base, base_stride, H_b, bt,
                          k.raw, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, k.stereo_blk, d_state.p,
                          S, d_flags.p);
-      k.pll_tail_on_side = (ps == side);
     });
     if (rc_agc) return rc_agc;
     HIPCHK(hipGetLastError());    // a launch of the rounds above that could not be enqueued
     // lock logic / PPS / state commit beside the audio chain (needed again only by fm_out)
-    if (!k.pll_tail_on_side) {
-      HIPCHK(hipEventRecord(ev_pll, stream));
-      HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
-    }
+    HIPCHK(hipEventRecord(ev_pll, stream));
+    HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
     timed_on(side, "pll_finish", [&] {
       hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, side, bt, ct, d_pll_G.p,
                          d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
@@ -1723,14 +1674,17 @@ int fmr_chain::run_fm(CallCtx &k) {
                        disc_nf, disc_bound, d_dec.p, (long long)max_if, k.base, base_stride, H_b,
                        d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p, rms_in_disc ? d_if_rms_blk.p : (float *)nullptr);
   });
-  HIPCHK(hipEventRecord(ev_disc, stream));
-  HIPCHK(hipStreamWaitEvent(side, ev_disc, 0));
+  // "the MPX is there": what the side streams start from.  Behind the fused front end on the decoder's own stream that is
+  // the event recorded behind it already (a second marker on the critical stream costs what a small kernel costs).
+  k.ev_mpx = (pipelined && k.fused_disc) ? ev_fe[k.par] : ev_disc;
+  if (k.ev_mpx == ev_disc) HIPCHK(hipEventRecord(ev_disc, stream));
+  HIPCHK(hipStreamWaitEvent(side, k.ev_mpx, 0));
   if (use_fused && !pipelined)      // input history for the next call's front end: off the critical path (the next
     timed_on(side, "in_halo", [&] {   // front end waits for this stream's table kernels anyway)
       hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, side, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
     });
   timed_on(side, "stats", [&] {     // (fused front end: the block values are summed from its partial sums on the fly)
-    hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+    hipLaunchKernelGGL(k_stats, dim3(S), dim3(FMR_STATS_THREADS), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
                        d_bb_rms_blk.p, d_state.p, S, (int)!(pipelined && k.fused_disc),   // (the front-end stage commits its own phase)
                        k.fused_disc ? k.part : (const FusedPart *)nullptr, fused_n_tiles, fused_kb_ref);
   });
@@ -1770,7 +1724,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr)) return rca; }   // PLL path not taken
   if (k.fe_post) { k.fe_post(); k.fe_post = nullptr; }
   t.fin_on_side = fin_on_side; t.fin_covers_all = fin_covers_all; t.agc_on_side = agc_on_side; t.mono_enqueued = mono_enqueued;
-  t.raw_at_fin = k.pll_tail_on_side;
+
   if (!pipelined) {
     if (fir_enable) add_halo(ifbuf, if_stride, H_if, N_if);
     add_halo(k.base, base_stride, H_b, N_if);
@@ -1790,12 +1744,10 @@ int fmr_chain::run_fm(CallCtx &k) {
     // of this call starts from it.  The tail stage itself is enqueued behind the NEXT call's front end (or by whatever
     // synchronises the chain first): it then runs beside that call's PLL stage and leaves the front end the whole chip.
     if (!stereo) HIPCHK(hipEventRecord(ev_pll, stream));
-    ev_pll_live = true;
     t.ht = k.ht; k.ht.n = 0;
     t.seq = pipe_seq;
     tail_job = t;
     tail_pending = true;
-    if (!env.tail_defer) return flush_tail(nullptr);
     return FMR_OK;
   }
   return tail_stage(t, stream);
@@ -1923,15 +1875,12 @@ int fmr_chain::flush_tail(hipEvent_t gate) {
   tail_pending = false;
   const TailCtx &t = tail_job;
   HIPCHK(hipStreamWaitEvent(tail, ev_pll, 0));
-  if (t.raw_at_fin) HIPCHK(hipStreamWaitEvent(tail, ev_fin, 0));
   if (gate) HIPCHK(hipStreamWaitEvent(tail, gate, 0));
   if (int rc = tail_stage(t, tail)) return rc;
   if (t.ht.n) {
     timed_on(tail, "shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(t.ht.n, S), dim3(256), 0, tail, t.ht); });
   }
   hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, tail, &h_marks[1], t.seq);
-  HIPCHK(hipEventRecord(ev_tail, tail));
-  ev_tail_live = true;
   HIPCHK(hipGetLastError());
   return FMR_OK;
 }
@@ -1952,7 +1901,7 @@ int fmr_chain::run_nbfm(CallCtx &k) {
                        d_state.p, (float *)nullptr);
   });
   timed("stats", [&] {
-    hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+    hipLaunchKernelGGL(k_stats, dim3(S), dim3(FMR_STATS_THREADS), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
                        d_bb_rms_blk.p, d_state.p, S, 1);
   });
   timed("nbfm_audio", [&] {
@@ -1978,7 +1927,7 @@ int fmr_chain::run_am(CallCtx &k) {
                        (long long)max_if, d_bb_mean_blk.p, d_bb_rms_blk.p);
   });
   timed("stats", [&] {
-    hipLaunchKernelGGL(k_stats, dim3(S), dim3(64), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+    hipLaunchKernelGGL(k_stats, dim3(S), dim3(FMR_STATS_THREADS), 0, stream, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
                        d_bb_rms_blk.p, d_state.p, S, 0);
   });
   timed("am_tail", [&] {
@@ -2141,7 +2090,7 @@ int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, cons
   HIPCHK(hipSetDevice(c->cfg.device));
   if (N_in)
     HIPCHK(hipMemcpy2DAsync(c->d_in.p, (size_t)c->in_bps * c->max_in, iq, (size_t)c->in_bps * stream_stride,
-                            (size_t)c->in_bps * N_in, c->S, hipMemcpyHostToDevice, c->pipelined ? c->fe : c->stream));
+                            (size_t)c->in_bps * N_in, c->S, hipMemcpyHostToDevice, c->stream));
   const size_t dstride = c->stereo ? 2 * c->max_au : c->max_au;
   std::vector<uint32_t> alen(n_blocks, 0);
   const int rc = c->run_cold_aware(c->d_in.p, c->max_in, block_len, n_blocks, c->d_audio.p, dstride, alen.data());
@@ -2276,7 +2225,7 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
   case 1: src = (c->d_dec.p && c->dec_valid) ? c->d_dec.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
   case 2: src = c->d_raw_de.p ? c->d_raw_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 3: src = c->d_base_de.p ? c->d_base_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
-  case 4: src = c->d_gain.p ? c->d_gain.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
+  case 4: src = (c->d_gain.p && c->gain_valid) ? c->d_gain.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
   default: return FMR_ERR_BAD_ARG;
   }
   if (!src) return FMR_ERR_BAD_ARG;

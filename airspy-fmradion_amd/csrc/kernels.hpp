@@ -1587,13 +1587,21 @@ __global__ __launch_bounds__(BLOCK) void k_fe_post(float2 *__restrict__ in_halo,
 // values are summed here from the fused front end's pieces (index order: deterministic) instead of read from the
 // per-block arrays k_disc writes -- mean / rms of the discriminator output (Utility.h:135-152) and the IF RMS
 // (Utility.h:118-132, FmDecode.cpp:95).
-__global__ __launch_bounds__(64) void k_stats(BlockTab bt, const float *__restrict__ if_rms_blk,
+#define FMR_STATS_THREADS 512
+__global__ __launch_bounds__(FMR_STATS_THREADS) void k_stats(BlockTab bt, const float *__restrict__ if_rms_blk,
                                               const float *__restrict__ bb_mean_blk,
                                               const float *__restrict__ bb_rms_blk, StreamState *st, int n_streams,
                                               int has_disc, const FusedPart *__restrict__ part = nullptr, int n_tiles = 0,
                                               int kb_ref = 0) {
+  // One workgroup per stream.  Phase 1, all waves: a lane per block fetches (or, behind the fused front end, sums from the
+  // partial sums, index order: deterministic) the block's three values -- every load of up to 512 blocks in flight at
+  // once; with one wave doing 64 blocks at a time this was 0.15-0.2 ms of memory latency.  Phase 2, wave 0: the EMA
+  // chain over the blocks in order, from LDS (8 KB: the kernel fits beside the front end's workgroup).
+  constexpr int NT = FMR_STATS_THREADS;
+  __shared__ float s_r[NT], s_m[NT], s_l[NT];
+  __shared__ int s_n[NT];
   const int s = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   if (s >= n_streams) return;
   float m = st[s].baseband_mean, l = st[s].baseband_level, r = st[s].if_rms;
   // The EMAs forget: 0.95^400 = 1.2e-9 is below half a float ulp of the result, so only the last ~400 non-empty blocks
@@ -1607,10 +1615,10 @@ __global__ __launch_bounds__(64) void k_stats(BlockTab bt, const float *__restri
       if (seen >= 400) { b_first = b0; break; }
     }
   }
-  for (int b0 = b_first; b0 < bt.nb; b0 += 64) {
-    const int b = min(b0 + lane, bt.nb - 1);
-    const int my_n = bt.if_len[b];
-    float my_r, my_m, my_l;
+  for (int b0 = b_first; b0 < bt.nb; b0 += NT) {
+    const int b = min(b0 + (int)threadIdx.x, bt.nb - 1);
+    const int my_n = (b0 + (int)threadIdx.x < bt.nb) ? bt.if_len[b] : 0;
+    float my_r = 0.f, my_m = 0.f, my_l = 0.f;
     if (part) {
       float sd = 0.f, sq = 0.f, se = 0.f;
       if (my_n) {
@@ -1625,20 +1633,30 @@ __global__ __launch_bounds__(64) void k_stats(BlockTab bt, const float *__restri
       }
       const float fn = (float)(unsigned)(my_n ? my_n : 1);
       my_m = sd / fn; my_l = sqrtf(sq / fn); my_r = sqrtf(se / fn);
-    } else {
+    } else if (my_n) {
       my_r = if_rms_blk[(long long)s * bt.nb + b];
       my_m = bb_mean_blk[(long long)s * bt.nb + b];
       my_l = bb_rms_blk[(long long)s * bt.nb + b];
     }
-    const int cnt = min(64, bt.nb - b0);
-    for (int j = 0; j < cnt; j++) {
-      if (__builtin_amdgcn_readlane(my_n, j) == 0) continue;
-      r = readlane_f(my_r, j);
-      m = (float)(0.95 * (double)m + 0.05 * (double)readlane_f(my_m, j));
-      l = (float)(0.95 * (double)l + 0.05 * (double)readlane_f(my_l, j));
+    __syncthreads();                     // (the previous stage's chain has read its values)
+    s_n[threadIdx.x] = my_n; s_r[threadIdx.x] = my_r; s_m[threadIdx.x] = my_m; s_l[threadIdx.x] = my_l;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int cnt = min(NT, bt.nb - b0);
+      for (int j0 = 0; j0 < cnt; j0 += 64) {
+        const int vn = s_n[j0 + lane];
+        const float vr = s_r[j0 + lane], vm = s_m[j0 + lane], vl = s_l[j0 + lane];
+        const int c2 = min(64, cnt - j0);
+        for (int j = 0; j < c2; j++) {
+          if (__builtin_amdgcn_readlane(vn, j) == 0) continue;
+          r = readlane_f(vr, j);
+          m = (float)(0.95 * (double)m + 0.05 * (double)readlane_f(vm, j));
+          l = (float)(0.95 * (double)l + 0.05 * (double)readlane_f(vl, j));
+        }
+      }
     }
   }
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     st[s].baseband_mean = m; st[s].baseband_level = l; st[s].if_rms = r;
     if (has_disc && st[s].disc_save_valid) { st[s].disc_save = st[s].disc_save_next; st[s].disc_save_valid = 0; }
   }

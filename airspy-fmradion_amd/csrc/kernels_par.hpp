@@ -394,13 +394,13 @@ __global__ void k_agc_shoot(const float2 *__restrict__ x, long long x_stride, in
   const int s = blockIdx.y;
   if (c >= nc || fl[s].agc_converged) return;
   const float2 *xs = x + (long long)s * x_stride + x_off;
-  float *gs = gain + (long long)s * g_stride;
-  const int i0 = c * C, i1 = min(i0 + C, n);
+  float *gs = gain ? gain + (long long)s * g_stride : nullptr;   // null: nobody reads the per-sample gains (FM without the
+  const int i0 = c * C, i1 = min(i0 + C, n);                      // equaliser: atan2 does not see them) -- only the state carries
   float g = nodes[(long long)s * (nc + 1) + c];
   double dg = 1.0;
   const double r = (double)rate;
   serial_prefetch<8>(xs, i0, i1, [&](int i, float2 v) {
-    gs[i] = g;
+    if (gs) gs[i] = g;
     const float xr = v.x * g, xi = v.y * g;
     const float nrm = xr * xr + xi * xi;
     const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
@@ -506,8 +506,11 @@ __global__ __launch_bounds__(1024) void k_agc_nodes(float *__restrict__ nodes, c
     // Over thousands of nodes a float node somewhere keeps flipping its last bit, so "one ulp everywhere" is not
     // reachable on long calls: from round 3 on a few ulps (1e-6: 2.5e-7 of audio at full scale, 40x inside the
     // tolerance) are accepted as well.
+    // gain_invariant == 2: nobody reads the per-sample gains of this call either (FM without the equaliser, no debug tap)
+    // -- the call is solved for the carried state only, and the node pass has just computed that state from the first
+    // integration pass: a second pass would only rewrite gains that are never read.  Round 1 is accepted at the same 5e-5.
     const float tight = gain_invariant ? 1.0e-6f : 1.5e-7f;
-    if (maxrel <= tight || (gain_invariant && fl[s].agc_iters >= 2 && maxrel <= 5.0e-5f) ||
+    if (maxrel <= tight || (gain_invariant && (fl[s].agc_iters >= 2 || gain_invariant == 2) && maxrel <= 5.0e-5f) ||
         (!gain_invariant && fl[s].agc_iters >= 3 && maxrel <= 1.0e-6f)) {   // gains of the last shoot pass stand
       fl[s].agc_converged = 1;
       st[s].agc_gain = nd[nc];
@@ -545,12 +548,12 @@ __global__ void k_if_agc_fallback(const float2 *__restrict__ x, long long x_stri
   if (s >= n_streams || fl[s].agc_converged) return;
   fl[s].agc_fallback = 1;
   const float2 *xs = x + (long long)s * x_stride + x_off;
-  float *gs = gain + (long long)s * g_stride;
+  float *gs = gain ? gain + (long long)s * g_stride : nullptr;
   float g = st[s].agc_gain;
   const double r = (double)rate;
   for (int i = 0; i < n; i++) {
     const float2 v = xs[i];
-    gs[i] = g;
+    if (gs) gs[i] = g;
     const float xr = v.x * g, xi = v.y * g;
     const float nrm = xr * xr + xi * xi;
     const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
@@ -722,6 +725,14 @@ __global__ void k_signal_host(unsigned long long *flag, unsigned long long value
 }
 
 // Per-call block table: pinned host slot -> device slot (the host pointer is device-visible).
+// two ranges in one launch (the pipelined chain's front-end tables: a launch on the critical stream costs microseconds)
+__global__ void k_copy_ints2(const int *__restrict__ src0, int *__restrict__ dst0, int n0, const int *__restrict__ src1,
+                             int *__restrict__ dst1, int n1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n0) dst0[i] = src0[i];
+  else if (i - n0 < n1) dst1[i - n0] = src1[i - n0];
+}
+
 __global__ void k_copy_ints(const int *__restrict__ src, int *__restrict__ dst, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = __builtin_nontemporal_load(src + i);

@@ -184,12 +184,14 @@ def verify_timed_step(iq0, audio_last, alen_last, B, blk, blocks_done, n_cmp=20,
             "what": "stream 0, the last blocks of the LAST TIMED step"}
 
 
-def cpu_baseline(mode, stages, seconds=8.0):
+def cpu_baseline(mode, stages, seconds=8.0, max_procs=None):
     """The CPU oracle on the same workload: (i) 1 core, 1 stream -- the reference is single-threaded per stream;
     (ii) N streams on N cores, N = the box's core count."""
     import multiprocessing as mp
     n1, t1 = _cpu_worker((mode, stages, 0, seconds))
     ncores = os.cpu_count() or 1
+    if max_procs:
+        ncores = min(ncores, max_procs)
     with mp.get_context("fork").Pool(ncores) as pool:
         res = pool.map(_cpu_worker, [(mode, stages, s, seconds) for s in range(ncores)])
     agg = sum(n / t for n, t in res)
@@ -246,6 +248,8 @@ def self_launch(args):
     sys.stdout.flush()
     if any(rcs):
         raise SystemExit(f"rank return codes {rcs}" + (f" (rank {failed} failed first; the others were stopped)" if failed is not None else ""))
+    if args.all_configs:
+        run_other_configs(n)           # each of them starts its own n ranks the same way
 
 
 def pin_rank_to_cores():
@@ -375,7 +379,7 @@ def main():
     # audio of the first call (cold start included) on the first blocks of stream 0: checked against the oracle below
     nchk = min(B, 4096 if am else 100)
     n_au_chk = int(alen0[:nchk].sum())
-    audio_chk = audio[0, :n_au_chk].cpu().numpy().copy() if (rank == 0 and fmt == 0) else None
+    audio_chk = audio[0, :n_au_chk].cpu().numpy().copy() if fmt == 0 else None      # every rank checks its own stream 0
     iq_chk = iq[0, :nchk * blk].cpu().numpy().view(np.complex64).reshape(-1).copy() if audio_chk is not None else None
     for _ in range(args.warmup):
         step()
@@ -396,7 +400,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     blocks_done = (1 + args.warmup + args.steps) * B     # stream blocks decoded so far (set-up call + warm-up + timed steps)
-    audio_last = audio[0, :int(alen.sum())].cpu().numpy().copy() if rank == 0 else None   # stream 0, the last TIMED step
+    audio_last = audio[0, :int(alen.sum())].cpu().numpy().copy()      # stream 0 of this rank, the last TIMED step
     region = {}
     for name, ms in ch.kernel_times():
         region.setdefault(name, []).append(ms)
@@ -410,9 +414,9 @@ def main():
     # host spends.  Four calls enqueued into an idle queue (fewer than the slots) are not paced by anything.
     ch.enable_kernel_timing(0)
     t1 = time.perf_counter()
-    for _ in range(4):
+    for _ in range(3):                        # (the pipelined chain keeps three calls in flight: a fourth would wait for the first)
         step()
-    host_unpaced_ms = (time.perf_counter() - t1) / 4 * 1e3
+    host_unpaced_ms = (time.perf_counter() - t1) / 3 * 1e3
     ch.synchronize()
     torch.cuda.synchronize()
     # what this box delivers to a kernel that only reads the same input buffer (context for the roofline fraction)
@@ -446,6 +450,36 @@ def main():
         assert st.stereo_detected == 1, "PLL did not lock: the timed work is not the stereo path"
     assert int(alen.sum()) > 0 and bool(torch.isfinite(audio[0, :int(alen.sum())]).all())
 
+    # ---- audio of THIS rank's stream 0 against the oracle: the chain's first call (cold start and lock included) and the
+    # last blocks of the last timed step.  Every rank checks its own stream; rank 0 reports all of them.
+    audio_check = {"stereo_locked": int(st.stereo_detected), "pilot_level": round(st.pilot_level, 6)}
+    my_errs = [-1.0, -1.0]
+    if audio_chk is not None:
+        ifr, dec = _oracle_chain(args.mode, args.multipath_stages)
+        ref = np.concatenate([dec.process(ifr.process(iq_chk[i:i + blk])) for i in range(0, len(iq_chk), blk)])
+        assert len(ref) == len(audio_chk), (len(ref), len(audio_chk))
+        err = float(np.sqrt(np.mean((audio_chk - ref) ** 2)))
+        my_errs[0] = err
+        audio_check.update({"audio_rms_err_vs_oracle": float("%.3e" % err), "audio_rms": float("%.4g" % np.sqrt(np.mean(ref ** 2))),
+                            "blocks_checked": nchk, "audio_samples_checked": len(ref), "tolerance": 1e-5,
+                            "what": "stream 0 of the rank, first call of this chain (cold start and lock included)"})
+        assert err < 1e-5, f"rank {rank}: audio RMS error {err} vs oracle exceeds the north-star tolerance"
+    if fmt == 0 and not am and not args.multipath_stages and B >= 20:
+        iq0 = iq[0].cpu().numpy().view(np.complex64).reshape(-1)
+        tv = verify_timed_step(iq0, audio_last, alen, B, blk, blocks_done)
+        del iq0
+        if tv is not None:
+            audio_check["timed_step"] = tv
+            my_errs[1] = tv["rms_err_vs_oracle"]
+            assert tv["rms_err_vs_oracle"] < 1e-5, f"rank {rank}, timed step: audio RMS error {tv} vs oracle exceeds the north-star tolerance"
+    if world > 1:
+        mine = torch.tensor(my_errs, dtype=torch.float64, device=dev)
+        alle = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(alle, mine)
+        audio_check["per_rank"] = [{"rank": r, "first_call_rms_err": float("%.3e" % e[0].item()), "timed_step_rms_err": float("%.3e" % e[1].item())}
+                                   for r, e in enumerate(alle)]
+        audio_check["max_over_ranks"] = float("%.3e" % max(float(e.max().item()) for e in alle))
+
     if rank == 0:
         kavg = {k: v[0] / v[1] for k, v in ktot.items()}
         ravg = {k: float(np.mean(v)) for k, v in region.items()}          # averages over the K timed steps
@@ -456,23 +490,6 @@ def main():
         bytes_per_launch = float(bps) * S * n     # algorithmic: 8 B per cf32 input IQ sample; 4 / 2 B for s16 / u8
         achieved = bytes_per_launch / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         stage_achieved = bytes_per_launch / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
-        audio_check = {"stereo_locked": int(st.stereo_detected), "pilot_level": round(st.pilot_level, 6)}
-        if audio_chk is not None:
-            ifr, dec = _oracle_chain(args.mode, args.multipath_stages)
-            ref = np.concatenate([dec.process(ifr.process(iq_chk[i:i + blk])) for i in range(0, len(iq_chk), blk)])
-            assert len(ref) == len(audio_chk), (len(ref), len(audio_chk))
-            err = float(np.sqrt(np.mean((audio_chk - ref) ** 2)))
-            audio_check.update({"audio_rms_err_vs_oracle": float("%.3e" % err), "audio_rms": float("%.4g" % np.sqrt(np.mean(ref ** 2))),
-                                "blocks_checked": nchk, "audio_samples_checked": len(ref), "tolerance": 1e-5,
-                                "what": "stream 0, first call of this chain (cold start and lock included)"})
-            assert err < 1e-5, f"audio RMS error {err} vs oracle exceeds the north-star tolerance"
-        if fmt == 0 and not am and not args.multipath_stages and B >= 20:
-            iq0 = iq[0].cpu().numpy().view(np.complex64).reshape(-1)
-            tv = verify_timed_step(iq0, audio_last, alen, B, blk, blocks_done)
-            del iq0
-            if tv is not None:
-                audio_check["timed_step"] = tv
-                assert tv["rms_err_vs_oracle"] < 1e-5, f"timed step: audio RMS error {tv} vs oracle exceeds the north-star tolerance"
         if am:
             workload = "configs[2]: AM 384 kS/s complex-float IQ in HBM, IfResampler(48 k) + AmDecoder narrow filter -> f64 audio"
         elif args.no_pilot:
@@ -528,8 +545,8 @@ def main():
             "kernel_ms_per_step": {k: round(v, 5) for k, v in kavg.items()},
             "kernel_ms_note": "from one extra instrumented step; kernels on the chain's three HIP streams overlap, so the entries sum to more than ms_per_step",
             "host_enqueue_ms_per_step": round(host_unpaced_ms, 4),
-            "host_enqueue_note": "host time per call for four calls enqueued into an idle queue (the host's own cost); in the "
-                                 "timed loop the host is paced by the GPU once it is eight calls ahead: " +
+            "host_enqueue_note": "host time per call for three calls enqueued into an idle queue (the host's own cost); in the "
+                                 "timed loop the host is paced by the GPU once it is three calls ahead: " +
                                  "%.4f ms per step there" % (t_enq / args.steps * 1e3),
             "cold_first_call_ms": round(cold_ms, 2),
             "audio_check": audio_check,
@@ -540,25 +557,44 @@ def main():
                             "agc_serial_fallback": st.agc_fallback, "pll_serial_fallback": st.pll_fallback,
                             "af_tail_serial_fallback": st.af_agc_fallback},
         }
-        if world == 1 and not args.no_cpu_baseline:
+    ch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        # The CPU legs run on rank 0 once the GPU part of every rank is over (the other ranks have left: the host's
+        # cores are free), on all the cores of the box again (the rank was pinned to its slice for the timed region).
+        if not args.no_cpu_baseline:
+            if hasattr(os, "sched_setaffinity"):
+                try:
+                    os.sched_setaffinity(0, range(os.cpu_count() or 1))
+                except OSError:
+                    pass
             out["cpu_baseline"] = cpu_baseline(args.mode, args.multipath_stages)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    ch.close()
-    if world > 1:
-        dist.destroy_process_group()
     if args.all_configs and world == 1:
-        # the other configurations of BASELINE.json, one line each, same run, same box (never the headline)
-        import subprocess
-        extra = [["--mode", "am", "--steps", "20", "--warmup", "3"],                                            # configs[2]
+        run_other_configs(1)
+
+
+# the other configurations of BASELINE.json (and the reference-equivalent resampler class), one line each, same run, same
+# box, never the headline
+OTHER_CONFIGS = [["--mode", "am", "--steps", "20", "--warmup", "3"],                                            # configs[2]
                  ["--multipath-stages", "64", "--blocks", "64", "--steps", "5", "--warmup", "3"],               # configs[3]
                  ["--streams", "32", "--blocks", "128", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],  # configs[4] shard
+                 ["--resampler-class", "r8b", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],            # r8b::CDSPResampler24's filter
                  ["--no-pilot", "--blocks", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]]        # mono station
-        for fl in extra:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + fl, capture_output=True, text=True)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            print(line[-1] if line else json.dumps({"config": {"workload": " ".join(fl)}, "error": r.stderr[-400:]}), flush=True)
+
+
+def run_other_configs(n_gpus):
+    import subprocess
+    for fl in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__)] + (["--gpus", str(n_gpus)] if n_gpus > 1 else []) + fl
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        print(line[-1] if line else json.dumps({"config": {"workload": " ".join(fl)}, "error": r.stderr[-400:]}), flush=True)
 
 
 def block_api(args, ch, iq, blk, fs, rank, world, am):
@@ -641,16 +677,19 @@ def dry_run(args, rank, world, S, B, blk):
         dist.all_reduce(mine, op=dist.ReduceOp.MAX)
         dt = float(mine.item())
     total = world * S * nb * blk * args.steps
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
+        # as in main(): the CPU legs on rank 0 once every rank's timed part is over, whatever the world size (bounded here)
+        cpu = None if args.no_cpu_baseline else cpu_baseline("fm", 0, seconds=0.5, max_procs=2)
         print(json.dumps({"metric": "IQ MS/s (FM stereo, 10 MS/s in), whole job", "value": round(total / dt / 1e6, 3), "unit": "MS/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
                           "ranks_seen": world, "per_rank_ms_per_step": per_rank_ms,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "cpu oracle", "data": "DRY RUN (CPU oracle, gloo) -- not a measurement",
                           "config": {"workload": "dry run of the launch contract", "streams_per_gpu": S, "blocks_per_step": nb,
                                      "samples_per_step_per_gpu": S * nb * blk},
-                          "roofline": None, "cpu_baseline": None}))
-    if world > 1:
-        dist.destroy_process_group()
+                          "roofline": None, "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":

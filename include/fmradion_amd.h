@@ -216,7 +216,7 @@ int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap);
 void fmr_enable_kernel_timing(fmr_chain *c, int enable);
 
 /* enable = 3: trace.  Every instrumented kernel of every call since the mode was switched on keeps its event pair; this
- * call synchronises, fills name / stream (0 decoder, 1 side, 2 AGC, 3 front end, 4 audio tail) / start / end (ms since the
+ * call synchronises, fills name / stream (0 decoder, 1 side, 2 AGC [in-order chain], 4 audio tail) / start / end (ms since the
  * first traced launch) for up to cap entries, clears the trace and returns the count.  The schedule of the chain's streams
  * as the GPU ran it, without a profiler in the host's launch path (tools/step_timeline.py). */
 int fmr_get_kernel_trace(fmr_chain *c, const char **names, int *streams, float *start_ms, float *end_ms, int cap);

@@ -80,6 +80,9 @@ def test_bench_launch_contract_two_ranks_gloo():
     assert out["config"]["samples_per_step_per_gpu"] == 2 * 2 * 65536
     assert out["value"] == pytest.approx(2 * 2 * 2 * 65536 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6, rel=1e-2)
     assert "DRY RUN" in out["data"]
+    # the CPU baseline is part of an N > 1 line too (rank 0, after the timed region)
+    assert out["cpu_baseline"] is not None and out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] == 1
+    assert out["cpu_baseline"]["all_cores"]["cores"] >= 1
 
 
 def test_bench_self_launch_two_ranks_gloo():

@@ -59,10 +59,10 @@ def main():
     fe = [r for r in tr if r[0] in ("ifr_fused", "ifr_decim")]
     lines = ["# %d blocks per step; %.4f ms per step untraced, %.4f ms with the trace's event markers" % (B, plain_ms, traced_ms),
              "# front-end start-to-start (us): " + " ".join("%.0f" % ((b[2] - a[2]) * 1e3) for a, b in zip(fe, fe[1:])),
-             "# columns: start us, duration us, stream (decoder | side | agc | front end | tail), kernel"]
+             "# columns: start us, duration us, stream (decoder | side | agc [in-order chain only] | tail), kernel"]
     if len(fe) > args.show + 2:
         w0, w1 = fe[-args.show - 2][2], fe[-2][2]
-        cols = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4}
+        cols = {0: 0, 1: 1, 2: 2, 3: 3, 4: 3}
         names = ["dec ", "side", "agc ", "fe  ", "tail"]
         for name, st, a, b in tr:
             if b < w0 or a > w1:
