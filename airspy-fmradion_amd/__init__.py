@@ -46,7 +46,7 @@ class Config(C.Structure):
         ("filter_coeff", C.POINTER(C.c_float)), ("n_filter_coeff", C.c_int), ("stereo", C.c_int),
         ("deemphasis_us", C.c_double), ("pilot_shift", C.c_int), ("multipath_stages", C.c_uint),
         ("max_block_len", C.c_size_t), ("max_blocks", C.c_int), ("nbfm_freq_dev", C.c_double),
-        ("input_format", C.c_int), ("output_rate", C.c_double), ("resampler_class", C.c_int),
+        ("input_format", C.c_int), ("output_rate", C.c_double), ("resampler_class", C.c_int), ("struct_size", C.c_uint),
     ]
 
 
@@ -61,6 +61,7 @@ class Status(C.Structure):
         ("agc_residual_history", C.c_float * 16), ("pll_residual_history", C.c_double * 16),
         ("pll_residual_components", C.c_double * 8),
         ("pll_mismatch_history", C.c_double * 16), ("pll_mismatch_accepted", C.c_int), ("af_agc_fallback", C.c_int),
+        ("agc_sync_timeouts", C.c_uint32),
     ]
 
 
@@ -209,6 +210,7 @@ class Chain:
         cfg.input_format = int(input_format)
         cfg.output_rate = float(output_rate)
         cfg.resampler_class = int(resampler_class)
+        cfg.struct_size = C.sizeof(Config)
         self.input_format = int(input_format)
         self.n_streams, self.mode, self.stereo = n_streams, mode, bool(stereo) and mode == MODE_FM
         self.h = C.c_void_p()

@@ -65,6 +65,8 @@ constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 512, K_A
 #endif
 constexpr int C_PLL_MIN = FMR_C_PLL_MIN;   // smallest PLL chunk (capacity); the actual length is c_pll
 constexpr long long kSmallCall = 8192;   // IF samples: calls up to this size enqueue fewer spare Newton rounds
+constexpr unsigned kAgcWaitTicks = 50000000u;   // 0.5 s of the 100 MHz clock: how long k_mpf3 waits for a chunk's gains (the AGC
+                                                // kernel beside it is three times faster than the equaliser: it never waits in practice)
 constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 4;   // PLL: 2 rounds in lock, 2 spare (an unused round is three launches that return at once: ~6 us measured)
 
 template <class T>
@@ -95,6 +97,7 @@ struct EnvKnobs {
   int pipeline = -1;            // FMR_PIPELINE=0/1   the three stages of a call (front end | PLL | audio tail) of consecutive calls
                                 //                    beside each other (1, the default for FM chains with the resampler) or one
                                 //                    in-order chain per call (0: the form the tests compare the product with)
+  int test_agc_late = 0;        // FMR_TEST_AGC_LATE=ms test hook (equaliser chain): the AGC kernel beside the equaliser starts this late; -1: never
   int fe_cus = 0;               // FMR_FE_CUS=n       pipelined chain: workgroups (= CUs) the persistent front-end kernel takes
                                 //                    (0: all but one per XCD)
   bool debug_taps = false;      // FMR_DEBUG_TAPS=1   keep intermediate signals readable through fmr_debug_read
@@ -108,7 +111,7 @@ struct EnvKnobs {
   void load() {
     serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS");
     auto num = [](const char *n, int dflt) { const char *e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
-    pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0);
+    pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0); test_agc_late = num("FMR_TEST_AGC_LATE", 0);
     host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED"); pll_v1 = set("FMR_PLL_V1");
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
   }
@@ -188,9 +191,9 @@ struct fmr_chain {
   // device buffers
   DevBuf<float2> d_in, d_in_halo, d_mid, d_if, d_fir, d_mpf, d_mpf_coeff, d_mpf_state;
   // FM with the equaliser: the serial IF AGC runs beside the equaliser kernel, which follows its progress counter
-  // (absolute sample count per stream; agc_progress_base = IF samples of the calls before this one)
+  // (IF samples of this call whose gain is in HBM, per stream; zeroed at the head of every call)
   DevBuf<unsigned long long> d_agc_progress;
-  unsigned long long agc_progress_base = 0;
+  std::vector<unsigned> agc_timeouts_seen;      // per stream: StreamState::agc_sync_timeouts already reported
   bool agc_beside_mpf = false;
   DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
   int poly2_tile = 0;                  // staged mid samples per tile, 0 = v2 kernel not applicable
@@ -361,6 +364,23 @@ struct fmr_chain {
     while (__atomic_load_n(mark, __ATOMIC_ACQUIRE) < need) {
       std::this_thread::yield();
       if (std::chrono::steady_clock::now() > t_lim) { set_err("the GPU did not reach mark %llu within 60 s", need); return FMR_ERR_HIP; }
+    }
+    return FMR_OK;
+  }
+  // Equaliser chain: k_mpf3 counts the waits for the AGC kernel it gave up (StreamState::agc_sync_timeouts).  Called by
+  // the entry points that synchronise: a new time-out is an error of that call (its audio is void).
+  int check_agc_sync() {
+    if (!enable_mpf || !d_agc_progress.p) return FMR_OK;
+    if (agc_timeouts_seen.size() != (size_t)S) agc_timeouts_seen.assign(S, 0u);
+    int bad = -1;
+    for (int s = 0; s < S; s++) {
+      unsigned v = 0;
+      HIPCHK(hipMemcpy(&v, reinterpret_cast<const char *>(d_state.p + s) + offsetof(StreamState, agc_sync_timeouts), sizeof v, hipMemcpyDeviceToHost));
+      if (v != agc_timeouts_seen[s]) { agc_timeouts_seen[s] = v; bad = s; }
+    }
+    if (bad >= 0) {
+      set_err("stream %d: the equaliser gave up waiting for the AGC kernel beside it (%u time-outs so far); the audio of this call is void", bad, agc_timeouts_seen[bad]);
+      return FMR_ERR_HIP;
     }
     return FMR_OK;
   }
@@ -536,6 +556,15 @@ int fmr_chain::init(const fmr_config *c) {
     if (sizeof(float2) * ((size_t)64 * rs.D + rs.NA - 1) > 60000) {
       set_err("decimation %d of the front end is outside the supported range", rs.D);
       return FMR_ERR_UNSUPPORTED;
+    }
+    {
+      // the generic stage-B kernels stage a window of (255 MB / LB + TB + 6) mid samples in LDS (64 KB without an attribute)
+      const unsigned long long span = (255ull * (unsigned long long)rs.MB) / (unsigned long long)rs.LB + (unsigned long long)rs.TB + 6;
+      if (span * sizeof(float2) > 65536) {
+        set_err("resampling ratio %.9g -> %.9g: stage B needs %d taps per phase at this ratio and class, more than the kernels stage",
+                c->input_rate, dec_rate, rs.TB);
+        return FMR_ERR_UNSUPPORTED;
+      }
     }
     H_in = rs.NA - 1 + rs.D;
     H_mid = rs.TB;
@@ -1064,8 +1093,8 @@ int fmr_chain::run_front_end(CallCtx &k) {
                            (long long)(H_mid + max_mid), H_mid, (unsigned)(abs_in & 3u), cfg.enable_fourth_down);
       };
       const size_t per_out = sizeof(float2) * (size_t)rs.D, tail = sizeof(float2) * (size_t)(rs.NA - 1);
-      // v2 kernel, 128 (default) or 256 lanes per workgroup (FMR_DECIM_BL=256: half the tile-halo over-fetch, twice the
-      // LDS per workgroup)
+      // v2 kernel, 128 lanes per workgroup (256 -- half the tile-halo over-fetch, twice the LDS per workgroup -- measured
+      // no faster in round 2)
       bool v2_done = false;
       auto launch_decim2 = [&](auto bl_tag) {
         constexpr int BL2 = decltype(bl_tag)::value, T2 = 2 * BL2;
@@ -1463,11 +1492,17 @@ int fmr_chain::run_if_stage(CallCtx &k) {
   // the equaliser kernel is the serial bottleneck anyway: use the exact serial AGC.
   if (enable_mpf && !serial_mode && mode == FMR_MODE_FM) {
     // beside the equaliser, which consumes the gains as they are published (k_if_agc / k_mpf3, kernels.hpp)
+    // (the progress words count the samples of THIS call: zeroed here, in front of both kernels -- a call that failed
+    // half way cannot leave a count behind that a later call would take for its own)
+    HIPCHK(hipMemsetAsync(d_agc_progress.p, 0, sizeof(unsigned long long) * (size_t)S, stream));
     HIPCHK(hipEventRecord(ev_if, stream));
     HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
+    if (env.test_agc_late > 0)      // test hook: the AGC kernel starts this many milliseconds late
+      hipLaunchKernelGGL(k_hold_stream, dim3(1), dim3(1), 0, side2, (unsigned long long)env.test_agc_late * 100000ull);
     timed_on(side2, "if_agc", [&] {
+      if (env.test_agc_late >= 0)   // (test hook, < 0: the AGC kernel is not launched at all)
       hipLaunchKernelGGL(k_if_agc, dim3((S + 63) / 64), dim3(64), 0, side2, xin, x_stride, x_off, (int)N_if, d_gain.p,
-                         (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_agc_progress.p, agc_progress_base);
+                         (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_agc_progress.p);
     });
     HIPCHK(hipEventRecord(ev_agc, side2));
     ev_agc_live = true;
@@ -1475,7 +1510,7 @@ int fmr_chain::run_if_stage(CallCtx &k) {
   } else if (serial_mode || enable_mpf) {
     timed("if_agc", [&] {
       hipLaunchKernelGGL(k_if_agc, dim3((S + 63) / 64), dim3(64), 0, stream, xin, x_stride, x_off, (int)N_if, d_gain.p,
-                         (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, (unsigned long long *)nullptr, 0ull);
+                         (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, (unsigned long long *)nullptr);
     });
   } else {
     // FM without the equaliser: the AGC output only feeds atan2, which is invariant to the
@@ -1650,7 +1685,7 @@ int fmr_chain::run_fm(CallCtx &k) {
         hipLaunchKernelGGL(kern, dim3(S), dim3(threads), bytes, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
                            bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
                            d_mpf_ok.p, d_state.p, agc_beside_mpf ? d_agc_progress.p : (const unsigned long long *)nullptr,
-                           agc_progress_base);
+                           kAgcWaitTicks);
       };
       // four waves per stream (kernels.hpp), taps per lane and row by equaliser length
       if (mpf_N <= 64 * 5) go(k_mpf3<4, 5>, 256, lds3);
@@ -1663,7 +1698,6 @@ int fmr_chain::run_fm(CallCtx &k) {
     // the discriminator multiplies the gains into the blocks the equaliser passed over (warm-up, resets), and the AGC's
     // state must be committed before the next call: the AGC kernel finished long ago (it is three times faster)
     HIPCHK(hipStreamWaitEvent(stream, ev_agc, 0));
-    agc_progress_base += (unsigned long long)N_if;
   }
   const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
   const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
@@ -1971,11 +2005,16 @@ int fmr_chain::run_am(CallCtx &k) {
 extern "C" {
 
 const char *fmr_last_error(void) { return g_err.c_str(); }
-const char *fmr_version(void) { return "fmradion_amd 0.2 (gfx950)"; }
+const char *fmr_version(void) { return "fmradion_amd 0.4 (gfx950)"; }
 
 int fmr_create(const fmr_config *cfg, fmr_chain **out) {
   if (!cfg || !out) return FMR_ERR_BAD_ARG;
   *out = nullptr;
+  if (cfg->struct_size != 0 && cfg->struct_size != sizeof(fmr_config)) {
+    set_err("fmr_config.struct_size %u is not this library's %zu: caller and library were built against different headers "
+            "(or the struct was not zero-initialised)", cfg->struct_size, sizeof(fmr_config));
+    return FMR_ERR_BAD_ARG;
+  }
   fmr_chain *c = new fmr_chain();
   const int rc = c->init(cfg);
   if (rc != FMR_OK) { delete c; return rc; }
@@ -2041,7 +2080,8 @@ void fmr_host_free(void *p) {
 
 int fmr_synchronize(fmr_chain *c) {
   if (!c) return FMR_ERR_BAD_ARG;
-  return c->sync_all();
+  if (int rc = c->sync_all()) return rc;
+  return c->check_agc_sync();
 }
 
 // how many doubles per stream the blocks would produce, from copies of the count-law counters (nothing is advanced)
@@ -2070,7 +2110,7 @@ int fmr_process_blocks_device(fmr_chain *c, const float *d_iq, size_t stream_str
     }
     const int rc = c->run_cold_aware((const float2 *)d_iq, stream_stride, block_len, n_blocks, d_audio, audio_stride, audio_len);
     if (rc) return rc;
-    if (sync) return c->sync_all();
+    if (sync) { if (int rcs = c->sync_all()) return rcs; return c->check_agc_sync(); }
     return FMR_OK;
   } catch (const std::exception &e) { set_err("exception: %s", e.what()); return FMR_ERR_HIP; }
 }
@@ -2104,7 +2144,8 @@ int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride, cons
     HIPCHK(hipMemcpy2DAsync(audio, sizeof(double) * audio_stride, c->d_audio.p, sizeof(double) * dstride,
                             sizeof(double) * total, c->S, hipMemcpyDeviceToHost, c->pipelined ? c->tail : c->stream));
   }
-  return c->sync_all();
+  if (int rcs = c->sync_all()) return rcs;
+  return c->check_agc_sync();
   } catch (const std::exception &e) { set_err("exception: %s", e.what()); return FMR_ERR_HIP; }
 }
 
@@ -2175,6 +2216,7 @@ int fmr_get_status(fmr_chain *c, int stream, fmr_status *st) {
   st->multipath_error = s.mpf_error;
   st->pll_freq_err = s.pll_freq_err;
   st->multipath_resets = s.mpf_resets;
+  st->agc_sync_timeouts = s.agc_sync_timeouts;
   const IterFlags &f = c->h_flags[stream];
   st->agc_iterations = f.agc_iters;
   st->pll_iterations = f.pll_iters;
@@ -2252,25 +2294,39 @@ __global__ __launch_bounds__(256) void k_probe_read(const float *__restrict__ p0
 
 int fmr_probe_read_bandwidth(int device, const void *d_buf, size_t bytes, int reps, double *gbytes_per_s) {
   if (!d_buf || !gbytes_per_s || bytes < (1u << 20) || reps < 1) return FMR_ERR_BAD_ARG;
+  // everything this function takes is given back on every path out of it, the caller's current device included
+  struct Scope {
+    int prev_dev = -1;
+    float *sink = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Scope() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+      if (st) (void)hipStreamDestroy(st);
+      if (sink) (void)hipFree(sink);
+      if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    }
+  } sc;
+  HIPCHK(hipGetDevice(&sc.prev_dev));
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  float *sink = nullptr;
-  HIPCHK(hipMalloc((void **)&sink, sizeof(float)));
-  hipEvent_t a, b;
-  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  HIPCHK(hipMalloc((void **)&sc.sink, sizeof(float)));
+  HIPCHK(hipStreamCreateWithFlags(&sc.st, hipStreamNonBlocking));      // (the null stream would wait for every blocking stream)
+  HIPCHK(hipEventCreate(&sc.a));
+  HIPCHK(hipEventCreate(&sc.b));
   double best = 0.0;
   for (int r = 0; r < reps + 1; r++) {          // (the first pass warms up and is not counted)
-    HIPCHK(hipEventRecord(a, 0));
-    hipLaunchKernelGGL(k_probe_read, dim3(n_cu * 8), dim3(256), 0, 0, (const float *)d_buf, bytes / 16, sink);
-    HIPCHK(hipEventRecord(b, 0));
-    HIPCHK(hipEventSynchronize(b));
+    HIPCHK(hipEventRecord(sc.a, sc.st));
+    hipLaunchKernelGGL(k_probe_read, dim3(n_cu * 8), dim3(256), 0, sc.st, (const float *)d_buf, bytes / 16, sc.sink);
+    HIPCHK(hipEventRecord(sc.b, sc.st));
+    HIPCHK(hipEventSynchronize(sc.b));
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    HIPCHK(hipEventElapsedTime(&ms, sc.a, sc.b));
     if (r > 0 && ms > 0.f) best = std::max(best, (double)(bytes / 16 * 16) / (ms * 1e-3) / 1e9);
   }
-  (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(sink);
   *gbytes_per_s = best;
   return FMR_OK;
 }

@@ -50,7 +50,8 @@ struct StreamState {
   double dc_mono_x1, dc_mono_x2, dc_st_x1, dc_st_x2;
   // MultipathFilter (MultipathFilter.cpp:59-75)
   double mpf_error;
-  unsigned mpf_resets, pad1;
+  unsigned mpf_resets;
+  unsigned agc_sync_timeouts;    // k_mpf3 gave up waiting for the AGC kernel beside it (protocol error: reported, fmr_status)
   // AmDecoder: AfSimpleAgc gain, dc block, de-emphasis
   double af_gain, am_dc_x1, am_dc_x2, am_de_x1;
   double am_de_x1_next, am_dc_x1_next, am_dc_x2_next;    // staged by the time-parallel AM tail, committed once it has converged
@@ -1140,13 +1141,13 @@ __global__ __launch_bounds__(BLOCK) void k_finetune(float2 *__restrict__ buf, lo
 // ---------------------------------------------------------------------------
 // progress != nullptr (FM with the equaliser, round 3): the equaliser kernel runs BESIDE this one on another stream and
 // consumes the gains as they appear -- every gain is stored write-through (agent scope) and, every 256 samples, the
-// count of finished samples is published in progress[s] (absolute: base = samples of earlier calls) behind a vmcnt(0)
+// count of finished samples of THIS call is published in progress[s] (zeroed at the head of the call) behind a vmcnt(0)
 // wait.  k_mpf3 polls it before it loads a chunk.  A serial recurrence of 80 ns per sample in front of a serial
 // recurrence of 240 ns per sample was a quarter of the call (12.9 of 52 ms per 161 k IF samples).
 __global__ void k_if_agc(const float2 *__restrict__ x, long long x_stride, int x_off, int n,
                          float *__restrict__ gain, long long g_stride, StreamState *st, int n_streams,
                          float initial_gain, float max_gain, float rate,
-                         unsigned long long *__restrict__ progress = nullptr, unsigned long long base = 0ull) {
+                         unsigned long long *__restrict__ progress = nullptr) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_streams) return;
   const float2 *xs = x + (long long)s * x_stride + x_off;
@@ -1159,7 +1160,7 @@ __global__ void k_if_agc(const float2 *__restrict__ x, long long x_stride, int x
   };
   auto publish = [&](int done) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(progress + s, base + (unsigned long long)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(progress + s, (unsigned long long)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   int i = 0;
   for (; i + 4 <= n; i += 4) {
@@ -1189,6 +1190,13 @@ __global__ void k_if_agc(const float2 *__restrict__ x, long long x_stride, int x
   }
   st[s].agc_gain = g;
   if (progress) publish(n);
+}
+
+// test hook (FMR_TEST_AGC_LATE): keeps a stream busy for `ticks` of the 100 MHz clock, so that the AGC kernel behind it
+// starts late and the equaliser beside it has to wait (tests/test_gpu_configs.py)
+__global__ void k_hold_stream(unsigned long long ticks) {
+  const unsigned long long t_lim = wall_clock64() + ticks;
+  while (wall_clock64() < t_lim) __builtin_amdgcn_s_sleep(64);
 }
 
 // ---------------------------------------------------------------------------
@@ -1255,7 +1263,7 @@ __global__ __launch_bounds__(64 * NW) void k_mpf3(
     const float *__restrict__ gain, long long g_stride, BlockTab bt,
     float2 *__restrict__ out, long long out_stride, float2 *__restrict__ coeff_g,
     float2 *__restrict__ state_g, int N, int ref, int *__restrict__ mpf_ok, StreamState *st,
-    const unsigned long long *__restrict__ progress = nullptr, unsigned long long base = 0ull) {
+    const unsigned long long *__restrict__ progress = nullptr, unsigned wait_ticks = 0u) {
   typedef float v2f __attribute__((ext_vector_type(2)));
   constexpr int NT = 64 * NW, SL = 16 * NW;      // SL: taps per slice j (one per row lane of every wave)
   extern __shared__ float2 lds_m[];
@@ -1280,6 +1288,7 @@ __global__ __launch_bounds__(64 * NW) void k_mpf3(
   double err_last = st[s].mpf_error;
   unsigned resets = st[s].mpf_resets;
   int buf = 0;
+  bool gave_up = false;
   for (int b = 0; b < bt.nb; b++) {
     const int n = bt.if_len[b];
     int ok = 1;
@@ -1292,16 +1301,25 @@ __global__ __launch_bounds__(64 * NW) void k_mpf3(
     __syncthreads();
     for (int c0 = 0; c0 < n && ok; c0 += FMR_MPF_CH) {
       const int cn = min(FMR_MPF_CH, n - c0);
-      if (progress) {
-        // the AGC kernel runs beside this one (k_if_agc): wait until it has published the gains of this chunk.  Bounded:
-        // a protocol error must show as wrong audio, not as a hung GPU.
+      if (progress && !gave_up) {
+        // the AGC kernel runs beside this one (k_if_agc): wait until it has published the gains of this chunk.  Bounded in
+        // TIME (wait_ticks of the 100 MHz clock): a protocol error -- the AGC kernel not resident, not launched -- must
+        // not hang the GPU.  It does not pass silently either: the stream's time-out counter goes up, the host turns it
+        // into an error at its next synchronising call (fmr_chain::check_agc_sync), and the rest of the call stops
+        // waiting (the gains it reads are then whatever the buffer holds: the audio of this call is void).
         if (tid == 0) {
-          const unsigned long long need = base + (unsigned long long)(off + c0 + cn);
-          for (int spin = 0; spin < (1 << 26); spin++) {
-            if (__hip_atomic_load(progress + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+          const unsigned long long need = (unsigned long long)(off + c0 + cn);
+          const unsigned long long t_lim = wall_clock64() + wait_ticks;
+          bool there = false;
+          for (;;) {
+            if (__hip_atomic_load(progress + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) { there = true; break; }
+            if (wall_clock64() > t_lim) break;
             __builtin_amdgcn_s_sleep(8);
           }
+          if (!there) { st[s].agc_sync_timeouts++; exch[0].x = 1.f; } else exch[0].x = 0.f;
         }
+        __syncthreads();
+        gave_up = exch[0].x != 0.f;
         __syncthreads();
       }
       for (int i = tid; i < cn; i += NT) {

@@ -128,9 +128,37 @@ private:
       } else if (!std::memcmp(ck, "data", 4)) {
         if (!have_fmt) { m_error = "data chunk before fmt chunk"; return false; }
         m_left = (rf64 && size == 0xFFFFFFFFu) ? data64 : size;
-        // streaming recorders leave 0 or 0xFFFFFFFF in the data size (the header is never finalised): the data then
-        // run to the end of the file
-        if (m_left == 0 || (!rf64 && size == 0xFFFFFFFFu) || (rf64 && size == 0xFFFFFFFFu && data64 == 0)) m_left = UINT64_MAX;
+        // what the file really holds behind this header (a regular file; a pipe reports nothing and is read to its end)
+        uint64_t rest = UINT64_MAX;
+        {
+          const long here = std::ftell(m_fp);
+          if (here >= 0 && std::fseek(m_fp, 0, SEEK_END) == 0) {
+            const long end = std::ftell(m_fp);
+            if (end >= here) rest = (uint64_t)(end - here);
+            std::fseek(m_fp, here, SEEK_SET);
+          }
+        }
+        // Streaming recorders leave 0 or 0xFFFFFFFF in the data size (the header is never finalised -- AudioFileWriter's
+        // own provisional header, if the writer is killed within its first second): the data then run to the end of the
+        // file.  Only if the data chunk is the LAST chunk, though: a size of 0 followed by something that reads as a
+        // chunk header (four printable characters and a length that fits the rest of the file: LIST, bext, id3 ...) is an
+        // empty recording with metadata behind it, not samples.
+        const bool unknown = m_left == 0 || (!rf64 && size == 0xFFFFFFFFu) || (rf64 && size == 0xFFFFFFFFu && data64 == 0);
+        if (unknown) {
+          bool chunk_follows = false;
+          if (size == 0 && rest != UINT64_MAX && rest >= 8) {
+            unsigned char nx[8];
+            const long here = std::ftell(m_fp);
+            if (std::fread(nx, 1, 8, m_fp) == 8) {
+              bool printable = true;
+              for (int i = 0; i < 4; i++) printable = printable && nx[i] >= 0x20 && nx[i] < 0x7f;
+              chunk_follows = printable && (uint64_t)rd32(nx + 4) + 8 <= rest;
+            }
+            std::fseek(m_fp, here, SEEK_SET);
+          }
+          m_left = chunk_follows ? 0 : UINT64_MAX;
+        }
+        if (m_left != UINT64_MAX && rest != UINT64_MAX && m_left > rest) m_left = rest;     // truncated file: what is there
         return true;
       } else {
         if (std::fseek(m_fp, (long)(size + (size & 1)), SEEK_CUR)) { m_error = "truncated file"; return false; }

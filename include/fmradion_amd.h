@@ -63,7 +63,9 @@ typedef struct {
   uint32_t stream;
 } fmr_pps_event;
 
-/* Configuration of one chain.  Zero-initialise, then set fields. */
+/* Configuration of one chain.  ZERO-INITIALISE (memset / = {0} / fmr_config cfg{}), then set fields and struct_size:
+ * every field added since the first version means "as before" when it is 0, and a field left uninitialised is refused
+ * if its value is not one this library knows. */
 typedef struct {
   int device;                 /* HIP device ordinal */
   int n_streams;              /* >= 1 independent IQ streams (batch) */
@@ -98,6 +100,10 @@ typedef struct {
    * IF rate (384 kHz).  Decoder chains ignore it (their rate is fixed: FmDecode.h:38, AmDecode.h:36). */
   double output_rate;
   int resampler_class;        /* FMR_RESAMPLER_FAST (default) | FMR_RESAMPLER_R8B: specification of the IF resampler */
+  /* sizeof(fmr_config) of the header the caller was built against; 0 = not stated (taken as this header's).  The struct
+   * grows at its end from version to version: fmr_create refuses a size it does not know instead of reading past a
+   * shorter struct or misreading a longer one.  Zero-initialise the whole struct first (an unset field must read 0). */
+  unsigned struct_size;
 } fmr_config;
 
 /* Per-stream status after the most recent call (getters of FmDecode.h:77-105 /
@@ -123,6 +129,9 @@ typedef struct {
   double pll_mismatch_history[16];  /* scaled chunk-boundary mismatch seen by each round's integration pass */
   int pll_mismatch_accepted;        /* 1: the last round was accepted on the mismatch alone (node pass skipped) */
   int af_agc_fallback;              /* AM: 1 = the audio tail (DC block / AfSimpleAgc / de-emphasis) ran in its serial form */
+  uint32_t agc_sync_timeouts;       /* FM with the equaliser: times the equaliser kernel gave up waiting for the AGC kernel
+                                     * that runs beside it (0 in a healthy chain; every synchronising call that sees a new one
+                                     * fails with FMR_ERR_HIP: the audio of that call is void) */
 } fmr_status;
 
 typedef struct fmr_chain fmr_chain;

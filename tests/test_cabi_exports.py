@@ -47,3 +47,16 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".inc", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_py" not in txt and "libfmoracle" not in txt and "fmradion_oracle" not in txt, f
+
+
+def test_config_struct_size_is_checked(lib):
+    """fmr_config grows at its end from version to version: a caller built against another header (or one that did not
+    zero-initialise the struct) is refused by name, before anything else is looked at -- also without a GPU."""
+    import ctypes as C
+    cfg = fmr.Config()
+    cfg.n_streams, cfg.max_block_len, cfg.max_blocks = 1, 1024, 1
+    cfg.struct_size = C.sizeof(fmr.Config) - 8
+    h = C.c_void_p()
+    assert lib.fmr_create(C.byref(cfg), C.byref(h)) == fmr.ERR_BAD_ARG
+    assert b"struct_size" in lib.fmr_last_error()
+    assert b"0.4" in lib.fmr_version()

@@ -157,6 +157,32 @@ def test_wav_with_unfinalised_data_size(exe, tmp_path):
         assert np.array_equal(got.view(np.float32).reshape(-1, 2), (iq / 32768.0).astype(np.float32))
 
 
+def test_wav_with_empty_data_chunk_and_metadata_behind_it(exe, tmp_path):
+    """A size of 0 means "runs to the end of the file" only if the data chunk is the last one: an empty recording with a
+    LIST chunk behind it holds no samples (the chunk's bytes must not be decoded as IQ), and a data size larger than what
+    the file holds is clamped to what is there."""
+    path = os.path.join(tmp_path, "empty_list.wav")
+    info = b"INFOISFT" + struct.pack("<I", 8) + b"recorder"
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 0) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 912000, 912000 * 4, 4, 16))
+        f.write(b"data" + struct.pack("<I", 0))
+        f.write(b"LIST" + struct.pack("<I", len(info)) + info)
+    got, rate, blocks, samples = _read(exe, str(tmp_path), path, False, "FLOAT")
+    assert rate == 912000 and samples == 0 and len(got) == 0
+    n = 500
+    iq = RNG.integers(-32768, 32768, size=(n, 2)).astype(np.int16)
+    path = os.path.join(tmp_path, "truncated.wav")
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + 4000 * 4) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 912000, 912000 * 4, 4, 16))
+        f.write(b"data" + struct.pack("<I", 4000 * 4))         # announces 4000 samples, holds 500
+        f.write(iq.tobytes())
+    got, rate, blocks, samples = _read(exe, str(tmp_path), path, False, "FLOAT")
+    assert samples == n
+    assert np.array_equal(got.view(np.float32).reshape(-1, 2), (iq / 32768.0).astype(np.float32))
+
+
 def test_wav_header_chunk_sizes_are_bounded(exe, tmp_path):
     """A header that announces a gigabyte-sized fmt chunk is refused, not allocated."""
     path = os.path.join(tmp_path, "evil.wav")

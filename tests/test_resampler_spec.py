@@ -99,8 +99,10 @@ def test_if_resampler_complex_lockstep():
                                       (2.048e6, 384e3), (3.2e6, 384e3), (1.92e6, 48e3), (912e3, 48e3), (6e6, 384e3)])
 def test_equiripple_stage_a_rule_holds_across_shapes(fin, fout):
     """Stage A of the IF class is an equiripple design of 0.68 x the Kaiser length (a fixed formula, not a search: product
-    and oracle cannot pick different lengths).  Measured directly on the PRODUCT's taps (host arithmetic): the pass band
-    stays within 0.0012 dB of unity and every alias of the protected band is at least 139 dB down, for D = 2 ... 61."""
+    and oracle cannot pick different lengths) -- where that design meets the class; the design code checks its response
+    (every stop band <= -140 dB, ripple <= 0.0012 dB peak to peak) and keeps the Kaiser window where it does not (D = 28
+    at 3.6 MHz -> 48 kHz misses by 0.2 dB, D = 61 too).  Measured directly on the PRODUCT's taps (host arithmetic): the
+    pass band stays within 0.0012 dB of unity and every alias of the protected band is 140 dB down, for D = 2 ... 61."""
     import importlib
     fmr = importlib.import_module("airspy-fmradion_amd")
     h, d = fmr.design_taps(fin, fout, 140.0, 0)
@@ -117,14 +119,18 @@ def test_equiripple_stage_a_rule_holds_across_shapes(fin, fout):
         if lo >= fin / 2:
             break
         worst = max(worst, 20 * np.log10(resp(np.linspace(lo, hi, 601)).max()))
-    assert worst < -139.0
-    # 0.68 x the Kaiser length
+    assert worst < -139.95           # (the design code checks 65 points per band, this test 601)
+    # 0.68 x the Kaiser length, or the Kaiser length itself
     dw = 2 * np.pi * ((mid - fstop) - fp) / fin
     nk = int(np.ceil((140.0 - 7.95) / (2.285 * dw))) + 1
     nk += nk % 2 == 0
-    ne = int(np.ceil(0.68 * nk))
-    ne += ne % 2 == 0
-    assert len(h) == ne
+    allowed = []
+    for pc in range(68, 97, 4):      # 0.68 N, then 4 % of N longer until the response meets the class; else Kaiser
+        ne = (nk * pc + 99) // 100
+        allowed.append(ne + (ne % 2 == 0))
+    assert len(h) in allowed + [nk]
+    if (fin, fout) in ((10e6, 384e3), (6e6, 384e3), (2e6, 48e3)):      # the shapes that are in use take the shortest design
+        assert len(h) == allowed[0]
 
 
 def test_very_large_decimation_keeps_the_kaiser_stage_a():

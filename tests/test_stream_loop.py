@@ -59,7 +59,7 @@ def test_stream_loop_fm_zero_if_with_pps(tmp_path, pilotcut):
     x = (x * (1j ** (np.arange(n) % 4))).astype(np.complex64)      # the station sits at +fs/4 (main.cpp:912-919)
     exe = _build(str(tmp_path))
     audio, pps = _run(exe, str(tmp_path), "fm", fs, True, blk, x)
-    f4, r = ora.FourthConverterIQ(False), ora.IfResampler(fs, 384e3)
+    f4, r = ora.FourthConverterIQ(False), ora.IfResampler(fs, 384e3, 180.0, 0.98, True)      # the facade's default class: r8brain's
     fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 0, pilotcut)
     ref, ev_ref = [], []
     for b, seg in enumerate(siggen.blocks(x, blk)):
@@ -90,7 +90,7 @@ def test_stream_loop_48k_modes(tmp_path, mode, fs, am_narrow, nbfm_default, nbfm
     x = siggen.am_iq(nblk * blk, fs) if mode == "am" else siggen.nbfm_iq(nblk * blk, fs)
     exe = _build(str(tmp_path))
     audio, _ = _run(exe, str(tmp_path), mode, fs, False, blk, x)
-    r = ora.IfResampler(fs, 48e3)
+    r = ora.IfResampler(fs, 48e3, 180.0, 0.98, True)       # the facade's default resampler class (R8B)
     dec = ora.AmDecoder(am_narrow, ora.MODE_AM) if mode == "am" else ora.NbfmDecoder(nbfm_default, 8000.0, nbfm_audio)
     ref = np.concatenate([0.5 * dec.process(r.process(seg)) for seg in siggen.blocks(x, blk)])
     assert len(audio) == len(ref) > 1000
