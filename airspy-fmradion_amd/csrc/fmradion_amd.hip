@@ -98,6 +98,8 @@ struct EnvKnobs {
                                 //                    beside each other (1, the default for FM chains with the resampler) or one
                                 //                    in-order chain per call (0: the form the tests compare the product with)
   int test_agc_late = 0;        // FMR_TEST_AGC_LATE=ms test hook (equaliser chain): the AGC kernel beside the equaliser starts this late; -1: never
+  bool r8b_f32 = false;         // FMR_R8B_F32=1      R8B class: stage B as the f32 MFMA product (k_ifr_poly5) instead of the fp16
+                                //                    three-product form (tests: the two against each other)
   int fe_cus = 0;               // FMR_FE_CUS=n       pipelined chain: workgroups (= CUs) the persistent front-end kernel takes
                                 //                    (0: all but one per XCD)
   bool debug_taps = false;      // FMR_DEBUG_TAPS=1   keep intermediate signals readable through fmr_debug_read
@@ -109,7 +111,7 @@ struct EnvKnobs {
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
   void load() {
-    serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS");
+    serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS"); r8b_f32 = on("FMR_R8B_F32");
     auto num = [](const char *n, int dflt) { const char *e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
     pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0); test_agc_late = num("FMR_TEST_AGC_LATE", 0);
     host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED"); pll_v1 = set("FMR_PLL_V1");
@@ -209,6 +211,11 @@ struct fmr_chain {
   bool poly5 = false;                  // stage-B v5 (f32 MFMA, 48/125 with any TB: the R8B class); its k-steps: poly5_nks
   int poly5_nks = 0;
   DevBuf<float> d_afrag5;
+  bool poly5h = false;                 // ... on the fp16 matrix cores, three-product split (k_ifr_poly5h): the form that runs
+  int poly5h_nkb = 0;
+  float poly5h_inv_scale = 1.f;
+  size_t poly5h_lds = 0;
+  DevBuf<_Float16> d_afrag5h;
   DevBuf<float> d_afrag;               // v4: constant A fragments
   // fused front end (kernels_fused.hpp): stage A + stage B + discriminator in one persistent kernel
   bool fused_ok = false;               // the chain's shape fits (10 MS/s class, FM, cf32, no Fs/4)
@@ -288,7 +295,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_taps.release(); d_fused_part.release(); d_afrag.release(); d_afrag5.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_taps.release(); d_fused_part.release(); d_afrag.release(); d_afrag5.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -646,6 +653,37 @@ int fmr_chain::init(const fmr_config *c) {
             poly2_tile = (int)tl + 64;
             poly5 = true; poly5_nks = nks;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly5<48, 125>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+            // the fp16 three-product form (k_ifr_poly5h): A fragments [k-block of 32 taps][row tile][h | l][lane][8], the
+            // taps scaled by the power of two that puts the largest into [512, 1024)
+            if (!env.r8b_f32) {
+              constexpr int KCH = FMR_POLY5H_KCH;
+              const int nkb = (((off[47] + rs.TB + 31) / 32 + KCH - 1) / KCH) * KCH;
+              double tmax = 0.0;
+              for (float v : fb) tmax = std::max(tmax, (double)std::fabs(v));
+              int ea = 0;
+              if (tmax > 0.0) { int e2; (void)std::frexp(tmax, &e2); ea = 10 - e2; }      // tmax 2^ea in [512, 1024)
+              const float sa = std::ldexp(1.0f, ea);
+              std::vector<_Float16> ah((size_t)nkb * 3 * 2 * 64 * 8, (_Float16)0.f);
+              for (int kb = 0; kb < nkb; kb++)
+                for (int mt = 0; mt < 3; mt++)
+                  for (int l = 0; l < 64; l++)
+                    for (int e = 0; e < 8; e++) {
+                      const int pp = 16 * mt + (l & 15), m = 32 * kb + 8 * (l >> 4) + e, j = m - off[pp];
+                      if (j < 0 || j >= rs.TB) continue;
+                      const float t = fb[(size_t)phi[pp] * rs.TB + j] * sa;
+                      const _Float16 hi = (_Float16)t;
+                      const size_t base = ((((size_t)kb * 3 + mt) * 2) * 64 + l) * 8 + e;
+                      ah[base] = hi;
+                      ah[base + 64 * 8] = (_Float16)(t - (float)hi);
+                    }
+              const size_t x_len = (size_t)((((int)tl + 64 + 127) / 128) * 128 + 96);
+              const size_t lds5h = 8 * x_len + 2 * (size_t)KCH * 3 * 2 * 64 * 16 + 4 * 8 * 48 * sizeof(float2);
+              if (lds5h <= 160 * 1024 - 64 && (size_t)63 * 125 + 32 * (size_t)nkb <= x_len && x_len <= 48 * 256) {
+                if ((rc = upload(d_afrag5h, ah.data(), ah.size()))) return rc;
+                poly5h = true; poly5h_nkb = nkb; poly5h_inv_scale = std::ldexp(1.0f, -ea); poly5h_lds = lds5h;
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly5h<48, 125>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5h));
+              }
+            }
           }
         }
         if (poly3 && rs.LB == 48 && rs.MB == 125 && rs.TB == 210) {
@@ -1140,7 +1178,12 @@ int fmr_chain::run_front_end(CallCtx &k) {
       const long long P_first = kB_prev / rs.LB, P_last = (kB_prev + N_if - 1) / rs.LB;
       const int tiles = (int)((P_last - P_first) / 64 + 1);
       timed_on(fes, "ifr_poly", [&] {
-        if (poly5)
+        if (poly5h)
+          hipLaunchKernelGGL((k_ifr_poly5h<48, 125>), dim3(std::min(tiles, n_cu), S), dim3(256), poly5h_lds,
+                             fes, d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag5h.p,
+                             poly5h_nkb, poly5h_inv_scale, rs.TB, kB_prev, (int)N_if, ifbuf, (long long)(H_if + max_if), H_if,
+                             poly2_tile, tiles);
+        else if (poly5)
           hipLaunchKernelGGL((k_ifr_poly5<48, 125>), dim3(std::min(tiles, n_cu), S), dim3(64 * FMR_POLY5_WAVES),
                              sizeof(float2) * (size_t)(((poly2_tile + 127) / 128) * 128 + FMR_POLY5_WAVES * 8 * 48) + sizeof(float) * 2 * FMR_POLY5_KC * 3 * 64,
                              fes, d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag5.p,

@@ -902,6 +902,241 @@ __global__ __launch_bounds__(64 * FMR_POLY5_WAVES) void k_ifr_poly5(
 }
 
 // ---------------------------------------------------------------------------
+// k_ifr_poly5h : the same dense product on the fp16 matrix cores -- v_mfma_f32_16x16x32_f16, 16 x the f32 MFMA rate --
+// with BOTH operands split in two fp16 terms, x = h + l, and three products per tile (hh + hl + lh; ll is 2^-22 of the
+// result): 16 / 3 of the f32 rate with fp32-class accuracy.  What makes the split safe for any signal level:
+//   * taps: scaled at design time by a power of two so that the largest is in [512, 1024) -- the smallest taps of a
+//     180 dB design then sit in fp16's subnormal range, whose absolute step (6e-8) is 2^-34 of the largest tap;
+//   * mid samples: every tile finds the maximum of its own window and scales by the power of two that brings it into
+//     [512, 1024) before the split (h keeps 11 bits, l the next 11: 2^-22 of the window's maximum);
+//   * the MFMA accumulates in fp32; as in the f32 kernel the accumulators are flushed into a second set every 128 taps;
+//   * the result is multiplied by the inverse of the two scales (powers of two: exact).
+// Layouts: the tile's window as four fp16 planes in LDS (re_h, re_l, im_h, im_l); a B fragment is eight consecutive
+// elements of a plane from (period n/2) 125 + 32 kb + 8 kq -- a 16-byte read on a 2-byte boundary (LDS takes it,
+// tools/test_mfma_f16.hip).  A fragments [k-block][row tile][h | l][lane][8], streamed through LDS in chunks of four
+// k-blocks (128 taps) by LDS-DMA, double buffered, fetched once per workgroup.  Wave w: column tiles w and w + 4 x three
+// row tiles = six accumulators, 18 MFMAs per k-block on ten 16-byte reads.
+// ---------------------------------------------------------------------------
+#define FMR_POLY5H_KCH 4                       // k-blocks (of 32 taps) per A chunk
+typedef _Float16 fmr_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ fmr_h8 lds_read_h8(const void *p, int byte_off) {     // 16 bytes from any 2-byte boundary
+  fmr_h8 v;
+  // ("memory": the read must stay behind the barrier that publishes the planes / the chunk, which the compiler only
+  // orders against memory operations it knows about)
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p + (unsigned)byte_off) : "memory");
+  return v;
+}
+// Eight consecutive fp16 elements that start A elements (2 A bytes) past a 16-byte boundary: two aligned reads and a
+// funnel shift by a compile-time amount (a read on a 2-byte boundary works but costs ~20 aligned ones, measured).  The
+// reads are issued by issue(), the fragment is formed by get() once they have landed.
+template <int A>
+struct FmrH8Shifted {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u lo, hi;
+  __device__ __forceinline__ void issue(const void *p, int byte_off) {       // byte_off: where the fragment starts (= 2 A mod 16)
+    const unsigned addr = (unsigned)(size_t)p + (unsigned)(byte_off - 2 * A);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+    if (A != 0) asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(hi) : "v"(addr) : "memory");
+  }
+  __device__ __forceinline__ void pin() { asm volatile("" : "+v"(lo)); if (A != 0) asm volatile("" : "+v"(hi)); }
+  __device__ __forceinline__ fmr_h8 get() const {
+    constexpr int Q = (2 * A) / 4, R = (2 * A) % 4;
+    const unsigned d[8] = {lo.x, lo.y, lo.z, lo.w, A ? hi.x : 0u, A ? hi.y : 0u, A ? hi.z : 0u, A ? hi.w : 0u};
+    v4u o;
+    if (R == 0) o = (v4u){d[Q], d[Q + 1], d[Q + 2], d[Q + 3]};
+    else o = (v4u){__builtin_amdgcn_alignbyte(d[Q + 1], d[Q], R), __builtin_amdgcn_alignbyte(d[Q + 2], d[Q + 1], R),
+                   __builtin_amdgcn_alignbyte(d[Q + 3], d[Q + 2], R), __builtin_amdgcn_alignbyte(d[(Q + 4) & 7], d[Q + 3], R)};
+    fmr_h8 r;
+    __builtin_memcpy(&r, &o, 16);
+    return r;
+  }
+  static constexpr int kReads = A ? 2 : 1;
+};
+
+template <int LB, int MB>
+__global__ __launch_bounds__(256) void k_ifr_poly5h(
+    const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
+    const _Float16 *__restrict__ afrag, int n_kb, float inv_tap_scale, int TB, long long k0, int count,
+    float2 *__restrict__ out, long long out_stride, int out_off, int tile_len, int n_tiles) {
+  static_assert(LB == 48, "three 16-row tiles");
+  constexpr int KCH = FMR_POLY5H_KCH, MT = LB / 16, NWV = 4, NT = 256, NH = 2;
+  constexpr int CHB = KCH * MT * 2 * 64 * 16;                  // bytes per A chunk
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_5h[];
+  // elements per plane (slack: the last k-block of the last period); = 32 mod 64, so that the im planes start 32 banks
+  // away from the re planes
+  const int x_len = ((tile_len + 127) / 128) * 128 + 96;
+  _Float16 *pl = reinterpret_cast<_Float16 *>(lds_5h);        // [4][x_len]: re_h, re_l, im_h, im_l
+  unsigned char *abuf = lds_5h + (size_t)4 * x_len * 2;        // [2][CHB]
+  float2 *stage = reinterpret_cast<float2 *>(abuf + 2 * CHB);  // NWV x (8 periods x LB)
+  __shared__ float s_max[NWV];
+  const int s = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int W = TB >> 1;
+  const float2 *ms = mid + (long long)s * mid_stride;
+  float2 *os = out + (long long)s * out_stride + out_off;
+  float2 *mystage = stage + wave * (8 * LB);
+  const int n_chunks = n_kb / KCH;
+  auto fetch_a = [&](int c) {       // chunk c -> buffer c & 1: CHB / 1024 one-KB pieces, wave w issues pieces w, w + 4, ...
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(afrag) + (size_t)c * CHB;
+    unsigned char *dst = abuf + (c & 1) * CHB;
+    for (int p = wave; p < CHB / 1024; p += NWV)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
+  };
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long P0 = k0 / LB + (long long)tile * 64;
+    const long long a0 = P0 * MB - W + 1;
+    __syncthreads();                                          // previous tile fully consumed
+    fetch_a(0);
+    // ---- the window: maximum, scale, split into the four planes
+    auto ld = [&](int i) -> float2 {
+      const long long idx = a0 + i - mid_abs0;
+      return (i < tile_len && idx >= 0 && idx < mid_valid) ? ms[idx] : make_float2(0.f, 0.f);
+    };
+    // one pass over the window: every lane keeps its (up to 48) samples in registers across the maximum -- all its loads
+    // in flight at once, nothing read twice
+    constexpr int NPL = 48;                                    // x_len <= NPL * NT (checked by the host)
+    float2 wv[NPL];
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPL; u++) wv[u] = (tid + u * NT < x_len) ? ld(tid + u * NT) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NPL; u++) mx = fmaxf(mx, fmaxf(fabsf(wv[u].x), fabsf(wv[u].y)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    // 2^e with mx 2^e in [512, 1024); a window of zeros (or one that holds no finite maximum) is not scaled
+    int ex = 0;
+    if (mx > 0.f && mx < 3.0e38f) ex = 9 - (int)((__float_as_uint(mx) >> 23) & 0xff) + 127;
+    ex = max(-100, min(100, ex));
+    const float sc = __uint_as_float((unsigned)(127 + ex) << 23);
+    const float inv = __uint_as_float((unsigned)(127 - ex) << 23) * inv_tap_scale;
+#pragma unroll
+    for (int u = 0; u < NPL; u++) {
+      const int i = tid + u * NT;
+      if (i < x_len) {
+        const float xr = wv[u].x * sc, xi = wv[u].y * sc;
+        const _Float16 rh = (_Float16)xr, ih = (_Float16)xi;
+        pl[i] = rh; pl[x_len + i] = (_Float16)(xr - (float)rh);
+        pl[2 * x_len + i] = ih; pl[3 * x_len + i] = (_Float16)(xi - (float)ih);
+      }
+    }
+    // this lane's B columns: column tile t = wave + 4 h holds the periods t, t + 8, ... t + 56 (column n: period
+    // 8 (n / 2) + t, plane pair re / im by n & 1).  Eight periods apart the windows start 1000 elements = 500 dwords apart,
+    // 52 banks: the sixteen 16-byte reads of a half-wave fall on sixteen different bank quads (8 consecutive periods,
+    // 62.5 dwords apart, landed on top of each other: ~6 cycles per read instead of 1).
+    int bofs[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) bofs[h] = 2 * ((n & 1) * 2 * x_len + (8 * (n >> 1) + (wave + NWV * h)) * MB + 8 * kq);
+    v4f acc[NH][MT], tot[NH][MT];
+#pragma unroll
+    for (int h = 0; h < NH; h++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) tot[h][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    // Fragments of k-block k live in register set k & 1: the reads of the next k-block are issued BEFORE the 18 MFMAs of
+    // the current one (one wave per SIMD: nothing else hides the LDS latency).  Column tile t starts 125 t elements into
+    // the planes: 5 t mod 8 elements past a 16-byte boundary, the same for every lane and k-block -- a compile-time
+    // constant per wave (FmrH8Shifted).
+    auto run_chunks = [&](auto a0_tag, auto a1_tag) {
+      constexpr int A0 = decltype(a0_tag)::value, A1 = decltype(a1_tag)::value;
+      constexpr int NRD = 2 * FmrH8Shifted<A0>::kReads + 2 * FmrH8Shifted<A1>::kReads + 2 * MT;    // LDS reads per k-block
+      FmrH8Shifted<A0> b0h[2], b0l[2];
+      FmrH8Shifted<A1> b1h[2], b1l[2];
+      fmr_h8 ah[2][MT], al[2][MT];
+      auto read_b = [&](int set, int kb) {
+        b0h[set].issue(pl, bofs[0] + 64 * kb); b0l[set].issue(pl, bofs[0] + 64 * kb + 2 * x_len);
+        b1h[set].issue(pl, bofs[1] + 64 * kb); b1l[set].issue(pl, bofs[1] + 64 * kb + 2 * x_len);
+      };
+      auto read_a = [&](int set, const unsigned char *ab, int k) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          ah[set][mt] = lds_read_h8(ab, ((k * MT + mt) * 2 + 0) * 1024);
+          al[set][mt] = lds_read_h8(ab, ((k * MT + mt) * 2 + 1) * 1024);
+        }
+      };
+      for (int c = 0; c < n_chunks; c++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of chunk c have landed
+        __syncthreads();                                        // ... and everybody's (and the planes, c = 0); chunk c - 1's buffer is free
+        if (c + 1 < n_chunks) fetch_a(c + 1);
+        const unsigned char *ab = abuf + (c & 1) * CHB + lane * 16;
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) acc[h][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        read_b(0, c * KCH);
+        read_a(0, ab, 0);
+#pragma unroll
+        for (int k = 0; k < KCH; k++) {
+          const int cur = k & 1, nxt = cur ^ 1;
+          if (k + 1 < KCH) {
+            // the current set must have landed, the next one may stay in flight: LDS returns in order
+            read_b(nxt, c * KCH + k + 1);
+            read_a(nxt, ab, k + 1);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+          // (the MFMAs must depend on something behind the wait: every fragment through an empty asm)
+          b0h[cur].pin(); b0l[cur].pin(); b1h[cur].pin(); b1l[cur].pin();
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) { asm volatile("" : "+v"(ah[cur][mt])); asm volatile("" : "+v"(al[cur][mt])); }
+          const fmr_h8 bh[NH] = {b0h[cur].get(), b1h[cur].get()}, bl[NH] = {b0l[cur].get(), b1l[cur].get()};
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int h = 0; h < NH; h++) acc[h][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][mt], bh[h], acc[h][mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int h = 0; h < NH; h++) acc[h][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][mt], bl[h], acc[h][mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int h = 0; h < NH; h++) acc[h][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][mt], bh[h], acc[h][mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) tot[h][mt] += acc[h][mt];
+      }
+    };
+    // column tiles w and w + 4: 125 w and 125 (w + 4) elements in, i.e. (5 w) mod 8 and (5 w + 4) mod 8 past a boundary
+    static_assert(MB == 125, "the misalignment table below is 125 t mod 8");
+    using I = std::integral_constant<int, 0>;
+    switch (wave) {
+    case 0: run_chunks(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); break;
+    case 1: run_chunks(std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{}); break;
+    case 2: run_chunks(std::integral_constant<int, 2>{}, std::integral_constant<int, 6>{}); break;
+    default: run_chunks(std::integral_constant<int, 7>{}, std::integral_constant<int, 3>{}); break;
+    }
+    (void)sizeof(I);
+    // D[row = 4 kq + v][col = n] -> position p = 16 mt + 4 kq + v of period 8 (n / 2) + t, component n & 1
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      const int t = wave + NWV * h;
+      float *sf = reinterpret_cast<float *>(mystage);
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * LB + 16 * mt + 4 * kq + v) + (n & 1)] = tot[h][mt][v] * inv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave writes and reads its own staging area
+      const long long kb = P0 * LB - k0;                      // local output index of the tile's first sample
+#pragma unroll
+      for (int u = 0; u < (8 * LB) / 64; u++) {
+        const int idx = u * 64 + lane, j = idx / LB, pos = idx - j * LB;      // staged period j = period 8 j + t of the tile
+        const long long k = kb + (long long)(8 * j + t) * LB + pos;
+        if (k >= 0 && k < count) os[k] = mystage[idx];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_shift_halo : re-seat prefix halos at the end of a call.  All elements are
 // 8 bytes (float2 or double).  newhalo[i] = concat(halo,data)[i + N].
 // ---------------------------------------------------------------------------
