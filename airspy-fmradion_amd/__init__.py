@@ -312,7 +312,7 @@ class Chain:
         return buf[:2 * n].view(np.complex64).copy()
 
     def debug_read(self, which, stream=0, cap=1 << 24):
-        dt = {0: np.complex64, 1: np.float32, 2: np.float64, 3: np.float64, 4: np.float32}[which]
+        dt = {0: np.complex64, 1: np.float32, 2: np.float64, 3: np.float64, 4: np.float32, 5: np.uint64}[which]
         buf = np.empty(cap, dtype=dt)
         n = self._chk(lib().fmr_debug_read(self.h, stream, which, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
         return buf[:n].copy()

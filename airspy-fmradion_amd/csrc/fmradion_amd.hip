@@ -97,6 +97,9 @@ struct EnvKnobs {
   int pipeline = -1;            // FMR_PIPELINE=0/1   the three stages of a call (front end | PLL | audio tail) of consecutive calls
                                 //                    beside each other (1, the default for FM chains with the resampler) or one
                                 //                    in-order chain per call (0: the form the tests compare the product with)
+  bool mpf3 = false;            // FMR_MPF3=1         equaliser: the round-3 kernel (four waves meet in every group) instead of chain + helpers
+  bool agc_first = false;       // FMR_AGC_FIRST=1    equaliser: the AGC kernel in front of it instead of beside it (tools/mpf_rate.py times each alone)
+  bool mpf_account = false;     // FMR_MPF_ACCOUNT=1  equaliser kernel with cycle stamps at its phase boundaries (fmr_debug_read 5)
   int test_agc_late = 0;        // FMR_TEST_AGC_LATE=ms test hook (equaliser chain): the AGC kernel beside the equaliser starts this late; -1: never
   bool r8b_f32 = false;         // FMR_R8B_F32=1      R8B class: stage B as the f32 MFMA product (k_ifr_poly5) instead of the fp16
                                 //                    three-product form (tests: the two against each other)
@@ -111,7 +114,7 @@ struct EnvKnobs {
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
   void load() {
-    serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS"); r8b_f32 = on("FMR_R8B_F32");
+    serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS"); r8b_f32 = on("FMR_R8B_F32"); mpf_account = on("FMR_MPF_ACCOUNT"); agc_first = on("FMR_AGC_FIRST"); mpf3 = on("FMR_MPF3");
     auto num = [](const char *n, int dflt) { const char *e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
     pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0); test_agc_late = num("FMR_TEST_AGC_LATE", 0);
     host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED"); pll_v1 = set("FMR_PLL_V1");
@@ -195,6 +198,7 @@ struct fmr_chain {
   // FM with the equaliser: the serial IF AGC runs beside the equaliser kernel, which follows its progress counter
   // (IF samples of this call whose gain is in HBM, per stream; zeroed at the head of every call)
   DevBuf<unsigned long long> d_agc_progress;
+  DevBuf<unsigned long long> d_mpf_dbg;          // FMR_MPF_ACCOUNT=1: cycle sums of k_mpf3's phases (fmr_debug_read 5)
   std::vector<unsigned> agc_timeouts_seen;      // per stream: StreamState::agc_sync_timeouts already reported
   bool agc_beside_mpf = false;
   DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
@@ -290,7 +294,7 @@ struct fmr_chain {
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     for (auto &k : dom_times) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     d_in.release(); d_in_halo.release(); d_mid.release(); d_if.release(); d_fir.release();
-    d_mpf.release(); d_mpf_coeff.release(); d_mpf_state.release(); d_gain.release(); d_dec.release(); d_agc_progress.release();
+    d_mpf.release(); d_mpf_coeff.release(); d_mpf_state.release(); d_gain.release(); d_dec.release(); d_agc_progress.release(); d_mpf_dbg.release();
     d_hA.release(); d_hB.release(); d_coeff.release(); d_atan.release(); d_if_rms_blk.release();
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
@@ -904,6 +908,7 @@ int fmr_chain::init(const fmr_config *c) {
     if ((rc = d_mpf_state.alloc((size_t)S * mpf_N))) return rc;
     if (enable_mpf && (rc = d_mpf.alloc((size_t)S * max_if))) return rc;
     if (enable_mpf && (rc = d_agc_progress.alloc((size_t)S))) return rc;
+    if (enable_mpf && env.mpf_account && (rc = d_mpf_dbg.alloc(16))) return rc;
   } else if (mode == FMR_MODE_NBFM) {
     nbfm_freq_dev = (c->nbfm_freq_dev > 0) ? c->nbfm_freq_dev : 8000.0;  // NbfmDecode.h:39 freq_dev_normal
     agc_init = 1.0f; agc_max = 100000.0f; agc_rate = 0.0001f;           // NbfmDecode.cpp:43
@@ -1533,7 +1538,7 @@ int fmr_chain::run_if_stage(CallCtx &k) {
                        pll_tick2_per_stream);
   // With the equaliser on, the AGC'd amplitude feeds the constant-modulus error, and
   // the equaliser kernel is the serial bottleneck anyway: use the exact serial AGC.
-  if (enable_mpf && !serial_mode && mode == FMR_MODE_FM) {
+  if (enable_mpf && !serial_mode && mode == FMR_MODE_FM && !env.agc_first) {
     // beside the equaliser, which consumes the gains as they are published (k_if_agc / k_mpf3, kernels.hpp)
     // (the progress words count the samples of THIS call: zeroed here, in front of both kernels -- a call that failed
     // half way cannot leave a count behind that a later call would take for its own)
@@ -1544,14 +1549,18 @@ int fmr_chain::run_if_stage(CallCtx &k) {
       hipLaunchKernelGGL(k_hold_stream, dim3(1), dim3(1), 0, side2, (unsigned long long)env.test_agc_late * 100000ull);
     timed_on(side2, "if_agc", [&] {
       if (env.test_agc_late >= 0)   // (test hook, < 0: the AGC kernel is not launched at all)
-      hipLaunchKernelGGL(k_if_agc, dim3((S + 63) / 64), dim3(64), 0, side2, xin, x_stride, x_off, (int)N_if, d_gain.p,
-                         (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_agc_progress.p);
+      hipLaunchKernelGGL(k_if_agc_wave, dim3(S), dim3(64), 0, side2, xin, x_stride, x_off, (int)N_if, d_gain.p,
+                         (long long)max_if, d_state.p, agc_init, agc_max, agc_rate, d_agc_progress.p);
     });
     HIPCHK(hipEventRecord(ev_agc, side2));
     ev_agc_live = true;
     agc_beside_mpf = true;
   } else if (serial_mode || enable_mpf) {
     timed("if_agc", [&] {
+      if (enable_mpf && !serial_mode)
+        hipLaunchKernelGGL(k_if_agc_wave, dim3(S), dim3(64), 0, stream, xin, x_stride, x_off, (int)N_if, d_gain.p,
+                           (long long)max_if, d_state.p, agc_init, agc_max, agc_rate, (unsigned long long *)nullptr);
+      else
       hipLaunchKernelGGL(k_if_agc, dim3((S + 63) / 64), dim3(64), 0, stream, xin, x_stride, x_off, (int)N_if, d_gain.p,
                          (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, (unsigned long long *)nullptr);
     });
@@ -1728,12 +1737,28 @@ int fmr_chain::run_fm(CallCtx &k) {
         hipLaunchKernelGGL(kern, dim3(S), dim3(threads), bytes, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
                            bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
                            d_mpf_ok.p, d_state.p, agc_beside_mpf ? d_agc_progress.p : (const unsigned long long *)nullptr,
+                           kAgcWaitTicks, d_mpf_dbg.p);
+      };
+      // the chain-and-helpers form (k_mpf4: no barrier inside a chunk); FMR_MPF3=1 keeps the four-waves-meet-per-group form
+      constexpr int NG4 = FMR_MPF_CH / 4 + 2;
+      const int tpl4 = mpf_N <= 320 ? 5 : mpf_N <= 640 ? 10 : 20;
+      const size_t lds4 = sizeof(float2) * ((size_t)mpf_N + FMR_MPF_CH + 8) + sizeof(float) * NG4 + sizeof(float2) * FMR_MPF_CH +
+                          sizeof(double) * NG4 + sizeof(float2) * (tpl4 <= 10 ? 16 : 8) * 64 * (size_t)tpl4 + sizeof(int) * 16 +
+                          sizeof(float2);
+      auto go4 = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        hipLaunchKernelGGL(kern, dim3(S), dim3(256), lds4, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
+                           bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
+                           d_mpf_ok.p, d_state.p, agc_beside_mpf ? d_agc_progress.p : (const unsigned long long *)nullptr,
                            kAgcWaitTicks);
       };
-      // four waves per stream (kernels.hpp), taps per lane and row by equaliser length
-      if (mpf_N <= 64 * 5) go(k_mpf3<4, 5>, 256, lds3);
+      if (env.mpf_account && mpf_N <= 64 * 5) go(k_mpf3<4, 5, true>, 256, lds3);        // cycle account (tools/mpf_account.py)
+      else if (!env.mpf3 && mpf_N <= 64 * 5) go4(k_mpf4<5>);
+      else if (!env.mpf3 && mpf_N <= 64 * 10) go4(k_mpf4<10>);
+      else if (!env.mpf3 && mpf_N <= 64 * 20) go4(k_mpf4<20>);                                     // N <= 1280
+      else if (mpf_N <= 64 * 5) go(k_mpf3<4, 5>, 256, lds3);
       else if (mpf_N <= 64 * 10) go(k_mpf3<4, 10>, 256, lds3);
-      else if (mpf_N <= 64 * 20) go(k_mpf3<4, 20>, 256, lds3);                                   // N <= 1280
+      else if (mpf_N <= 64 * 20) go(k_mpf3<4, 20>, 256, lds3);
       else set_err("equaliser length out of range");
     });
   }
@@ -2311,6 +2336,10 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
   case 2: src = c->d_raw_de.p ? c->d_raw_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 3: src = c->d_base_de.p ? c->d_base_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 4: src = (c->d_gain.p && c->gain_valid) ? c->d_gain.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
+  case 5:      // FMR_MPF_ACCOUNT=1: nine 64-bit counters (cycle sums of the five phases of a group, [8] = groups)
+    if (!c->d_mpf_dbg.p || cap_bytes < 9 * 8) return FMR_ERR_BAD_ARG;
+    HIPCHK(hipMemcpy(out, c->d_mpf_dbg.p, 9 * 8, hipMemcpyDeviceToHost));
+    return 9;
   default: return FMR_ERR_BAD_ARG;
   }
   if (!src) return FMR_ERR_BAD_ARG;

@@ -1427,6 +1427,74 @@ __global__ void k_if_agc(const float2 *__restrict__ x, long long x_stride, int x
   if (progress) publish(n);
 }
 
+// The same recurrence with one WAVE per stream, for the equaliser's chain (k_mpf4 runs beside it and consumes the gains as
+// they are published).  The recurrence is serial whatever runs it; what one lane per stream pays on top is a memory
+// instruction per sample (a 4-byte write-through store, an 8-byte load) -- 168 ns per sample beside the equaliser.  Here
+// the wave loads 64 samples with one instruction, every lane runs the same chain on v_readlane'd samples, lane u keeps
+// the gain of sample u, and one 256-byte store writes 64 gains: ~17 instructions per sample, none of them memory.
+// Bit-identical to k_if_agc (same operations in the same order on the same values).
+__global__ __launch_bounds__(64) void k_if_agc_wave(const float2 *__restrict__ x, long long x_stride, int x_off, int n,
+                                                    float *__restrict__ gain, long long g_stride, StreamState *st,
+                                                    float initial_gain, float max_gain, float rate,
+                                                    unsigned long long *__restrict__ progress) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const float2 *xs = x + (long long)s * x_stride + x_off;
+  float *gs = gain + (long long)s * g_stride;
+  float g = st[s].agc_gain;
+  const double r = (double)rate;
+  auto ld = [&](int i0) { const int i = i0 + lane; return i < n ? xs[i] : make_float2(0.f, 0.f); };
+  auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+  float2 v = ld(0);
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const float2 vn = ld(i0 + 64);
+    const int cnt = min(64, n - i0);
+    float gv = 0.f;
+    auto chain = [&](float sx, float sy) {
+      const float xr = sx * g, xi = sy * g;
+      const float nrm = xr * xr + xi * xi;
+      const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
+      const float g2 = g * z;
+      const float gm = (g2 > max_gain) ? max_gain : g2;       // (selects, not branches: the values are uniform and the
+      g = isfinite(g2) ? gm : initial_gain;                    //  compiler would branch on them, 64 times per pass)
+    };
+    if (cnt == 64) {
+      auto body = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const int sg = __builtin_amdgcn_readfirstlane(__float_as_int(g));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(gv) : "s"(sg), "n"(u));
+        chain(rl(v.x, u), rl(v.y, u));
+      };
+      auto all = [&](auto... uc) { (body(uc), ...); };
+      auto run = [&](auto base) {
+        constexpr int B = decltype(base)::value;
+        all(std::integral_constant<int, B>{}, std::integral_constant<int, B + 1>{}, std::integral_constant<int, B + 2>{},
+            std::integral_constant<int, B + 3>{}, std::integral_constant<int, B + 4>{}, std::integral_constant<int, B + 5>{},
+            std::integral_constant<int, B + 6>{}, std::integral_constant<int, B + 7>{});
+      };
+      run(std::integral_constant<int, 0>{}); run(std::integral_constant<int, 8>{}); run(std::integral_constant<int, 16>{});
+      run(std::integral_constant<int, 24>{}); run(std::integral_constant<int, 32>{}); run(std::integral_constant<int, 40>{});
+      run(std::integral_constant<int, 48>{}); run(std::integral_constant<int, 56>{});
+    } else {
+      for (int u = 0; u < cnt; u++) {
+        gv = (lane == u) ? g : gv;
+        chain(rl(v.x, u), rl(v.y, u));
+      }
+    }
+    if (lane < cnt) {
+      if (progress) __hip_atomic_store(gs + i0 + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else gs[i0 + lane] = gv;
+    }
+    const int done = i0 + cnt;
+    if (progress && ((done & 255) == 0 || done == n)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(progress + s, (unsigned long long)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    v = vn;
+  }
+  if (lane == 0) st[s].agc_gain = g;
+  if (progress && n == 0 && lane == 0) __hip_atomic_store(progress + s, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // test hook (FMR_TEST_AGC_LATE): keeps a stream busy for `ticks` of the 100 MHz clock, so that the AGC kernel behind it
 // starts late and the equaliser beside it has to wait (tests/test_gpu_configs.py)
 __global__ void k_hold_stream(unsigned long long ticks) {
@@ -1492,15 +1560,27 @@ __device__ __forceinline__ float row_sum_dpp(float v) {        // every lane of 
   return v;
 }
 
-template <int NW, int TPLR>
+// DBG: cycle account of a group (tools/mpf_account.py): s_memtime stamps at the phase boundaries, each behind a wait for
+// what the phase started (so the phases do not overlap as they do in the product: the sum is an upper bound of the group),
+// sums over all groups of the call in dbg[0..7], the group count in dbg[8].
+template <int NW, int TPLR, bool DBG = false>
 __global__ __launch_bounds__(64 * NW) void k_mpf3(
     const float2 *__restrict__ xin, long long x_stride, int x_off,
     const float *__restrict__ gain, long long g_stride, BlockTab bt,
     float2 *__restrict__ out, long long out_stride, float2 *__restrict__ coeff_g,
     float2 *__restrict__ state_g, int N, int ref, int *__restrict__ mpf_ok, StreamState *st,
-    const unsigned long long *__restrict__ progress = nullptr, unsigned wait_ticks = 0u) {
+    const unsigned long long *__restrict__ progress = nullptr, unsigned wait_ticks = 0u,
+    unsigned long long *__restrict__ dbg = nullptr) {
   typedef float v2f __attribute__((ext_vector_type(2)));
   constexpr int NT = 64 * NW, SL = 16 * NW;      // SL: taps per slice j (one per row lane of every wave)
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tgroups = 0, tmark = 0;
+  auto stamp = [&](int slot) {
+    if (!DBG) return;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long now = __builtin_readcyclecounter();
+    if (slot >= 0) tacc[slot] += now - tmark;
+    tmark = now;
+  };
   extern __shared__ float2 lds_m[];
   float2 *xw = lds_m;                                                     // [N + CH + 8]
   float *smu = reinterpret_cast<float *>(xw + N + FMR_MPF_CH + 8);        // [CH / 4 + 2]
@@ -1583,14 +1663,22 @@ __global__ __launch_bounds__(64 * NW) void k_mpf3(
         // state after the push of sample q+t = xw[q+t+1 .. q+t+N]; y = sum state[i]*coeff[i] (V9); this row: t = row.
         // All LDS reads first (lanes past the last tap read a clamped address against a zero coefficient), then the
         // multiply-accumulates on two chains: no branch and one wait inside the step.
+        stamp(-1);
         float2 sv[TPLR], sl[TPLR];                              // sl: state values of the group's LAST output (update operand)
 #pragma unroll
         for (int j = 0; j < TPLR; j++) { sv[j] = xw[q + 1 + row + ic[j]]; sl[j] = xw[qlast + 1 + ic[j]]; }
+        if (DBG) {
+#pragma unroll
+          for (int j = 0; j < TPLR; j++) { asm volatile("" : "+v"(sv[j].x), "+v"(sv[j].y), "+v"(sl[j].x), "+v"(sl[j].y)); }
+        }
+        stamp(0);                                               // 0: the ten LDS reads of the state window
         v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < TPLR; j++) mpf_cmac((j & 1) ? acc1 : acc0, sv[j], c[j]);
         const v2f acc = acc0 + acc1;
-        const float ax = row_sum_dpp(acc.x), ay = row_sum_dpp(acc.y);
+        float ax = row_sum_dpp(acc.x), ay = row_sum_dpp(acc.y);
+        if (DBG) asm volatile("" : "+v"(ax), "+v"(ay));
+        stamp(1);                                               // 1: complex MACs + DPP row sums
         float2 y[4];
         if (NW == 1) {                                          // one wave: the four row sums travel through SGPRs
 #pragma unroll
@@ -1609,6 +1697,8 @@ __global__ __launch_bounds__(64 * NW) void k_mpf3(
           }
           buf ^= 1;
         }
+        if (DBG) { asm volatile("" : "+v"(y[0].x), "+v"(y[1].x), "+v"(y[2].x), "+v"(y[3].x)); }
+        stamp(2);                                               // 2: exchange between the waves (LDS write, barrier, reads, adds)
         bool fin = true;
 #pragma unroll
         for (int t = 0; t < 4; t++) fin = fin && (t >= glen || (isfinite(y[t].x) && isfinite(y[t].y)));
@@ -1625,6 +1715,7 @@ __global__ __launch_bounds__(64 * NW) void k_mpf3(
           if (tid < glen) yo[q + tid] = yv;                     // put its round trip (vmcnt) into the chain
           stored = q + glen;
         }
+        stamp(3);                                               // 3: finite checks + the outputs into LDS
         if ((((c0 + qlast) & 3) == 0)) {                        // :176,186
           const float2 yl = glen == 1 ? y[0] : glen == 2 ? y[1] : glen == 3 ? y[2] : y[3];
           const double env = (double)(yl.x * yl.x + yl.y * yl.y);
@@ -1643,6 +1734,12 @@ __global__ __launch_bounds__(64 * NW) void k_mpf3(
           err_last = error;
           if (!isfinite(error)) { ok = 0; break; }                   // :190-192
         }
+        if (DBG) {
+#pragma unroll
+          for (int j = 0; j < TPLR; j++) asm volatile("" : "+v"(c[j].x), "+v"(c[j].y));
+        }
+        stamp(4);                                               // 4: error, factor, coefficient update
+        tgroups++;
         q += glen;
       }
       // new state = last N entries pushed so far
@@ -1670,6 +1767,328 @@ __global__ __launch_bounds__(64 * NW) void k_mpf3(
   if (row == 0) {
 #pragma unroll
     for (int j = 0; j < TPLR; j++) { const int i = SL * j + 16 * w + r16; if (i < N) cg[i] = c[j]; }
+  }
+  if (tid == 0) { st[s].mpf_error = err_last; st[s].mpf_resets = resets; }
+  if (DBG && dbg && tid == 0 && s == 0) {
+    for (int i = 0; i < 6; i++) dbg[i] += tacc[i];
+    dbg[8] += tgroups;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K_mpf v4 (round 4): a CHAIN wave and three HELPER waves, no barrier inside a chunk.
+// The cycle account of k_mpf3 (tools/mpf_account.py: 2100 cycles per group of four samples, of which the ten LDS reads
+// and the complex MACs are 150; the exchange between the four waves through LDS and a barrier, the error / factor chain
+// and the coefficient update the rest) says what a group costs is not its arithmetic but that four waves meet in every
+// group -- and that a single wave issues one instruction every four to five cycles whatever its kind, so the chain's
+// INSTRUCTION COUNT is its time.  The coefficients only change after every fourth sample (MultipathFilter.cpp:176,186),
+// and only the output of THAT sample feeds the update, so:
+//   * wave 0, the chain: holds all N taps (TPL per lane), computes the dot product of the group's update sample alone
+//     (2 TPL packed FMAs per lane, then ONE reduction for both components: v_permlane32_swap folds the real parts
+//     into lanes 0-31 and the imaginary parts into lanes 32-63, four DPP steps and a row_bcast:15 finish it, two
+//     v_readlane fetch the result), error -> factor (:115-135), updates its taps (:139; 2 TPL packed FMAs) and writes them
+//     into a ring of coefficient snapshots in LDS;
+//   * waves 1..3, the helpers: each computes ONE of the group's other three outputs from the snapshot of that group --
+//     behind the chain, which never waits for them (it looks at their progress every RING/2-th group: the ring must not
+//     lap them; they look at the chain's progress only when they have caught up with what they last saw).
+// What keeps the chain short:
+//   * tap (j, lane) is coefficient (ref + 64 j + lane) mod 64 TPL: the reference tap (:158) is lane 0 of j = 0 for every
+//     equaliser length, its reset two v_cndmask; a lane without a tap (index >= N) reads a zero cell instead of the
+//     window (address = position * stride + base with stride 0), so its coefficient stays zero without a select;
+//   * nobody looks for non-finite values (:182-184,190-192) inside the chunk: once an output or an error is not finite
+//     everything behind it is not either (the taps are), so the chunk's epilogue scans the outputs and the errors for the
+//     FIRST bad one, restores what the reference would have left (the state up to that sample, the error of the last
+//     update before it) and ends the block;
+//   * mu of every update position (:130) comes from a prefix sum of |x|^2 over the chunk (fp64), not from a window sum per
+//     position;
+//   * flags and snapshots are read and written through address-space-3 pointers: a volatile access through a generic
+//     pointer is a FLAT instruction, 400 cycles each on LDS.
+// Summation order of a dot product: per lane two chains over its taps (j even / odd), then the wave sum; the update is
+// fused multiply-adds where the reference rounds the products first -- as far from the reference's VOLK kernels as
+// k_mpf3's order was, and within the same tolerances (hazard H7).
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) int fmr_lds_int;
+typedef float fmr_v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) fmr_v2f fmr_lds_v2f;
+__device__ __forceinline__ int lds_ld_volatile(const int *p) { return *(const volatile fmr_lds_int *)(fmr_lds_int *)(p); }
+__device__ __forceinline__ void lds_st_volatile(int *p, int v) { *(volatile fmr_lds_int *)(fmr_lds_int *)(p) = v; }
+__device__ __forceinline__ float2 lds_ld_volatile2(const float2 *p) {
+  const fmr_v2f v = *(const volatile fmr_lds_v2f *)(fmr_lds_v2f *)(p);
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ unsigned lds_offset(const void *p) { return (unsigned)(size_t)(const fmr_lds_int *)(p); }
+__device__ __forceinline__ float2 lds_ld2_at(unsigned byte_off) {
+  const fmr_v2f v = *(const fmr_lds_v2f *)(size_t)byte_off;
+  return make_float2(v.x, v.y);
+}
+// c += conj(s) * f   (:139: c.x += s.x f.x + s.y f.y,  c.y += s.x f.y - s.y f.x)
+__device__ __forceinline__ void mpf_cupd(fmr_v2f &c, float2 sv, fmr_v2f f) {
+  const fmr_v2f s = {sv.x, sv.y};
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "v"(s), "v"(f));                                   // += s.x * (f.x, f.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "+v"(c) : "v"(s), "v"(f));      // += s.y * (f.y, -f.x)
+}
+__device__ __forceinline__ void mpf_cmac2(fmr_v2f &acc, float2 sv, fmr_v2f c) {     // acc += s * c
+  const fmr_v2f s = {sv.x, sv.y};
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(s), "v"(c));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(acc) : "v"(s), "v"(c));
+}
+// sum of a complex value over the wave, as two scalars
+__device__ __forceinline__ void wave_sum_c(fmr_v2f a, float &sx, float &sy) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(a.y), false, false);
+  float t = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);     // lanes 0-31: real parts of lanes l and l + 32; lanes 32-63: imaginary
+  auto dpp_add = [](float x, auto ctrl, auto rows) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xF, true));
+  };
+  t = dpp_add(t, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});    // quad_perm [1,0,3,2]
+  t = dpp_add(t, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});    // quad_perm [2,3,0,1]
+  t = dpp_add(t, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});   // row_half_mirror
+  t = dpp_add(t, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});   // row_mirror: every lane of a row = the row's sum
+  t = dpp_add(t, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});   // row_bcast:15 into rows 1 and 3
+  sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 16));
+  sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 48));
+}
+template <int TPL>
+__global__ __launch_bounds__(256) void k_mpf4(
+    const float2 *__restrict__ xin, long long x_stride, int x_off,
+    const float *__restrict__ gain, long long g_stride, BlockTab bt,
+    float2 *__restrict__ out, long long out_stride, float2 *__restrict__ coeff_g,
+    float2 *__restrict__ state_g, int N, int ref, int *__restrict__ mpf_ok, StreamState *st,
+    const unsigned long long *__restrict__ progress, unsigned wait_ticks) {
+  constexpr int NT = 256, CH = FMR_MPF_CH, NG = CH / 4 + 2, M = 64 * TPL;
+  constexpr int RING = (TPL <= 10) ? 16 : 8, LOOK = RING / 2;           // (the ring is the largest array: 160 KB of LDS hold 8 slots of 1280 taps)
+  constexpr int NOBAD = 0x7fffffff;
+  extern __shared__ float2 lds_m[];
+  float2 *xw = lds_m;                                                     // [N + CH + 8]
+  float *smu = reinterpret_cast<float *>(xw + N + CH + 8);                // [NG]
+  float2 *yo = reinterpret_cast<float2 *>(smu + NG);                      // [CH] outputs of the chunk
+  double *errs = reinterpret_cast<double *>(yo + CH);                     // [NG] error after update k of the chunk
+  float2 *snap = reinterpret_cast<float2 *>(errs + NG);                   // [RING][M] coefficients of group g in slot g % RING
+  int *ctl = reinterpret_cast<int *>(snap + RING * M);                    // [0] updates published by the chain, [1..3] groups done
+                                                                          // by helper h, [4] first bad event of the chunk
+  float2 *zcell = reinterpret_cast<float2 *>(ctl + 16);                   // [1] zero: what a lane without a tap reads
+  double *psum = reinterpret_cast<double *>(snap + M);                    // [N + CH + 1] prefix sums of |x|^2 (slots 1.. of the ring,
+  double *ptot = psum + (N + CH + 2);                                     //  free until the chain starts) and [NT] segment totals
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float2 *xs = xin + (long long)s * x_stride + x_off;
+  const float *gs = gain + (long long)s * g_stride;
+  float2 *os = out + (long long)s * out_stride;
+  float2 *cg = coeff_g + (long long)s * N;
+  float2 *sg = state_g + (long long)s * N;
+  fmr_v2f c[TPL];
+  unsigned wstr[TPL], wbas[TPL];          // window address of tap j at chunk position p: p * wstr + wbas (bytes)
+  int tapi[TPL];
+#pragma unroll
+  for (int j = 0; j < TPL; j++) {
+    const int i = (ref + 64 * j + lane) % M;
+    const bool v = i < N;
+    tapi[j] = v ? i : -1;
+    const float2 cv = v ? cg[i] : make_float2(0.f, 0.f);
+    c[j] = fmr_v2f{cv.x, cv.y};
+    wstr[j] = v ? 8u : 0u;
+    wbas[j] = v ? lds_offset(xw + 1 + i) : lds_offset(zcell);
+  }
+  if (tid == 0) zcell[0] = make_float2(0.f, 0.f);
+  double err_last = st[s].mpf_error;
+  unsigned resets = st[s].mpf_resets;
+  bool gave_up = false;
+  auto ldwin = [&](float2 (&d)[TPL], int p) {
+#pragma unroll
+    for (int j = 0; j < TPL; j++) d[j] = lds_ld2_at(__umul24((unsigned)p, wstr[j]) + wbas[j]);
+  };
+  auto dot = [&](const float2 (&sv)[TPL], float &yx, float &yy) {
+    fmr_v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TPL; j++) mpf_cmac2((j & 1) ? a1 : a0, sv[j], c[j]);
+    wave_sum_c(a0 + a1, yx, yy);
+  };
+  for (int b = 0; b < bt.nb; b++) {
+    const int n = bt.if_len[b];
+    int ok = 1;
+    if (n == 0 || !bt.mpf_active[b]) {
+      if (tid == 0) mpf_ok[(long long)s * bt.nb + b] = 0;
+      continue;
+    }
+    const int off = bt.if_off[b];
+    for (int i = tid; i < N; i += NT) xw[i] = sg[i];
+    __syncthreads();
+    for (int c0 = 0; c0 < n && ok; c0 += CH) {
+      const int cn = min(CH, n - c0);
+      if (progress && !gave_up) {       // (the AGC kernel beside this one: see k_mpf3)
+        if (tid == 0) {
+          const unsigned long long need = (unsigned long long)(off + c0 + cn);
+          const unsigned long long t_lim = wall_clock64() + wait_ticks;
+          bool there = false;
+          for (;;) {
+            if (__hip_atomic_load(progress + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) { there = true; break; }
+            if (wall_clock64() > t_lim) break;
+            __builtin_amdgcn_s_sleep(8);
+          }
+          if (!there) { st[s].agc_sync_timeouts++; ctl[0] = -1; } else ctl[0] = 0;
+        }
+        __syncthreads();
+        gave_up = ctl[0] < 0;
+        __syncthreads();
+      }
+      for (int i = tid; i < cn; i += NT) {
+        const float2 v = xs[off + c0 + i];
+        const float g = progress ? __hip_atomic_load(gs + off + c0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gs[off + c0 + i];
+        xw[N + i] = make_float2(v.x * g, v.y * g);
+      }
+      if (tid < 8) xw[N + cn + tid] = make_float2(0.f, 0.f);
+      if (tid < 16) ctl[tid] = (tid == 4) ? NOBAD : 0;
+      if (w == 0) {                                                  // the coefficients the chunk starts with: snapshot 0
+#pragma unroll
+        for (int j = 0; j < TPL; j++) snap[64 * j + lane] = make_float2(c[j].x, c[j].y);
+      }
+      __syncthreads();
+      // mu of every update position of the chunk: p = q0 + 4 k, window xw[p + 1 .. p + N] = psum[p + 1 + N] - psum[p + 1]
+      const int q0 = (4 - (c0 & 3)) & 3;
+      const int nu = (q0 < cn) ? (cn - q0 + 3) / 4 : 0;
+      {
+        const int L = N + cn, seg = (L + NT - 1) / NT, i0 = tid * seg, i1 = min(L, i0 + seg);
+        double acc = 0.0;
+        for (int i = i0; i < i1; i++) { const float2 v = xw[i]; acc += (double)(v.x * v.x + v.y * v.y); }
+        ptot[tid] = acc;
+        __syncthreads();
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int t = 0;
+        for (; t + 4 <= tid; t += 4) { a0 += ptot[t]; a1 += ptot[t + 1]; a2 += ptot[t + 2]; a3 += ptot[t + 3]; }
+        for (; t < tid; t++) a0 += ptot[t];
+        double run = (a0 + a1) + (a2 + a3);
+        for (int i = i0; i < i1; i++) { psum[i] = run; const float2 v = xw[i]; run += (double)(v.x * v.x + v.y * v.y); }
+        if (i1 == L && i0 < i1) psum[L] = run;
+        __syncthreads();
+        for (int k = tid; k < nu; k += NT) {
+          const int p = q0 + 4 * k;
+          const double e = psum[p + 1 + N] - psum[p + 1];
+          smu[k] = (float)(0.1 / ((double)(float)e + 1e-10));        // :130
+        }
+        __syncthreads();
+      }
+      // ---- the groups of the chunk: group k = the outputs behind update k - 1 up to and including update position
+      // q0 + 4 k; the last group (k = nu) is what follows the last update position, without an update
+      const int u_last = q0 + 4 * (nu - 1);          // (nu = 0: -4 or less, every sample is in the last group)
+      const bool has_tail = cn - 1 > u_last;
+      if (w == 0) {
+        // ================================================================ chain
+        float2 sA[TPL], sB[TPL];
+        auto step = [&](const float2 (&sl)[TPL], float2 (&sn)[TPL], int k) {
+          const int p = q0 + 4 * k;
+          const float mu = smu[k];
+          ldwin(sn, (k + 1 < nu) ? p + 4 : cn - 1);        // the next group's window: issued now, used after this group's update
+          float yx, yy;
+          dot(sl, yx, yy);
+          yo[p] = make_float2(yx, yy);
+          const double env = (double)(yx * yx + yy * yy);
+          const double error = 1.0 - env;
+          const float factor = (float)(error * (double)mu);         // :133
+          const fmr_v2f f = {factor * yx, factor * yy};
+#pragma unroll
+          for (int j = 0; j < TPL; j++) mpf_cupd(c[j], sl[j], f);
+          if (lane == 0) c[0] = fmr_v2f{1.f, 0.f};                   // :158
+          float2 *sp = snap + ((k + 1) & (RING - 1)) * M;            // the coefficients of group k + 1
+#pragma unroll
+          for (int j = 0; j < TPL; j++) sp[64 * j + lane] = make_float2(c[j].x, c[j].y);
+          errs[k] = error;
+          asm volatile("" ::: "memory");     // (LDS executes a wave's operations in order: the flag lands behind the snapshot)
+          lds_st_volatile(ctl, k + 1);
+          if (((k + 1) & (LOOK - 1)) == 0) {           // the ring must not lap the helpers
+            for (;;) {
+              const int h1 = lds_ld_volatile(ctl + 1), h2 = lds_ld_volatile(ctl + 2), h3 = lds_ld_volatile(ctl + 3);
+              if (min(h1, min(h2, h3)) + (RING - LOOK - 1) >= k + 1) break;   // helpers read slot >= k + 1 - (LOOK - 1) - ..., the chain writes <= k + LOOK
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+        };
+        ldwin(sA, nu > 0 ? q0 : cn - 1);
+        int k = 0;
+        for (; k + 2 <= nu; k += 2) { step(sA, sB, k); step(sB, sA, k + 1); }
+        if (k < nu) {
+          step(sA, sB, k);
+#pragma unroll
+          for (int j = 0; j < TPL; j++) sA[j] = sB[j];
+        }
+        if (has_tail) { float yx, yy; dot(sA, yx, yy); yo[cn - 1] = make_float2(yx, yy); }
+      } else {
+        // ================================================================ helper w: the output w samples before the group's last
+        int known = 0;          // updates the chain had published when last looked at
+        fmr_v2f keep[TPL];
+#pragma unroll
+        for (int j = 0; j < TPL; j++) keep[j] = c[j];
+        for (int g = 0; g <= nu; g++) {
+          if (g == nu && !has_tail) break;
+          const int p_end = (g < nu) ? q0 + 4 * g : cn - 1, p_lo = (g > 0) ? q0 + 4 * (g - 1) : -1;
+          const int p = p_end - w;                                  // my sample of this group (if it belongs to it)
+          if (p > p_lo) {
+            float2 sv[TPL];
+            ldwin(sv, p);
+            if (g > known) {                                        // caught up with what I last saw of the chain: look again
+              do { known = lds_ld_volatile(ctl); if (known < g) __builtin_amdgcn_s_sleep(1); } while (known < g);
+            }
+            const float2 *sp = snap + (g & (RING - 1)) * M;
+#pragma unroll
+            for (int j = 0; j < TPL; j++) { const float2 cv = lds_ld_volatile2(sp + 64 * j + lane); c[j] = fmr_v2f{cv.x, cv.y}; }
+            float yx, yy;
+            dot(sv, yx, yy);
+            yo[p] = make_float2(yx, yy);
+          }
+          lds_st_volatile(ctl + w, g + 1);
+        }
+#pragma unroll
+        for (int j = 0; j < TPL; j++) c[j] = keep[j];
+      }
+      __syncthreads();
+      // ---- what the reference would have left behind: the earliest bad sample ends the block (:182-184,190-192).
+      // Event key = 2 * position + (1 if it is the error of that position's update that is not finite, its output being so)
+      {
+        int key = NOBAD;
+        for (int i = tid; i < cn; i += NT) {
+          const float2 y = yo[i];
+          if (!(isfinite(y.x) && isfinite(y.y))) { key = 2 * i; break; }
+        }
+        for (int k = tid; k < nu; k += NT)
+          if (!isfinite(errs[k])) { key = min(key, 2 * (q0 + 4 * k) + 1); break; }
+        if (key != NOBAD) atomicMin(ctl + 4, key);
+      }
+      __syncthreads();
+      const int key = ctl[4];
+      int pushed = cn, stored = cn;
+      if (key != NOBAD) {
+        const int bad = key >> 1;
+        ok = 0;
+        pushed = bad + 1;
+        stored = bad;                                                // (the block falls back to the AGC output anyway)
+        if (key & 1) err_last = errs[(bad - q0) >> 2];               // :190-192: the error of THIS update stands
+        else {
+          const int gp = (bad <= q0) ? 0 : (bad - q0 + 3) >> 2;      // the group of the bad output: updates 0 .. gp - 1 came before it
+          if (gp > 0) err_last = errs[gp - 1];
+        }
+      } else if (nu > 0) err_last = errs[nu - 1];
+      // new state = last N entries pushed so far
+      for (int i = tid; i < stored; i += NT) os[off + c0 + i] = yo[i];
+      constexpr int TPS = (M + NT - 1) / NT + 1;
+      float2 tmp[TPS];
+#pragma unroll
+      for (int j = 0; j < TPS; j++) { const int i = tid + NT * j; tmp[j] = (i < N) ? xw[pushed + i] : make_float2(0.f, 0.f); }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TPS; j++) { const int i = tid + NT * j; if (i < N) xw[i] = tmp[j]; }
+      __syncthreads();
+    }
+    for (int i = tid; i < N; i += NT) sg[i] = xw[i];
+    if (!ok) {
+      // FmDecode.cpp:117-123: re-initialise the taps, block falls back to the AGC output
+#pragma unroll
+      for (int j = 0; j < TPL; j++) c[j] = fmr_v2f{tapi[j] == ref ? 1.f : 0.f, 0.f};
+      resets++;
+    }
+    if (tid == 0) mpf_ok[(long long)s * bt.nb + b] = ok;
+    __syncthreads();
+  }
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < TPL; j++) if (tapi[j] >= 0) cg[tapi[j]] = make_float2(c[j].x, c[j].y);
   }
   if (tid == 0) { st[s].mpf_error = err_last; st[s].mpf_resets = resets; }
 }
