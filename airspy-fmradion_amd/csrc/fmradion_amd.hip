@@ -233,7 +233,7 @@ struct fmr_chain {
   DevBuf<float> d_hpA;                 // stage-A taps in polyphase order [D][Q] (k_ifr_decim2)
   int qa = 0;                          // taps per phase (even), 0 = v2 kernel not applicable
   int hB_pitch = 0;                    // fractional-phase stage B: row pitch of d_hB (floats)
-  DevBuf<float> d_gain, d_dec, d_hA, d_hB, d_coeff, d_atan, d_if_rms_blk, d_bb_mean_blk, d_bb_rms_blk;
+  DevBuf<float> d_gain, d_dec, d_hA, d_hB, d_coeff, d_atan, d_if_rms_blk, d_bb_mean_blk, d_bb_rms_blk, d_blk_ph;
   DevBuf<double> d_base, d_raw, d_am0, d_am1, d_a10, d_a11, d_pc0, d_pc1, d_audio, d_ahA, d_ahB, d_pilotcut;
   DevBuf<int> d_tab, d_mpf_ok, d_stereo_blk;
   DevBuf<StreamState> d_state;
@@ -296,7 +296,7 @@ struct fmr_chain {
     d_in.release(); d_in_halo.release(); d_mid.release(); d_if.release(); d_fir.release();
     d_mpf.release(); d_mpf_coeff.release(); d_mpf_state.release(); d_gain.release(); d_dec.release(); d_agc_progress.release(); d_mpf_dbg.release();
     d_hA.release(); d_hB.release(); d_coeff.release(); d_atan.release(); d_if_rms_blk.release();
-    d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_base.release(); d_raw.release();
+    d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_taps.release(); d_fused_part.release(); d_afrag.release(); d_afrag5.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
@@ -422,6 +422,7 @@ struct fmr_chain {
     long long N_if{};
     bool use_fused{};
     bool fused_disc{};     // the fused kernel's epilogue is the discriminator (else: IF samples only)
+    bool fir_disc{};       // the IF filter kernel's epilogue is the discriminator (k_fm_block3<.., true>)
     FusedGeom fused_geom{};
     int par{};
     float2 *ifbuf = nullptr;
@@ -786,6 +787,7 @@ int fmr_chain::init(const fmr_config *c) {
   if ((rc = d_if_rms_blk.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_bb_mean_blk.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_bb_rms_blk.alloc((size_t)S * max_blocks))) return rc;
+  if ((rc = d_blk_ph.alloc((size_t)S * max_blocks * 2))) return rc;
   if ((rc = d_mpf_ok.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_stereo_blk.alloc((size_t)S * max_blocks))) return rc;
 
@@ -1505,11 +1507,23 @@ int fmr_chain::run_if_stage(CallCtx &k) {
   rms_in_disc = (mode == FMR_MODE_FM) && !fir_enable && !serial_mode;
   if (!rms_in_disc) {
     timed("fm_block", [&] {
+      // four outputs per lane; FM without the equaliser: the discriminator is its epilogue (k_disc is not launched)
       constexpr int TL = 1024;
-      const size_t lds_fb = sizeof(float2) * ((size_t)(ntaps - 1) + TL) + sizeof(float) * (size_t)ntaps;
-      if (fir_enable && ntaps >= 2 && lds_fb <= 60000)
-        hipLaunchKernelGGL((k_fm_block2<256, TL>), dim3(nb, S), dim3(256), lds_fb, stream, ifbuf, if_stride, H_if, bt,
-                           d_coeff.p, ntaps, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if, d_if_rms_blk.p);
+      const size_t lds_fb = sizeof(float2) * 4 * (size_t)fm_block3_plane(ntaps - 1, TL) + sizeof(float) * ((size_t)ntaps + 3);
+      const bool blocked = fir_enable && ntaps >= 2 && lds_fb <= 60000 && !serial_mode;
+      k.fir_disc = blocked && mode == FMR_MODE_FM && !enable_mpf;
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(nb, S), dim3(256), lds_fb, stream, ifbuf, if_stride, H_if, bt,
+                           d_coeff.p, ntaps, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if, d_if_rms_blk.p,
+                           disc_nf, disc_bound, d_dec.p, (long long)max_if, k.base, H_b + (long long)max_if, H_b,
+                           d_bb_mean_blk.p, d_bb_rms_blk.p, d_blk_ph.p);
+      };
+      if (k.fir_disc) {
+        go(k_fm_block3<256, true>);
+        hipLaunchKernelGGL(k_disc_heads, dim3((nb + 255) / 256, S), dim3(256), 0, stream, bt, d_blk_ph.p, disc_bound, d_dec.p,
+                           (long long)max_if, k.base, H_b + (long long)max_if, H_b, d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);
+      }
+      else if (blocked) go(k_fm_block3<256, false>);
       else
       hipLaunchKernelGGL(k_fm_block<256>, dim3(nb, S), dim3(256), 0, stream, ifbuf, if_stride, H_if, bt, d_coeff.p,
                          ntaps, (int)fir_enable, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if,
@@ -1693,9 +1707,12 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
         hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                            nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
       }
-      hipLaunchKernelGGL(k_pll_fallback, dim3((S + 63) / 64), dim3(64), 0, ps, k.base, base_stride, H_b, bt,
-                         k.raw, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, k.stereo_blk, d_state.p,
-                         S, d_flags.p);
+      if (pilot_shift)
+        hipLaunchKernelGGL(k_pll_fallback<true>, dim3(S), dim3(64), 0, ps, k.base, base_stride, H_b, bt,
+                           k.raw, base_stride, H_b, d_atan.p, pllc, k.stereo_blk, d_state.p, S, d_flags.p);
+      else
+        hipLaunchKernelGGL(k_pll_fallback<false>, dim3(S), dim3(64), 0, ps, k.base, base_stride, H_b, bt,
+                           k.raw, base_stride, H_b, d_atan.p, pllc, k.stereo_blk, d_state.p, S, d_flags.p);
     });
     if (rc_agc) return rc_agc;
     HIPCHK(hipGetLastError());    // a launch of the rounds above that could not be enqueued
@@ -1769,7 +1786,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   }
   const long long base_stride = H_b + (long long)max_if;   // pre-de-emphasis buffers
   const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
-  if (!k.fused_disc)     // (the fused front end's discriminator epilogue has already written the MPX and the block statistics)
+  if (!k.fused_disc && !k.fir_disc)     // (the fused front end's / the IF filter's discriminator epilogue has already written the MPX and the block statistics)
   timed("disc", [&] {
     hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
                        (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,

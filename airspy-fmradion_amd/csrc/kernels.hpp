@@ -1272,70 +1272,207 @@ __global__ __launch_bounds__(BLOCK) void k_fm_block(
   if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);
 }
 
-// K_blk v2: the same arithmetic (identical operation order, bit-identical results) out of LDS.  The block is walked in
-// tiles of TL outputs; a tile's window (order history samples + TL) and the coefficients are staged once, so a tap costs
-// two LDS reads instead of two cached global loads -- the AM / SSB filters have 255 / 2049 taps, and with the 48 kHz
-// modes' short blocks almost every output takes the sequential block-head path (hazard H1).
-template <int BLOCK, int TL>
-__global__ __launch_bounds__(BLOCK) void k_fm_block2(
+// ---------------------------------------------------------------------------
+// K_fm_block3 (round 4): k_fm_block's arithmetic (identical operation order, bit-identical results) out of LDS -- the block
+// is walked in tiles, a tile's window (order history samples + the tile) and the coefficients are staged once; the AM / SSB
+// filters have 255 / 2049 taps, and with the 48 kHz modes' short blocks almost every output takes the sequential block-head
+// path (hazard H1) -- with FOUR consecutive outputs per lane and, for FM, the phase discriminator
+// (k_disc: PhaseDiscriminator.cpp:33-46, the fp64 widening FmDecode.cpp:143, the block statistics Utility.h:135-152)
+// as its epilogue.  The folded body (Filter.cpp:73-82) of output i is sum_k (x[i - k] + x[i - order + k]) c[k]: as k
+// advances one window slides down and the other up, by one sample each -- a lane that owns four outputs keeps both
+// windows in registers and reads ONE new sample per window and step (0.5 LDS reads per output and tap pair instead of
+// 2, the coefficients four at a time), and the three operations of a pair (add, multiply, add -- the reference's
+// rounding, no FMA) are packed over re / im.  Every output is still one accumulator chain over k in the reference's
+// order: bit-identical to k_fm_block.  Head outputs (i < order, Filter.cpp:59-68, hazard H1) take the one-output
+// code.  The discriminator's neighbour phase crosses lanes through LDS; a block's first difference needs the last
+// output of the block before it, which belongs to another workgroup: the kernel leaves that one sample out, stores the
+// phases of the block's first and last output and the block's sums without it, and k_disc_heads (one lane per block)
+// finishes the block -- recomputing the neighbour's output on one lane, 127 dependent loads, made the kernel twice as
+// slow as the two it replaces.
+// Round 3's one-output-per-lane form (k_fm_block2, 94 us) + k_disc (32 us) per 5.2 M IF samples -> one kernel.
+// ---------------------------------------------------------------------------
+template <class XF>
+__device__ __forceinline__ float2 fir_one(XF X /* X(j) = x[i - j] */, int i, int order, const float *cs) {
+  const int half_order = (order - 1) / 2;
+  float yr = 0.f, yi = 0.f;
+  if (i < order) {
+#pragma unroll 8
+    for (int j = i + 1; j <= order; j++) { const float2 tt = X(j); const float c = cs[j]; yr += tt.x * c; yi += tt.y * c; }
+#pragma unroll 8
+    for (int j = 1; j <= i; j++) { const float2 tt = X(j); const float c = cs[j]; yr += tt.x * c; yi += tt.y * c; }
+  } else {
+#pragma unroll 4
+    for (int k = 0; k <= half_order; k++) {
+      const float2 a = X(k), bb = X(order - k);
+      const float c = cs[k];
+      yr += (a.x + bb.x) * c; yi += (a.y + bb.y) * c;
+    }
+    if ((order % 2) == 0) { const float2 tt = X(order / 2); const float c = cs[order / 2]; yr += tt.x * c; yi += tt.y * c; }
+  }
+  return make_float2(yr, yi);
+}
+// LDS layout of a tile's window for k_fm_block3: sample m in plane m & 3 at position m >> 2.  A lane that owns four
+// consecutive outputs reads sample 4 lane + c: with the samples in order that is a stride of 32 bytes, an eight-way bank
+// conflict; in planes the lanes of one instruction read consecutive positions of one plane.  A plane's length is 8 mod 32
+// float2, so that lanes reading consecutive samples (the staging stores, the one-output code) spread over all banks too.
+__host__ __device__ inline int fm_block3_plane(int order, int tl) {
+  int p = (order + tl + 3) / 4;
+  p += (8 - p % 32 + 32) % 32;
+  return p;
+}
+template <int BLOCK, bool DISC>
+__global__ __launch_bounds__(BLOCK) void k_fm_block3(
     const float2 *__restrict__ ifb, long long if_stride, int if_halo, BlockTab bt,
     const float *__restrict__ coeff, int ntaps, int rms_after_fir,
-    float2 *__restrict__ firb, long long fir_stride, float *__restrict__ if_rms_blk) {
+    float2 *__restrict__ firb, long long fir_stride, float *__restrict__ if_rms_blk,
+    float nf, float bound, float *__restrict__ dec, long long dec_stride,
+    double *__restrict__ base, long long base_stride, int base_off,
+    float *__restrict__ bb_mean_blk /* DISC: the block's sum of d without its first sample */,
+    float *__restrict__ bb_rms_blk /* DISC: the sum of d^2 likewise */, float *__restrict__ blk_ph /* [S][nb][2] */) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int R = 4, TL = BLOCK * R;
   extern __shared__ float2 lds_fb[];
   __shared__ float scratch[BLOCK / 64];
+  __shared__ float ph[DISC ? TL + 1 : 1];                           // ph[1 + t] = phase of the tile's output t, ph[0] the one before
   const int b = blockIdx.x, s = blockIdx.y;
   const int n = bt.if_len[b];
   if (n == 0) return;
   const int order = ntaps - 1;
-  const int half_order = (order - 1) / 2;
-  float2 *xs = lds_fb;                                              // [order + TL]: xs[order + t] = x[i0 + t]
-  float *cs = reinterpret_cast<float *>(lds_fb + order + TL);       // [ntaps]
+  const int half_order = (order - 1) / 2, npairs = half_order + 1;
+  const int PL = fm_block3_plane(order, TL);
+  float2 *xs = lds_fb;                                              // [4 PL]: sample m of the window (x[i0 - order + m]) at XS(m)
+  auto XS = [&](int m) -> float2 & { return xs[(m & 3) * PL + (m >> 2)]; };
+  float *cs = reinterpret_cast<float *>(lds_fb + 4 * PL);           // [ntaps + 3], 16-byte aligned
   const float2 *x = ifb + (long long)s * if_stride + if_halo + bt.if_off[b];
   float2 *y = firb + (long long)s * fir_stride + bt.if_off[b];
-  for (int k = threadIdx.x; k < ntaps; k += BLOCK) cs[k] = coeff[k];
-  float acc = 0.f;
+  for (int k = threadIdx.x; k < ntaps + 3; k += BLOCK) cs[k] = k < ntaps ? coeff[k] : 0.f;
+  float acc = 0.f, vsum = 0.f, vsq = 0.f;
+  float carry = 0.f;                                                // (lane BLOCK - 1: phase of the last output of the tile before)
   for (int i0 = 0; i0 < n; i0 += TL) {
     const int tn = min(TL, n - i0);
     __syncthreads();
-    for (int k = threadIdx.x; k < order + tn; k += BLOCK) xs[k] = x[i0 - order + k];    // (reaches into the prefix halo)
+    if (DISC && i0 > 0 && threadIdx.x == BLOCK - 1) ph[0] = carry;
+    for (int k = threadIdx.x; k < order + tn; k += BLOCK) XS(k) = x[i0 - order + k];    // (reaches into the prefix halo)
     __syncthreads();
-    for (int t = threadIdx.x; t < tn; t += BLOCK) {
-      const int i = i0 + t;
-      const float2 *xl = xs + order + t;                            // xl[-j] = x[i - j]
-      float yr = 0.f, yi = 0.f;
-      if (i < order) {
-        // head: lags 1..order, state part first then in-block part (Filter.cpp:59-68)
-        for (int j = i + 1; j <= order; j++) {
-          const float2 tt = xl[-j];
-          const float c = cs[j];
-          yr += tt.x * c; yi += tt.y * c;
-        }
-        for (int j = 1; j <= i; j++) {
-          const float2 tt = xl[-j];
-          const float c = cs[j];
-          yr += tt.x * c; yi += tt.y * c;
-        }
-      } else {
-        // body: folded symmetric form incl. lag 0 (Filter.cpp:73-82)
-        for (int k = 0; k <= half_order; k++) {
-          const float2 a = xl[-k], bb = xl[-(order - k)];
-          const float c = cs[k];
-          yr += (a.x + bb.x) * c; yi += (a.y + bb.y) * c;
-        }
+    const int t0 = R * threadIdx.x;
+    auto emit = [&](int t, float2 o) {       // output t of the tile: the filtered sample, the level sum, the phase
+      y[i0 + t] = o;
+      const float2 v = rms_after_fir ? o : XS(order + t);
+      acc += v.x * v.x + v.y * v.y;
+      if (DISC) ph[1 + t] = atan2f(o.y, o.x) / nf;                         // V4
+    };
+    // one output per lane: the head outputs (i < order: 2 x order dependent steps each -- four of them on one lane were most
+    // of the block's time), the up to three body outputs that complete a group of four behind them, and the tile's last
+    // outputs that do not fill a group
+    const int hb = min(tn, max(0, (order - i0 + R - 1) & ~(R - 1))), tb = hb + ((tn - hb) & ~(R - 1));
+    for (int t = threadIdx.x; t < hb + (tn - tb); t += BLOCK) {
+      const int tt = t < hb ? t : tb + (t - hb);
+      emit(tt, fir_one([&](int j) { return XS(order + tt - j); }, i0 + tt, order, cs));
+    }
+    if (t0 >= hb && t0 < tb) {
+      // (t0 is a multiple of four: sample order + t0 + idx sits in plane (order + idx) & 3 at position t0 / 4 + ((order + idx) >> 2))
+      const float2 *xq = xs + (t0 >> 2);
+      {
+        // ---- four body outputs: windows A (x[i - k], slides down) and B (x[i - order + k], slides up) in registers
+        v2f ac[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) ac[r] = v2f{0.f, 0.f};
+        auto ldf = [&](int idx) { const int m = order + idx; return xq[(m & 3) * PL + (m >> 2)]; };
+        auto ld = [&](int idx) { const float2 v = ldf(idx); return v2f{v.x, v.y}; };
+        v2f A[4], B[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { A[r] = ld(r); B[r] = ld(r - order); }
+        auto four_steps = [&](int k, int nsteps) {      // steps k .. k + nsteps - 1 (nsteps uniform, 1..4)
+          const float4 c4 = *reinterpret_cast<const float4 *>(cs + k);
+          const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (u < nsteps) {
+              // step k + u: output r takes A sample (r - u) -> slot (r - u) & 3 (slots hold samples -k-u .. -k-u+3),
+              //                             B sample (r + u) -> slot (r + u) & 3
+#pragma unroll
+              for (int r = 0; r < R; r++) {
+                const v2f sum = A[(r - u) & 3] + B[(r + u) & 3];
+                const v2f pr = sum * cc[u];
+                ac[r] = ac[r] + pr;
+              }
+              // next step: A gains sample -(k + u) - 1 in the slot of the one it drops, B gains -order + k + u + 4
+              A[(3 - u) & 3] = ld(-(k + u) - 1);
+              B[u & 3] = ld(-order + k + u + 4);
+            }
+          }
+        };
+        int k = 0;
+        for (; k + 4 <= npairs; k += 4) four_steps(k, 4);
+        if (k < npairs) four_steps(k, npairs - k);
         if ((order % 2) == 0) {
-          const float2 tt = xl[-(order / 2)];
-          const float c = cs[order / 2];
-          yr += tt.x * c; yi += tt.y * c;
+          const float cm = cs[order / 2];
+#pragma unroll
+          for (int r = 0; r < R; r++) { const v2f pr = ld(r - order / 2) * cm; ac[r] = ac[r] + pr; }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) emit(t0 + r, make_float2(ac[r].x, ac[r].y));
+      }
+    }
+    if (DISC) {
+      __syncthreads();
+      // the tile's last phase moves to lane BLOCK - 1 for the next tile
+      const float last = ph[tn];
+      if (threadIdx.x == BLOCK - 1) carry = last;
+      if (t0 < tn) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const int t = t0 + r;
+          if (t < tn && i0 + t == 0) blk_ph[((long long)s * bt.nb + b) * 2] = ph[1];
+          if (t < tn && i0 + t > 0) {
+            float d = ph[1 + t] - ph[t];                               // V5
+            if (d > bound) d -= 2 * bound;
+            if (d < -bound) d += 2 * bound;
+            if (isnan(d)) d = 0.f;                                     // Utility.h:336-343
+            const int i = i0 + t;
+            dec[(long long)s * dec_stride + bt.if_off[b] + i] = d;
+            base[(long long)s * base_stride + base_off + bt.if_off[b] + i] = (double)d;
+            vsum += d;
+            vsq += d * d;
+          }
+          if (t < tn && i0 + t == n - 1) blk_ph[((long long)s * bt.nb + b) * 2 + 1] = ph[1 + t];
         }
       }
-      const float2 o = make_float2(yr, yi);
-      y[i] = o;
-      const float2 v = rms_after_fir ? o : xl[0];
-      acc += v.x * v.x + v.y * v.y;
     }
   }
   const float tot = block_sum<BLOCK>(acc, scratch);
   if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);
+  if (DISC) {
+    const float ts = block_sum<BLOCK>(vsum, scratch);
+    const float tq = block_sum<BLOCK>(vsq, scratch);
+    if (threadIdx.x == 0) { bb_mean_blk[(long long)s * bt.nb + b] = ts; bb_rms_blk[(long long)s * bt.nb + b] = tq; }
+  }
+}
+// the first sample of every block behind k_fm_block3<.., true>: its difference against the last phase of the block before
+// (or the carried phase, PhaseDiscriminator.cpp:33-46), the block's statistics, the phase the call leaves behind
+__global__ void k_disc_heads(BlockTab bt, const float *__restrict__ blk_ph, float bound,
+                             float *__restrict__ dec, long long dec_stride, double *__restrict__ base, long long base_stride,
+                             int base_off, float *__restrict__ bb_mean_blk, float *__restrict__ bb_rms_blk, StreamState *st) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+  if (b >= bt.nb) return;
+  const int n = bt.if_len[b];
+  if (n == 0) return;
+  const float *pp = blk_ph + (long long)s * bt.nb * 2;
+  int pb = b - 1;
+  while (pb >= 0 && bt.if_len[pb] == 0) pb--;
+  const float prev = pb < 0 ? st[s].disc_save : pp[2 * pb + 1];
+  float d = pp[2 * b] - prev;                                          // V5
+  if (d > bound) d -= 2 * bound;
+  if (d < -bound) d += 2 * bound;
+  if (isnan(d)) d = 0.f;                                               // Utility.h:336-343
+  dec[(long long)s * dec_stride + bt.if_off[b]] = d;
+  base[(long long)s * base_stride + base_off + bt.if_off[b]] = (double)d;
+  const long long bi = (long long)s * bt.nb + b;
+  bb_mean_blk[bi] = (bb_mean_blk[bi] + d) / (float)(unsigned)n;
+  bb_rms_blk[bi] = sqrtf((bb_rms_blk[bi] + d * d) / (float)(unsigned)n);
+  int nb2 = b + 1;
+  while (nb2 < bt.nb && bt.if_len[nb2] == 0) nb2++;
+  if (nb2 >= bt.nb) { st[s].disc_save_next = pp[2 * b + 1]; st[s].disc_save_valid = 1; }
 }
 
 // ---------------------------------------------------------------------------

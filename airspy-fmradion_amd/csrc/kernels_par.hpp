@@ -1765,22 +1765,31 @@ __global__ __launch_bounds__(64) void k_pll_finish(
   S.stereo_detected = (lock_cnt >= pc.lock_delay);
 }
 
-// serial fallback: the plain k_pll when the shooting iteration did not converge
+// Serial fallback: the plain loop when the shooting iteration did not converge (unlocked: without a pilot the loop's
+// state is not a function of the recent input and nothing along time can be decomposed, NOTEBOOK.md).
+// Round 4: one WAVE per stream.  A lone wave issues an instruction every ~4.8 cycles whatever it is, and the round-3
+// loop was 150 instructions per sample (720 cycles): a third of them the sin / cos of the phase.  Here the pair
+// (sin, cos) is carried along: turned by the phase increment of the sample (whose sine and cosine are fourth-order
+// polynomials around the middle of the 60 Hz wide frequency range, eight fused multiply-adds) and set again from
+// pll_sincos at the head of every run of 64 samples, so that it is never more than 64 rotations (1e-14) from it.
+// The 64 samples of a run arrive with one load and leave with one store (v_readlane in, a select per sample out),
+// wraps and PPS bookkeeping are scalar branches.  Everything else is the reference's arithmetic as in pll_step<false>.
+template <bool PILOT_SHIFT>
 __global__ __launch_bounds__(64) void k_pll_fallback(
     const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt,
     double *__restrict__ raw, long long raw_stride, int raw_off, const float *__restrict__ atan_tab,
-    PllConst pc, int pilot_shift, int *__restrict__ stereo_blk, StreamState *st, int n_streams, IterFlags *fl) {
+    PllConst pc, int *__restrict__ stereo_blk, StreamState *st, int n_streams, IterFlags *fl) {
   __shared__ float tab[257];
   for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
   __syncthreads();
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.x, lane = threadIdx.x;
   if (s >= n_streams || fl[s].pll_converged) return;
-  fl[s].pll_fallback = 1;
+  if (lane == 0) fl[s].pll_fallback = 1;
   StreamState &S = st[s];
-  PllRegs R;
-  R.v[0] = S.pll_phase; R.v[1] = S.pll_freq; R.v[2] = S.lf_x1;
-  R.v[3] = S.bq_i_x1; R.v[4] = S.bq_i_x2; R.v[5] = S.bq_q_x1; R.v[6] = S.bq_q_x2;
-  R.li = S.pll_level; R.lq = 0.0; R.freq_err = S.pll_freq_err;
+  // (every lane holds the same state and runs the same chain: the values are wave-uniform)
+  double phase = S.pll_phase, freq = S.pll_freq, lf1 = S.lf_x1;
+  double wi1 = S.bq_i_x1, wi2 = S.bq_i_x2, wq1 = S.bq_q_x1, wq2 = S.bq_q_x2;
+  double li = S.pll_level, lq = 0.0, freq_err = S.pll_freq_err;
   int lock_cnt = S.lock_cnt, pilot_periods = S.pilot_periods;
   unsigned long long pps_cnt = S.pps_cnt, sample_cnt = S.sample_cnt;
   int n_pps = 0;
@@ -1789,40 +1798,88 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
   bool favg_locked = (S.lock_cnt >= pc.lock_delay);
   const double *xin = base + (long long)s * base_stride + base_off;
   double *out = raw + (long long)s * raw_stride + raw_off;
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  // sin / cos of the phase increment around the middle of the frequency range: |f - f0| <= 2 pi 30 / 384000 = 4.9e-4,
+  // the fifth-order term is 2e-19
+  const double f0 = 0.5 * (pc.minfreq + pc.maxfreq);
+  double S0, C0;
+  pll_sincos(f0, S0, C0);
+  const double fminv = pc.minfreq, fmaxv = pc.maxfreq;
+  const double s2 = -0.5 * S0, s3 = -C0 / 6.0, s4 = S0 / 24.0, c2 = -0.5 * C0, c3 = S0 / 6.0, c4 = C0 / 24.0;
   for (int b = 0; b < bt.nb; b++) {
     const int n = bt.if_len[b];
-    if (n == 0) { stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay); continue; }
+    if (n == 0) { if (lane == 0) stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay); continue; }
     const int off = bt.if_off[b];
     const bool was_locked = (lock_cnt >= pc.lock_delay);
     // the mean phase increment that seeds the next call's node guess is measured over locked signal only, and over
     // the last quarter of a long call: the pull-in transient would put it off by far more than the ~1e-9
     // rad/sample the ramp guess tolerates over millions of samples
-    if ((was_locked && !favg_locked) || b == (bt.nb * 3) / 4) { wr = 0; ns = 0; ph_start = R.v[0]; }
+    if ((was_locked && !favg_locked) || b == (bt.nb * 3) / 4) { wr = 0; ns = 0; ph_start = phase; }
     favg_locked = was_locked;
     const int pps_blk_start = n_pps;
-    for (int i = 0; i < n; i++) {
-      double o;
-      if (pll_step<false>(R, xin[off + i], pc, tab, pilot_shift, o, nullptr)) {
-        pilot_periods++;
-        wr++;
-        if (pilot_periods == pc.pilot_frequency) {
-          pilot_periods = 0;
-          if (was_locked) {
-            if (n_pps < FMR_MAX_PPS) {
-              PpsEventDev &ev = S.pps[n_pps];
-              ev.pps_index = pps_cnt;
-              ev.sample_index = sample_cnt + (unsigned long long)i;
-              ev.block_position = (double)i / (double)n;
-              ev.block = (unsigned)b;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int cnt = min(64, n - i0);
+      const double xv = (lane < cnt) ? xin[off + i0 + lane] : 0.0;
+      double psin, pcos;
+      pll_sincos(phase, psin, pcos);           // exact at the head of every run of 64 samples
+      double ov = 0.0;
+      for (int u = 0; u < cnt; u++) {
+        const double x = readlane_d(xv, u);
+        // PilotPhaseLock.cpp:73-151, the arithmetic of pll_step<false>
+        const double carrier = PILOT_SHIFT ? (2 * pcos * pcos - 1) : (2 * psin * pcos);
+        const double o = (carrier * x) * 2.0;
+        ov = (lane == u) ? o : ov;
+        const double phasor_i = psin * x, phasor_q = pcos * x;
+        const double wi0 = phasor_i - (pc.bq_a1 * wi1 + pc.bq_a2 * wi2);
+        const double wq0 = phasor_q - (pc.bq_a1 * wq1 + pc.bq_a2 * wq2);
+        const double new_i = pc.bq_b0 * wi0, new_q = pc.bq_b0 * wq0;
+        const double e = (double)fast_atan2f_dev((float)new_q, (float)new_i, tab);
+        li = new_i; lq = new_q;
+        const double y = pc.lf_b0 * e + pc.lf_b1 * lf1;
+        freq_err = y;
+        const double f_un = freq + y;
+        // fmax(minfreq, fmin(maxfreq, f_un)) without the two canonicalising v_max the compiler puts in front of a
+        // constant operand it cannot prove quiet (same instructions, same result: v_min / v_max return the other operand
+        // for a NaN)
+        double f_new;
+        asm("v_min_f64 %0, %1, %2" : "=v"(f_new) : "v"(f_un), "v"(fmaxv));
+        asm("v_max_f64 %0, %1, %2" : "=v"(f_new) : "v"(f_new), "v"(fminv));
+        lf1 = e;
+        wi2 = wi1; wi1 = wi0;
+        wq2 = wq1; wq1 = wq0;
+        freq = f_new;
+        double ph = phase + f_new;
+        const bool wrapped = __ballot(ph > two_pi) != 0ull;        // (wave-uniform: a scalar branch)
+        if (wrapped) ph -= two_pi;
+        phase = ph;
+        // sin / cos of the next phase: the current pair turned by f_new (explicit fma: this is not reference arithmetic)
+        const double d = f_new - f0;
+        const double sd = fma(d, fma(d, fma(d, fma(d, s4, s3), s2), C0), S0);
+        const double cd = fma(d, fma(d, fma(d, fma(d, c4, c3), c2), -S0), C0);
+        const double ns_ = fma(pcos, sd, psin * cd), nc_ = fma(-psin, sd, pcos * cd);
+        psin = ns_; pcos = nc_;
+        if (wrapped) {
+          pilot_periods++;
+          wr++;
+          if (pilot_periods == pc.pilot_frequency) {
+            pilot_periods = 0;
+            if (was_locked) {
+              if (n_pps < FMR_MAX_PPS && lane == 0) {
+                PpsEventDev &ev = S.pps[n_pps];
+                ev.pps_index = pps_cnt;
+                ev.sample_index = sample_cnt + (unsigned long long)(i0 + u);
+                ev.block_position = (double)(i0 + u) / (double)n;
+                ev.block = (unsigned)b;
+              }
+              n_pps++;
+              pps_cnt++;
             }
-            n_pps++;
-            pps_cnt++;
           }
         }
       }
-      out[off + i] = o;
+      if (lane < cnt) out[off + i0 + lane] = ov;
     }
-    if (2 * pll_level(R) > pc.minsignal) {
+    if (2 * sqrt((li * li) + (lq * lq)) > pc.minsignal) {
       if (lock_cnt < pc.lock_delay) lock_cnt += n;
     } else {
       lock_cnt = 0;
@@ -1830,15 +1887,16 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
     if (lock_cnt < pc.lock_delay) { pilot_periods = 0; pps_cnt = 0; n_pps = pps_blk_start; }
     sample_cnt += (unsigned long long)n;
     ns += n;
-    stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay);
+    if (lane == 0) stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay);
   }
+  if (lane != 0) return;
   if (ns >= 65536) {
-    S.pll_favg = ((double)wr * 2.0 * 3.14159265358979323846 + (R.v[0] - ph_start)) / (double)ns;
+    S.pll_favg = ((double)wr * 2.0 * 3.14159265358979323846 + (phase - ph_start)) / (double)ns;
     S.pll_favg_valid = (lock_cnt >= pc.lock_delay) ? 1 : 0;
   }
-  S.pll_phase = R.v[0]; S.pll_freq = R.v[1]; S.lf_x1 = R.v[2];
-  S.bq_i_x1 = R.v[3]; S.bq_i_x2 = R.v[4]; S.bq_q_x1 = R.v[5]; S.bq_q_x2 = R.v[6];
-  S.pll_level = pll_level(R); S.pll_freq_err = R.freq_err;
+  S.pll_phase = phase; S.pll_freq = freq; S.lf_x1 = lf1;
+  S.bq_i_x1 = wi1; S.bq_i_x2 = wi2; S.bq_q_x1 = wq1; S.bq_q_x2 = wq2;
+  S.pll_level = sqrt((li * li) + (lq * lq)); S.pll_freq_err = freq_err;
   S.lock_cnt = lock_cnt; S.pilot_periods = pilot_periods; S.pps_cnt = pps_cnt; S.sample_cnt = sample_cnt;
   S.n_pps = n_pps < FMR_MAX_PPS ? n_pps : FMR_MAX_PPS;
   S.stereo_detected = (lock_cnt >= pc.lock_delay);
