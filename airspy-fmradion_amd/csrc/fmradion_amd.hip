@@ -1509,7 +1509,7 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     timed("fm_block", [&] {
       // four outputs per lane; FM without the equaliser: the discriminator is its epilogue (k_disc is not launched)
       constexpr int TL = 1024;
-      const size_t lds_fb = sizeof(float2) * 4 * (size_t)fm_block3_plane(ntaps - 1, TL) + sizeof(float) * ((size_t)ntaps + 3);
+      const size_t lds_fb = sizeof(float2) * (4 * (size_t)fm_block3_plane(ntaps - 1, TL) + ((size_t)ntaps + 4) / 2 + (size_t)(ntaps - 1) + TL);
       const bool blocked = fir_enable && ntaps >= 2 && lds_fb <= 60000 && !serial_mode;
       k.fir_disc = blocked && mode == FMR_MODE_FM && !enable_mpf;
       auto go = [&](auto kern) {

@@ -1293,23 +1293,25 @@ __global__ __launch_bounds__(BLOCK) void k_fm_block(
 // ---------------------------------------------------------------------------
 template <class XF>
 __device__ __forceinline__ float2 fir_one(XF X /* X(j) = x[i - j] */, int i, int order, const float *cs) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
   const int half_order = (order - 1) / 2;
-  float yr = 0.f, yi = 0.f;
+  v2f y = {0.f, 0.f};                     // (packed over re / im: the same multiply, then add, per component)
+  auto ldv = [&](int j) { const float2 t = X(j); return v2f{t.x, t.y}; };
   if (i < order) {
 #pragma unroll 8
-    for (int j = i + 1; j <= order; j++) { const float2 tt = X(j); const float c = cs[j]; yr += tt.x * c; yi += tt.y * c; }
+    for (int j = i + 1; j <= order; j++) { const v2f pr = ldv(j) * cs[j]; y = y + pr; }
 #pragma unroll 8
-    for (int j = 1; j <= i; j++) { const float2 tt = X(j); const float c = cs[j]; yr += tt.x * c; yi += tt.y * c; }
+    for (int j = 1; j <= i; j++) { const v2f pr = ldv(j) * cs[j]; y = y + pr; }
   } else {
 #pragma unroll 4
     for (int k = 0; k <= half_order; k++) {
-      const float2 a = X(k), bb = X(order - k);
-      const float c = cs[k];
-      yr += (a.x + bb.x) * c; yi += (a.y + bb.y) * c;
+      const v2f sum = ldv(k) + ldv(order - k);
+      const v2f pr = sum * cs[k];
+      y = y + pr;
     }
-    if ((order % 2) == 0) { const float2 tt = X(order / 2); const float c = cs[order / 2]; yr += tt.x * c; yi += tt.y * c; }
+    if ((order % 2) == 0) { const v2f pr = ldv(order / 2) * cs[order / 2]; y = y + pr; }
   }
-  return make_float2(yr, yi);
+  return make_float2(y.x, y.y);
 }
 // LDS layout of a tile's window for k_fm_block3: sample m in plane m & 3 at position m >> 2.  A lane that owns four
 // consecutive outputs reads sample 4 lane + c: with the samples in order that is a stride of 32 bytes, an eight-way bank
@@ -1321,7 +1323,8 @@ __host__ __device__ inline int fm_block3_plane(int order, int tl) {
   return p;
 }
 template <int BLOCK, bool DISC>
-__global__ __launch_bounds__(BLOCK) void k_fm_block3(
+// (waves_per_eu: 94 registers and five waves per SIMD instead of 112 and four)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_fm_block3(
     const float2 *__restrict__ ifb, long long if_stride, int if_halo, BlockTab bt,
     const float *__restrict__ coeff, int ntaps, int rms_after_fir,
     float2 *__restrict__ firb, long long fir_stride, float *__restrict__ if_rms_blk,
@@ -1342,7 +1345,9 @@ __global__ __launch_bounds__(BLOCK) void k_fm_block3(
   const int PL = fm_block3_plane(order, TL);
   float2 *xs = lds_fb;                                              // [4 PL]: sample m of the window (x[i0 - order + m]) at XS(m)
   auto XS = [&](int m) -> float2 & { return xs[(m & 3) * PL + (m >> 2)]; };
-  float *cs = reinterpret_cast<float *>(lds_fb + 4 * PL);           // [ntaps + 3], 16-byte aligned
+  float *cs = reinterpret_cast<float *>(lds_fb + 4 * PL);           // [ntaps + 3 (+1)], 16-byte aligned
+  float2 *xlin = lds_fb + 4 * PL + ((ntaps + 3 + 1) / 2);           // [order + TL]: the same window in order, for the one-output code
+                                                                    // (lanes read consecutive samples there; in planes every read needs its own address arithmetic)
   const float2 *x = ifb + (long long)s * if_stride + if_halo + bt.if_off[b];
   float2 *y = firb + (long long)s * fir_stride + bt.if_off[b];
   for (int k = threadIdx.x; k < ntaps + 3; k += BLOCK) cs[k] = k < ntaps ? coeff[k] : 0.f;
@@ -1352,12 +1357,12 @@ __global__ __launch_bounds__(BLOCK) void k_fm_block3(
     const int tn = min(TL, n - i0);
     __syncthreads();
     if (DISC && i0 > 0 && threadIdx.x == BLOCK - 1) ph[0] = carry;
-    for (int k = threadIdx.x; k < order + tn; k += BLOCK) XS(k) = x[i0 - order + k];    // (reaches into the prefix halo)
+    for (int k = threadIdx.x; k < order + tn; k += BLOCK) { const float2 v = x[i0 - order + k]; XS(k) = v; xlin[k] = v; }    // (reaches into the prefix halo)
     __syncthreads();
     const int t0 = R * threadIdx.x;
     auto emit = [&](int t, float2 o) {       // output t of the tile: the filtered sample, the level sum, the phase
       y[i0 + t] = o;
-      const float2 v = rms_after_fir ? o : XS(order + t);
+      const float2 v = rms_after_fir ? o : xlin[order + t];
       acc += v.x * v.x + v.y * v.y;
       if (DISC) ph[1 + t] = atan2f(o.y, o.x) / nf;                         // V4
     };
@@ -1367,7 +1372,8 @@ __global__ __launch_bounds__(BLOCK) void k_fm_block3(
     const int hb = min(tn, max(0, (order - i0 + R - 1) & ~(R - 1))), tb = hb + ((tn - hb) & ~(R - 1));
     for (int t = threadIdx.x; t < hb + (tn - tb); t += BLOCK) {
       const int tt = t < hb ? t : tb + (t - hb);
-      emit(tt, fir_one([&](int j) { return XS(order + tt - j); }, i0 + tt, order, cs));
+      const float2 *xl = xlin + order + tt;
+      emit(tt, fir_one([&](int j) { return xl[-j]; }, i0 + tt, order, cs));
     }
     if (t0 >= hb && t0 < tb) {
       // (t0 is a multiple of four: sample order + t0 + idx sits in plane (order + idx) & 3 at position t0 / 4 + ((order + idx) >> 2))
@@ -2492,7 +2498,8 @@ __device__ __forceinline__ float fast_atan2f_dev(float y, float x, const float *
   const float t0 = tab[index], t1 = tab[index + 1];
   float base_angle = t0;
   base_angle += (t1 - t0) * alpha;
-  base_angle = ((double)z < 0.003921569) ? z : base_angle;
+  // (double)z < 0.003921569 in the reference: for a float z that is z < 0x1.010104p-8f, the smallest float above the constant
+  base_angle = (z < 0x1.010104p-8f) ? z : base_angle;
   const bool xgt = x_abs > y_abs, xpos = x >= 0.0f, ypos = y >= 0.0f;
   const float c = xgt ? (xpos ? 0.0f : 3.14159265358979323846f) : 1.57079632679489661923f;
   const bool minus = xgt ? !xpos : xpos;

@@ -1805,7 +1805,8 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
   double S0, C0;
   pll_sincos(f0, S0, C0);
   const double fminv = pc.minfreq, fmaxv = pc.maxfreq;
-  const double s2 = -0.5 * S0, s3 = -C0 / 6.0, s4 = S0 / 24.0, c2 = -0.5 * C0, c3 = S0 / 6.0, c4 = C0 / 24.0;
+  double s2 = -0.5 * S0, s3 = -C0 / 6.0, s4 = S0 / 24.0, c2 = -0.5 * C0, c3 = S0 / 6.0, c4 = C0 / 24.0, nS0 = -S0;
+  asm volatile("" : "+v"(s2), "+v"(c2), "+v"(nS0));       // (held in registers: the compiler would recompute them per sample)
   for (int b = 0; b < bt.nb; b++) {
     const int n = bt.if_len[b];
     if (n == 0) { if (lane == 0) stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay); continue; }
@@ -1823,15 +1824,17 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
       double psin, pcos;
       pll_sincos(phase, psin, pcos);           // exact at the head of every run of 64 samples
       double ov = 0.0;
-      for (int u = 0; u < cnt; u++) {
+      // one sample; (w1, w2) are the biquad delays (newest, older) on entry -- the new value is written over the OLDER
+      // one, so the caller swaps the roles instead of the kernel moving registers
+      auto step = [&](int u, double &wi_1, double &wi_2, double &wq_1, double &wq_2) {
         const double x = readlane_d(xv, u);
         // PilotPhaseLock.cpp:73-151, the arithmetic of pll_step<false>
         const double carrier = PILOT_SHIFT ? (2 * pcos * pcos - 1) : (2 * psin * pcos);
         const double o = (carrier * x) * 2.0;
         ov = (lane == u) ? o : ov;
         const double phasor_i = psin * x, phasor_q = pcos * x;
-        const double wi0 = phasor_i - (pc.bq_a1 * wi1 + pc.bq_a2 * wi2);
-        const double wq0 = phasor_q - (pc.bq_a1 * wq1 + pc.bq_a2 * wq2);
+        const double wi0 = phasor_i - (pc.bq_a1 * wi_1 + pc.bq_a2 * wi_2);
+        const double wq0 = phasor_q - (pc.bq_a1 * wq_1 + pc.bq_a2 * wq_2);
         const double new_i = pc.bq_b0 * wi0, new_q = pc.bq_b0 * wq0;
         const double e = (double)fast_atan2f_dev((float)new_q, (float)new_i, tab);
         li = new_i; lq = new_q;
@@ -1842,23 +1845,20 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
         // constant operand it cannot prove quiet (same instructions, same result: v_min / v_max return the other operand
         // for a NaN)
         double f_new;
-        asm("v_min_f64 %0, %1, %2" : "=v"(f_new) : "v"(f_un), "v"(fmaxv));
-        asm("v_max_f64 %0, %1, %2" : "=v"(f_new) : "v"(f_new), "v"(fminv));
+        asm("v_min_f64 %0, %1, %2" : "=v"(f_new) : "v"(f_un), "s"(fmaxv));
+        asm("v_max_f64 %0, %1, %2" : "=v"(f_new) : "v"(f_new), "s"(fminv));
         lf1 = e;
-        wi2 = wi1; wi1 = wi0;
-        wq2 = wq1; wq1 = wq0;
+        wi_2 = wi0; wq_2 = wq0;
         freq = f_new;
-        double ph = phase + f_new;
-        const bool wrapped = __ballot(ph > two_pi) != 0ull;        // (wave-uniform: a scalar branch)
-        if (wrapped) ph -= two_pi;
-        phase = ph;
+        phase = phase + f_new;
         // sin / cos of the next phase: the current pair turned by f_new (explicit fma: this is not reference arithmetic)
         const double d = f_new - f0;
         const double sd = fma(d, fma(d, fma(d, fma(d, s4, s3), s2), C0), S0);
-        const double cd = fma(d, fma(d, fma(d, fma(d, c4, c3), c2), -S0), C0);
+        const double cd = fma(d, fma(d, fma(d, fma(d, c4, c3), c2), nS0), C0);
         const double ns_ = fma(pcos, sd, psin * cd), nc_ = fma(-psin, sd, pcos * cd);
         psin = ns_; pcos = nc_;
-        if (wrapped) {
+        if (__ballot(phase > two_pi) != 0ull) {       // (wave-uniform: a scalar branch)
+          phase -= two_pi;
           pilot_periods++;
           wr++;
           if (pilot_periods == pc.pilot_frequency) {
@@ -1876,6 +1876,13 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
             }
           }
         }
+      };
+      int u = 0;
+      for (; u + 2 <= cnt; u += 2) { step(u, wi1, wi2, wq1, wq2); step(u + 1, wi2, wi1, wq2, wq1); }
+      if (u < cnt) {
+        step(u, wi1, wi2, wq1, wq2);
+        const double ti = wi1, tq = wq1;
+        wi1 = wi2; wi2 = ti; wq1 = wq2; wq2 = tq;
       }
       if (lane < cnt) out[off + i0 + lane] = ov;
     }
