@@ -708,7 +708,7 @@ __global__ void k_am_commit(StreamState *st, IterFlags *fl, int n_streams) {
 // State vector: 0 phase, 1 freq, 2 loop-filter delay (previous phase error),
 // 3,4 biquad-I delays, 5,6 biquad-Q delays.
 // ---------------------------------------------------------------------------
-struct PllRegs { double v[7]; double li, lq, freq_err; };   // li,lq: biquad outputs of the last sample
+struct PllRegs { double v[7]; double li, lq, freq_err; double sn, cs; };   // li,lq: biquad outputs of the last sample; sn,cs: sin / cos of v[0]
 __device__ __forceinline__ double pll_level(const PllRegs &S) { return sqrt((S.li * S.li) + (S.lq * S.lq)); }  // PilotPhaseLock.cpp:106
 
 struct ChunkTab {
@@ -788,14 +788,39 @@ __device__ __forceinline__ void pll_sincos(double x, double &sn, double &cs) {
   cs = ((q + 1) & 2) ? -b : b;
 }
 
+// sin / cos of the NEXT phase from the current pair: turned by the phase increment f of the sample.  A lone wave issues an
+// instruction every ~4.8 cycles whatever it is, and pll_sincos is 60 of the 150 instructions of a sample step; the phase
+// increment lives in [minfreq, maxfreq], 2 pi 30 / 384000 = 4.9e-4 either side of the middle f0 of the range, where its sine
+// and cosine are fourth-order polynomials (the fifth-order term is 2e-19): eight fused multiply-adds, four operations for
+// the rotation.  The pair is set from pll_sincos at the head of every chunk (64 samples), so it is never more than 64
+// rotations -- 1e-14 -- away from it.  (Explicit fma: this is not reference arithmetic, like pll_sincos itself.)
+struct PllRot { double f0, S0, C0, nS0, s2, s3, s4, c2, c3, c4; };
+__device__ __forceinline__ PllRot pll_rot_make(const PllConst &pc) {
+  PllRot r;
+  r.f0 = 0.5 * (pc.minfreq + pc.maxfreq);
+  pll_sincos(r.f0, r.S0, r.C0);
+  r.nS0 = -r.S0;
+  r.s2 = -0.5 * r.S0; r.s3 = -r.C0 / 6.0; r.s4 = r.S0 / 24.0;
+  r.c2 = -0.5 * r.C0; r.c3 = r.S0 / 6.0; r.c4 = r.C0 / 24.0;
+  // (held in registers: the compiler would recompute the derived ones per sample)
+  asm volatile("" : "+v"(r.s2), "+v"(r.c2), "+v"(r.nS0));
+  return r;
+}
+__device__ __forceinline__ void pll_rotate(double &sn, double &cs, double f, const PllRot &r) {
+  const double d = f - r.f0;
+  const double sd = fma(d, fma(d, fma(d, fma(d, r.s4, r.s3), r.s2), r.C0), r.S0);
+  const double cd = fma(d, fma(d, fma(d, fma(d, r.c4, r.c3), r.c2), r.nS0), r.C0);
+  const double ns = fma(cs, sd, sn * cd), nc = fma(-sn, sd, cs * cd);
+  sn = ns; cs = nc;
+}
+
 // One PLL sample step, the reference's arithmetic (PilotPhaseLock.cpp:73-151);
 // JAC: also advance the 7x7 sensitivity Mx = d state / d start-state.
 template <bool JAC>
-__device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc, const float *tab, int pilot_shift,
+__device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc, const PllRot &rot, const float *tab, int pilot_shift,
                                         double &out, double (*Mx)[7]) {
   const double two_pi = 2.0 * 3.14159265358979323846;
-  double psin, pcos;
-  pll_sincos(S.v[0], psin, pcos);
+  const double psin = S.sn, pcos = S.cs;        // (PilotPhaseLock.cpp:78-79: sin / cos of the phase, carried along -- pll_rotate)
   const double carrier = pilot_shift ? (2 * pcos * pcos - 1) : (2 * psin * pcos);
   out = (carrier * x) * 2.0;
   const double phasor_i = psin * x, phasor_q = pcos * x;
@@ -807,7 +832,12 @@ __device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc
   const double y = pc.lf_b0 * e + pc.lf_b1 * S.v[2];
   S.freq_err = y;
   const double f_un = S.v[1] + y;
-  const double f_new = fmax(pc.minfreq, fmin(pc.maxfreq, f_un));
+  // fmax(minfreq, fmin(maxfreq, f_un)) (:96-97) without the two canonicalising v_max the compiler puts in front of a
+  // constant operand it cannot prove quiet (same two instructions, same result: they return the other operand for a NaN)
+  double f_new;
+  asm("v_min_f64 %0, %1, %2" : "=v"(f_new) : "v"(f_un), "s"(pc.maxfreq));
+  asm("v_max_f64 %0, %1, %2" : "=v"(f_new) : "v"(f_new), "s"(pc.minfreq));
+  pll_rotate(S.sn, S.cs, f_new, rot);
   if (JAC) {
     const double den = wi0 * wi0 + wq0 * wq0;
     const double eI = den > 0.0 ? -wq0 / den : 0.0, eQ = den > 0.0 ? wi0 / den : 0.0;
@@ -960,6 +990,8 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
 #pragma unroll
   for (int k = 0; k < 7; k++) S.v[k] = nd[k];
   S.li = 0.0; S.lq = 0.0; S.freq_err = 0.0;
+  pll_sincos(S.v[0], S.sn, S.cs);
+  const PllRot rot = pll_rot_make(pc);
   double Mx[7][7];
 #pragma unroll
   for (int r = 0; r < 7; r++)
@@ -992,9 +1024,10 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
     __syncthreads();
     const int m = min(T, n - t0);
     double *row = xs + lane * TP;
-    for (int i = 0; i < m; i++) {
+    // (two samples per pass: the delay-line moves of the state and of the sensitivities become register names)
+    auto sample = [&](int i) {
       double o;
-      const int wflag = pll_step<JAC>(S, row[i], pc, tab, pilot_shift, o, Mx);
+      const int wflag = pll_step<JAC>(S, row[i], pc, rot, tab, pilot_shift, o, Mx);
       wraps += wflag;
       if (WOUT) {
         const int gi = t0 + i;
@@ -1002,7 +1035,10 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
         if ((gi & 63) == 63) { mk[gi >> 6] = word; word = 0; }
         row[i] = o;
       }
-    }
+    };
+    int i = 0;
+    for (; i + 2 <= m; i += 2) { sample(i); sample(i + 1); }
+    if (i < m) sample(i);
     if (WOUT) {
       __syncthreads();
 #pragma unroll 8
@@ -1799,14 +1835,8 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
   const double *xin = base + (long long)s * base_stride + base_off;
   double *out = raw + (long long)s * raw_stride + raw_off;
   const double two_pi = 2.0 * 3.14159265358979323846;
-  // sin / cos of the phase increment around the middle of the frequency range: |f - f0| <= 2 pi 30 / 384000 = 4.9e-4,
-  // the fifth-order term is 2e-19
-  const double f0 = 0.5 * (pc.minfreq + pc.maxfreq);
-  double S0, C0;
-  pll_sincos(f0, S0, C0);
+  const PllRot rot = pll_rot_make(pc);
   const double fminv = pc.minfreq, fmaxv = pc.maxfreq;
-  double s2 = -0.5 * S0, s3 = -C0 / 6.0, s4 = S0 / 24.0, c2 = -0.5 * C0, c3 = S0 / 6.0, c4 = C0 / 24.0, nS0 = -S0;
-  asm volatile("" : "+v"(s2), "+v"(c2), "+v"(nS0));       // (held in registers: the compiler would recompute them per sample)
   for (int b = 0; b < bt.nb; b++) {
     const int n = bt.if_len[b];
     if (n == 0) { if (lane == 0) stereo_blk[(long long)s * bt.nb + b] = (lock_cnt >= pc.lock_delay); continue; }
@@ -1851,12 +1881,7 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
         wi_2 = wi0; wq_2 = wq0;
         freq = f_new;
         phase = phase + f_new;
-        // sin / cos of the next phase: the current pair turned by f_new (explicit fma: this is not reference arithmetic)
-        const double d = f_new - f0;
-        const double sd = fma(d, fma(d, fma(d, fma(d, s4, s3), s2), C0), S0);
-        const double cd = fma(d, fma(d, fma(d, fma(d, c4, c3), c2), nS0), C0);
-        const double ns_ = fma(pcos, sd, psin * cd), nc_ = fma(-psin, sd, pcos * cd);
-        psin = ns_; pcos = nc_;
+        pll_rotate(psin, pcos, f_new, rot);       // sin / cos of the next phase
         if (__ballot(phase > two_pi) != 0ull) {       // (wave-uniform: a scalar branch)
           phase -= two_pi;
           pilot_periods++;
