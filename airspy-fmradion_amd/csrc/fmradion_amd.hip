@@ -61,7 +61,7 @@ constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
 constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 512, K_AF_ITERS = 6;
 #ifndef FMR_C_PLL_MIN
-#define FMR_C_PLL_MIN 64
+#define FMR_C_PLL_MIN 32
 #endif
 constexpr int C_PLL_MIN = FMR_C_PLL_MIN;   // smallest PLL chunk (capacity); the actual length is c_pll
 constexpr long long kSmallCall = 8192;   // IF samples: calls up to this size enqueue fewer spare Newton rounds
@@ -98,6 +98,7 @@ struct EnvKnobs {
                                 //                    beside each other (1, the default for FM chains with the resampler) or one
                                 //                    in-order chain per call (0: the form the tests compare the product with)
   bool mpf3 = false;            // FMR_MPF3=1         equaliser: the round-3 kernel (four waves meet in every group) instead of chain + helpers
+  int c_pll = 0;                // FMR_C_PLL=<n>      PLL chunk length (32 .. 128; default: the chain's own choice)
   bool agc_first = false;       // FMR_AGC_FIRST=1    equaliser: the AGC kernel in front of it instead of beside it (tools/mpf_rate.py times each alone)
   bool mpf_account = false;     // FMR_MPF_ACCOUNT=1  equaliser kernel with cycle stamps at its phase boundaries (fmr_debug_read 5)
   int test_agc_late = 0;        // FMR_TEST_AGC_LATE=ms test hook (equaliser chain): the AGC kernel beside the equaliser starts this late; -1: never
@@ -114,7 +115,8 @@ struct EnvKnobs {
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
   void load() {
-    serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS"); r8b_f32 = on("FMR_R8B_F32"); mpf_account = on("FMR_MPF_ACCOUNT"); agc_first = on("FMR_AGC_FIRST"); mpf3 = on("FMR_MPF3");
+    serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS"); r8b_f32 = on("FMR_R8B_F32"); mpf_account = on("FMR_MPF_ACCOUNT"); agc_first = on("FMR_AGC_FIRST");
+    if (const char *e = getenv("FMR_C_PLL")) c_pll = atoi(e); mpf3 = on("FMR_MPF3");
     auto num = [](const char *n, int dflt) { const char *e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
     pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0); test_agc_late = num("FMR_TEST_AGC_LATE", 0);
     host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED"); pll_v1 = set("FMR_PLL_V1");
@@ -756,7 +758,8 @@ int fmr_chain::init(const fmr_config *c) {
     st.af_gain = 1.0;
   }
   if ((rc = upload(d_state, h_state.data(), h_state.size()))) return rc;
-  max_ck = max_if / C_PLL_MIN + (size_t)max_blocks + 2;
+  if (env.c_pll >= C_PLL_MIN && env.c_pll <= 128) c_pll = env.c_pll;
+  max_ck = max_if / (size_t)c_pll + (size_t)max_blocks + 2;
   tab_ints = 5 * (size_t)max_blocks + 3 * max_ck + (size_t)max_blocks + 1 + kMaxFusedWg;   // tail: first block of each fused workgroup
   HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * tab_ints));
   // The marks are written by one-thread kernels and polled by the host while more work is queued behind them: COHERENT

@@ -840,7 +840,11 @@ __device__ __forceinline__ int pll_step(PllRegs &S, double x, const PllConst &pc
   pll_rotate(S.sn, S.cs, f_new, rot);
   if (JAC) {
     const double den = wi0 * wi0 + wq0 * wq0;
-    const double eI = den > 0.0 ? -wq0 / den : 0.0, eQ = den > 0.0 ? wi0 / den : 0.0;
+    // (one reciprocal -- v_rcp_f64 and a Newton step -- instead of two fp64 divisions of ~20 instructions each: the
+    // sensitivities are this implementation's own quantity and steer a chord iteration, they need no last bit)
+    double inv = __builtin_amdgcn_rcp(den);
+    inv = fma(fma(-den, inv, 1.0), inv, inv);
+    const double eI = den > 0.0 ? -wq0 * inv : 0.0, eQ = den > 0.0 ? wi0 * inv : 0.0;
     const double cI = x * pcos, cQ = -x * psin;
     const double mask = (f_un >= pc.minfreq && f_un <= pc.maxfreq) ? 1.0 : 0.0;
     const double na1 = -pc.bq_a1, na2 = -pc.bq_a2;
