@@ -1862,8 +1862,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   if (stereo) add_halo(d_a11.p, a1_stride, H_pc, N_au);
   if (audio_len) for (int b = 0; b < nb; b++) audio_len[b] = (uint32_t)(stereo ? 2 * t_au_len[b] : t_au_len[b]);
   if (pipelined) {
-    // end of the PLL stage on the decoder stream: the next call's front end may be gated on it (FMR_FE_GATE), the tail
-    // of this call starts from it.  The tail stage itself is enqueued behind the NEXT call's front end (or by whatever
+    // end of the PLL stage on the decoder stream: the tail of this call starts from it.  The tail stage itself is enqueued behind the NEXT call's front end (or by whatever
     // synchronises the chain first): it then runs beside that call's PLL stage and leaves the front end the whole chip.
     if (!stereo) HIPCHK(hipEventRecord(ev_pll, stream));
     t.ht = k.ht; k.ht.n = 0;

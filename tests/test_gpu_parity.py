@@ -136,9 +136,10 @@ def _fm_case(name, x, blk, batch, *, fir=None, stereo=True, deemph=50.0, pilot_s
     assert st.if_agc_gain == pytest.approx(fm.get_if_agc_gain(), rel=1e-5)
     if stereo:
         # get_pilot_level is a status display value: the PLL rounds stop at a chunk-boundary mismatch of 1e-6
-        # relative in the pilot filter states, i.e. node errors of a few 1e-6 .. 1e-5; audio is
-        # unaffected at the 1e-9 level (tools/diag_rtol.py)
-        assert st.pilot_level == pytest.approx(fm.get_pilot_level(), rel=1e-4, abs=1e-9)
+        # relative in the pilot filter states; audio is unaffected at the 1e-9 level
+        # (tools/diag_rtol.py).  Measured over the suite: 1.5e-8 .. 1.5e-6 (the largest with 2517-sample blocks,
+        # whose short calls accept on the first mismatch under the threshold)
+        assert st.pilot_level == pytest.approx(fm.get_pilot_level(), rel=5e-6, abs=1e-9)
     return ch, fm, got, ref
 
 
