@@ -139,11 +139,13 @@ struct fmr_chain {
   DeScan de_scan{};
   DevBuf<double> d_de_pow;
   // Mismatch-based acceptance threshold of the PLL rounds, in units of the convergence scales (phase 1e-7 rad,
-  // freq 1e-9, phase error 1e-5, biquad delays 1e-7 relative); env FMR_PLL_RTOL, 0 = off.  At 10 the trajectory of
-  // the second integration pass is accepted in lock (boundary mismatch ~9 = 9e-7 rad): measured against the 0.01
-  // setting (third pass) the audio moves by 1.7e-9 RMS -- a tenth of the float32 front end's own 1.8e-8 deviation
-  // from the fp64-accumulating oracle, 6000x inside the 1e-5 target -- and get_pilot_level by 2e-6 .. 2e-5 relative.
-  double pll_rtol = 10.0;
+  // freq 1e-9, phase error 1e-5, biquad delays 1e-7 relative); env FMR_PLL_RTOL, 0 = off.  The second integration pass of
+  // a call in lock sees a boundary mismatch of 8.7 .. 9.0 behind the FAST resampler class and 10.4 behind the R8B class
+  // (tools/pll_mismatch.py: 7e4 after the nominal-ramp guess, 0.008 after a third pass): at 16 both are accepted there.
+  // Measured against the 0.01 setting (third pass) the audio moves by 1.7e-9 RMS -- a tenth of the float32 front end's
+  // own 1.8e-8 deviation from the fp64-accumulating oracle, 6000x inside the 1e-5 target -- and get_pilot_level by
+  // up to 2e-6 relative.  (Round 3's 10 put the R8B class one pass -- 0.15 ms per 2^27-sample call -- behind.)
+  double pll_rtol = 16.0;
   DevBuf<double> d_pll_wgr, d_pll_pre;
   DevBuf<PllSync> d_pll_sync;
   DevBuf<unsigned int> d_pll_tick2;

@@ -139,7 +139,8 @@ def _fm_case(name, x, blk, batch, *, fir=None, stereo=True, deemph=50.0, pilot_s
         # relative in the pilot filter states; audio is unaffected at the 1e-9 level
         # (tools/diag_rtol.py).  Measured over the suite: 1.5e-8 .. 1.5e-6 (the largest with 2517-sample blocks,
         # whose short calls accept on the first mismatch under the threshold)
-        assert st.pilot_level == pytest.approx(fm.get_pilot_level(), rel=5e-6, abs=1e-9)
+        # (behind the equaliser the level follows the taps, which are held to 1e-4)
+        assert st.pilot_level == pytest.approx(fm.get_pilot_level(), rel=5e-6 if stages == 0 else 1e-4, abs=1e-9)
     return ch, fm, got, ref
 
 

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--show", type=int, default=2, help="front-end periods printed")
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--out", default="")
+    ap.add_argument("--r8b", action="store_true", help="the R8B resampler class (three-kernel front end, fp16 stage B)")
+    ap.add_argument("--if-filter", action="store_true", help="the IF filter (-f medium) behind the fused front end")
     args = ap.parse_args()
     import torch
     fmr = importlib.import_module("airspy-fmradion_amd")
@@ -33,7 +35,14 @@ def main():
     n = B * blk
     iq = torch.stack([bench.synth_fm_stereo_torch(n, bench.FS, 0, dev)])
     audio = torch.zeros((1, 2 * (int(n * 0.0048) + 64)), dtype=torch.float64, device=dev)
-    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=bench.FS, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=B)
+    kw = {}
+    if args.r8b:
+        kw["resampler_class"] = fmr.RESAMPLER_R8B
+    if args.if_filter:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import load_filter
+        kw.update(fmfilter_enable=True, filter_coeff=load_filter("jj1bdx_fm_384kHz_medium"))
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=bench.FS, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=B, **kw)
     bl = [blk] * B
 
     def step():
