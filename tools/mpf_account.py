@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Cycle account of one group (four samples -> error -> coefficient update) of the equaliser kernel k_mpf3.
+"""Cycle account of one group (four samples -> error -> coefficient update) of the round-3 equaliser kernel k_mpf3 -- the
+measurement k_mpf4 (chain wave + helpers) was designed from.
 
 FMR_MPF_ACCOUNT=1 python tools/mpf_account.py [--stages 64]
 Runs FM stereo + -E at the IF rate through a chain whose equaliser kernel carries s_memtime stamps at its phase
@@ -42,4 +43,4 @@ for acct in ("0", "1"):
         print("%-64s %8.0f cycles (phases serialised by the stamps; loop control outside the stamps not counted)" % ("sum", tot))
     ch.close()
 for acct, (ms, groups) in res.items():
-    print("kernel time %s: %.3f ms for %.0f groups = %.0f ns per group" % ("with stamps" if acct == "1" else "product   ", ms, groups, ms * 1e6 / groups))
+    print("kernel time, %s: %.3f ms for %.0f groups = %.0f ns per group" % ("k_mpf3 with the stamps" if acct == "1" else "the product's kernel (k_mpf4 unless FMR_MPF3=1)", ms, groups, ms * 1e6 / groups))
