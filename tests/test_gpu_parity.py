@@ -169,6 +169,19 @@ def test_fm_medium_filter(pilotcut, fm_medium):
     ch.close()
 
 
+@pytest.mark.parametrize("ntaps", [2, 9, 32, 130, 257])
+def test_fm_if_filter_of_any_length(pilotcut, ntaps):
+    """LowPassFilterFirIQ (Filter.cpp:37-96) takes whatever symmetric coefficient vector the caller hands it: even and odd
+    lengths, shorter than a group of four outputs, longer than the golden 127 taps (k_fm_block3's four-outputs-per-lane
+    body, its remainder pairs, the middle tap, the head path at every block start and the discriminator epilogue)."""
+    h = np.hamming(ntaps).astype(np.float64) * np.sinc((np.arange(ntaps) - (ntaps - 1) / 2) * 0.5)
+    h = (h / h.sum()).astype(np.float32)
+    assert np.array_equal(h, h[::-1])
+    x = siggen.fm_stereo_iq(36 * 2517, 384e3)
+    ch, *_ = _fm_case("fm_if_filter_%d_taps" % ntaps, x, 2517, 6, fir=h, pilotcut=pilotcut)
+    ch.close()
+
+
 def test_fm_mono_75us(pilotcut):
     x = siggen.fm_mono_iq(40 * 2048, 384e3)
     ch, *_ = _fm_case("fm_mono_75us", x, 2048, 5, stereo=False, deemph=75.0, pilotcut=pilotcut)
@@ -220,6 +233,22 @@ def test_fm_multipath_config4(pilotcut):
     _report("fm_multipath_E64_coeff", coeff_rms_err=cerr, coeff_rms=rms(c_ref))
     assert cerr < 1e-4
     assert abs(ch.status().multipath_error) < 0.1
+    ch.close()
+
+
+@pytest.mark.parametrize("stages", [100, 300])
+def test_fm_multipath_long_equalisers(pilotcut, stages):
+    """-E 100 (401 taps: ten per lane of the chain wave) and -E 300 (1201 taps, the longest the chain takes: twenty per
+    lane, an eight-slot snapshot ring) -- the other two shapes of k_mpf4 (MultipathFilter.cpp:39-75: order = 4 stages + 1,
+    reference tap 3 stages + 1)."""
+    x = siggen.two_ray(siggen.fm_stereo_iq(130 * 2517, 384e3), 20)
+    ch, fm, got, ref = _fm_case("fm_multipath_E%d" % stages, x, 2517, 10, stages=stages, tol=1e-5, pilotcut=pilotcut)
+    c_got, c_ref = ch.multipath_coefficients(), fm.get_multipath_coefficients()
+    assert len(c_got) == len(c_ref) == 4 * stages + 1
+    cerr = rms(c_got - c_ref)
+    _report("fm_multipath_E%d_coeff" % stages, coeff_rms_err=cerr, coeff_rms=rms(c_ref))
+    assert cerr < 1e-4
+    assert ch.status().multipath_resets == 0
     ch.close()
 
 
