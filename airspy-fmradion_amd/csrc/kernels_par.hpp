@@ -1142,7 +1142,7 @@ __device__ __forceinline__ double pll_mismatch(const double *g, const double *nd
 // chunks ahead: 288 eight-byte gather instructions per group and one memory latency per batch -- 59 us per pass.)
 __device__ __forceinline__ void pll_stage_group(const double *__restrict__ m, const double *__restrict__ g,
                                                 const double *__restrict__ nd, int c0, int n, int lane,
-                                                double *sm, double *sr, double *so) {
+                                                double *sm, double *sr, double *so, int rs = 8 /* row stride of sr / so */) {
   constexpr int NL = (FMR_NODE_GRP * 49 + 63) / 64;
   const double *mb = m + (long long)c0 * 49;
   double tmp[NL];
@@ -1166,7 +1166,7 @@ __device__ __forceinline__ void pll_stage_group(const double *__restrict__ m, co
   for (int u = 0; u < NR; u++) {
     const int idx = lane + 64 * u;
     const int c = idx / 7, q = idx - 7 * c;
-    if (idx < FMR_NODE_GRP * 7) { sr[c * 8 + q] = tr[u]; if (so) so[c * 8 + q] = to[u]; }
+    if (idx < FMR_NODE_GRP * 7) { sr[c * rs + q] = tr[u]; if (so) so[c * rs + q] = to[u]; }
   }
 }
 
@@ -1365,15 +1365,12 @@ __global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, 
     }
     if (i == 1) nv = fmax(minfreq, fmin(maxfreq, nv));   // the true freq never leaves the clamp range
     if (act) {
-      so[t * 8 + i] = nv;                     // (each lane reads and writes only its own column)
+      so[t * 7 + i] = nv;                     // (each lane reads and writes only its own column)
       resid = fmax(resid, fabs(d) * inv_scale);
     }
   }
   __syncthreads();
-  for (int idx = i; idx < (c1 - c0) * 7; idx += 64) {
-    const int c = idx / 7, q = idx - 7 * c;
-    nd[(long long)(c0 + 1) * 7 + idx] = so[c * 8 + q];
-  }
+  for (int idx = i; idx < (c1 - c0) * 7; idx += 64) nd[(long long)(c0 + 1) * 7 + idx] = so[idx];
   // one residual row per group (component 0..6, slot 7 = max); k_pll_check reduces them --
   // same-address atomics from thousands of groups would serialise in L2
   double rmax = act ? resid : 0.0;
@@ -1450,10 +1447,12 @@ __global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes,
                                                double *__restrict__ PRE, double *PQ2, int ngrp2,
                                                double *__restrict__ dstart2, const IterFlags *__restrict__ fl,
                                                PllSync *__restrict__ sync, unsigned int *__restrict__ tick2) {
-  __shared__ double sm[FMR_NODE_GRP2 * 56];      // phase A uses FMR_NODE_GRP * 49 of it
-  __shared__ double sr[FMR_NODE_GRP * 8];
+  // 14.8 KB of LDS in all: ten workgroups per CU, i.e. the ~2500 groups of a 2^27-sample call in ONE round (with the
+  // mismatches in an array of their own it was 16.9 KB, nine per CU, and a tenth of the groups ran behind the others)
+  __shared__ double sm[FMR_NODE_GRP2 * 56];      // phase A: FMR_NODE_GRP * 49 Jacobian entries, then the mismatches (stride 7)
   __shared__ double sh[64];
-  static_assert(FMR_NODE_GRP2 * 56 >= FMR_NODE_GRP * 49, "shared staging buffer");
+  static_assert(FMR_NODE_GRP2 * 56 >= FMR_NODE_GRP * (49 + 7), "shared staging buffer");
+  double *const sr = sm + FMR_NODE_GRP * 49;
   const int s = blockIdx.y, grp = blockIdx.x, ngrp = gridDim.x;
   if (fl[s].pll_converged) return;
   const int lane = threadIdx.x, i = lane >> 3, k = lane & 7;
@@ -1464,13 +1463,13 @@ __global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes,
     const double *g = G + (long long)s * nck * 9;
     const double *m = M + (long long)s * nck * 49;
     const int c0 = grp * FMR_NODE_GRP, c1 = min(c0 + FMR_NODE_GRP, nck);
-    pll_stage_group(m, g, nd, c0, c1 - c0, lane, sm, sr, nullptr);
+    pll_stage_group(m, g, nd, c0, c1 - c0, lane, sm, sr, nullptr, 7);
     __syncthreads();
     double val = (act && i == k) ? 1.0 : 0.0;   // P = I, q = 0
     for (int t = 0; t < c1 - c0; t++) {
       sh[lane] = val;
       __syncthreads();                      // one wave per block: just orders the LDS write
-      double acc = (k == 7) ? sr[t * 8 + ii] : 0.0;
+      double acc = (k == 7) ? sr[t * 7 + ii] : 0.0;
       const double *row = sm + t * 49 + ii * 7;
 #pragma unroll
       for (int j = 0; j < 7; j++) acc = fma(row[j], sh[j * 8 + k], acc);
@@ -1534,9 +1533,9 @@ __global__ __launch_bounds__(64) void k_pll_down(double *__restrict__ nodes, con
                                                  const double *__restrict__ PRE, const double *__restrict__ dstart2,
                                                  int ngrp2, const IterFlags *__restrict__ fl, double minfreq,
                                                  double maxfreq, PllSync *__restrict__ sync) {
-  __shared__ double sm[FMR_NODE_GRP * 49];
-  __shared__ double sr[FMR_NODE_GRP * 8];
-  __shared__ double so[FMR_NODE_GRP * 8];
+  __shared__ double sm[FMR_NODE_GRP * 49];       // (15.8 KB in all: ten workgroups per CU, see k_pll_up)
+  __shared__ double sr[FMR_NODE_GRP * 7];
+  __shared__ double so[FMR_NODE_GRP * 7];
   const int s = blockIdx.y, grp = blockIdx.x, ngrp = gridDim.x;
   if (fl[s].pll_converged) return;
   const int i = threadIdx.x;
@@ -1559,7 +1558,7 @@ __global__ __launch_bounds__(64) void k_pll_down(double *__restrict__ nodes, con
   const double wm = fabs(g[(long long)c0 * 9 + 3]) + fabs(g[(long long)c0 * 9 + 5]);
   double inv_scale = 1.0 / (1e-7 * (wm + 1.0));
   if (i == 0) inv_scale = 1e7; else if (i == 1) inv_scale = 1e9; else if (i == 2) inv_scale = 1e5;
-  pll_stage_group(m, g, nd, c0, c1 - c0, i, sm, sr, so);
+  pll_stage_group(m, g, nd, c0, c1 - c0, i, sm, sr, so, 7);
   __syncthreads();
   double d = fma(pr[0], dv[0], fma(pr[1], dv[1], pr[7])) + (fma(pr[2], dv[2], pr[3] * dv[3]) +
              fma(pr[4], dv[4], fma(pr[5], dv[5], pr[6] * dv[6])));
@@ -1568,26 +1567,23 @@ __global__ __launch_bounds__(64) void k_pll_down(double *__restrict__ nodes, con
     const double *row = sm + t * 49 + ii * 7;
     const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2v = readlane_d(d, 2), d3 = readlane_d(d, 3),
                  d4 = readlane_d(d, 4), d5 = readlane_d(d, 5), d6 = readlane_d(d, 6);
-    const double p0 = fma(row[0], d0, fma(row[1], d1, sr[t * 8 + ii]));
+    const double p0 = fma(row[0], d0, fma(row[1], d1, sr[t * 7 + ii]));
     const double p1 = fma(row[2], d2v, row[3] * d3);
     const double p2 = fma(row[4], d4, fma(row[5], d5, row[6] * d6));
     d = p0 + (p1 + p2);                       // delta of node c+1
-    double nv = so[t * 8 + ii] + d;
+    double nv = so[t * 7 + ii] + d;
     if (i == 0) {                             // keep the phase inside (0, 2 pi] like the reference
       nv -= two_pi * floor(nv * inv_two_pi);
       if (nv <= 0.0) nv += two_pi;
     }
     if (i == 1) nv = fmax(minfreq, fmin(maxfreq, nv));   // the true freq never leaves the clamp range
     if (act) {
-      so[t * 8 + i] = nv;                     // (each lane reads and writes only its own column)
+      so[t * 7 + i] = nv;                     // (each lane reads and writes only its own column)
       resid = fmax(resid, fabs(d) * inv_scale);
     }
   }
   __syncthreads();
-  for (int idx = i; idx < (c1 - c0) * 7; idx += 64) {
-    const int c = idx / 7, q = idx - 7 * c;
-    nd[(long long)(c0 + 1) * 7 + idx] = so[c * 8 + q];
-  }
+  for (int idx = i; idx < (c1 - c0) * 7; idx += 64) nd[(long long)(c0 + 1) * 7 + idx] = so[idx];
   // ~40 groups share a slot: same-address atomics from all the groups would serialise in L2
   if (act) atomicMax(&sync[s].dslot[grp & 63][i], pll_max_bits(resid));
 }
