@@ -1011,8 +1011,9 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
     __syncthreads();
     // tile in: lanes 0-31 take chunk j, lanes 32-63 chunk j+1 (clamped addresses instead of predicates: loads under a
     // branch make the compiler wait for each of them)
-    // (all loads of a tile in flight at once: one memory latency per tile; the Jacobian variant has no registers to spare)
-    constexpr int NLD = JAC ? 8 : 32;
+    // (all loads of a tile in flight at once: one memory latency per tile.  The Jacobian variant took them eight at a time
+    // while it needed 226 registers without them; since the rotation and the reciprocal it has room: 246 with all 32)
+    constexpr int NLD = 32;
 #pragma unroll 1
     for (int j0 = 0; j0 < 64; j0 += 2 * NLD) {
       double v[NLD];
@@ -1509,11 +1510,23 @@ __global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes,
     const bool a7 = lane < 7;
     const int l7 = a7 ? lane : 0;
     double d = 0.0;
+    // the maps of the next batch of 32 are fetched while this one is walked (a memory latency per batch otherwise)
+    constexpr int NLQ = (FMR_NODE_GRP2 * 56 + 63) / 64;
+    double nxt[NLQ];
+    auto fetch = [&](int q0) {
+      const int n = min(FMR_NODE_GRP2, ngrp2 - q0);
+      const double *pb = pq2 + (long long)q0 * 56;
+#pragma unroll
+      for (int u = 0; u < NLQ; u++) { const int idx = lane + 64 * u; nxt[u] = (idx < n * 56) ? ld_agent(pb + idx) : 0.0; }
+    };
+    fetch(0);
     for (int q0 = 0; q0 < ngrp2; q0 += FMR_NODE_GRP2) {
       const int n = min(FMR_NODE_GRP2, ngrp2 - q0);
       __syncthreads();
-      pll_stage_pq<true>(pq2, q0, n, lane, sm);
+#pragma unroll
+      for (int u = 0; u < NLQ; u++) { const int idx = lane + 64 * u; if (idx < FMR_NODE_GRP2 * 56) sm[idx] = nxt[u]; }
       __syncthreads();
+      if (q0 + FMR_NODE_GRP2 < ngrp2) fetch(q0 + FMR_NODE_GRP2);
       for (int t = 0; t < n; t++) {
         if (a7) ds[(long long)(q0 + t) * 7 + lane] = d;
         const double *row = sm + (t * 7 + l7) * 8;
