@@ -470,6 +470,8 @@ struct fmr_chain {
     long long N_if{}, N_au{}, a_top0{}, amA_prev{}, akB_prev{}, astride{};
     int nb{}, count_am{}, de_tout{}, dc_nc{}, nch{};
     bool de_fused{}, fin_on_side{}, fin_covers_all{}, agc_on_side{}, mono_enqueued{};
+    bool can_split{};            // the mono channel can be enqueued by itself (the shapes the per-channel tail kernels take)
+    hipEvent_t ev_mpx = nullptr; // "the MPX of this call is there" (pipelined chain: what a drained tail's mono channel waits for)
     BlockTab bt{};
     double *d_aud = nullptr;
     DcCoef dk{};
@@ -1838,8 +1840,9 @@ int fmr_chain::run_fm(CallCtx &k) {
   // the PLL iterates, and only L-R stays behind the PLL on the decoder stream.  In the pipelined chain both channels belong
   // to the tail STAGE (its own stream, a call behind the PLL stage): the mono channel's buffers are still being read by the
   // previous call's DC block and mux while this call's PLL iterates.
-  const bool split_mono = stereo && !serial_mode && !pipelined && t.de_fused && (ars.LB == 3 && ars.MB == 8) &&
-                          n_pilotcut <= FMR_PCUT_MAXTAPS;
+  t.can_split = stereo && !serial_mode && t.de_fused && (ars.LB == 3 && ars.MB == 8) && n_pilotcut <= FMR_PCUT_MAXTAPS;
+  t.ev_mpx = k.ev_mpx;
+  const bool split_mono = t.can_split && !pipelined;
   bool mono_enqueued = false;
   if (stereo) {
     auto tail_fn = [&](hipStream_t st, int ch_base, int nch_l) { tail_channels(t, st, ch_base, nch_l); };
@@ -1996,7 +1999,17 @@ int fmr_chain::tail_stage(const TailCtx &t, hipStream_t ts) {
 int fmr_chain::flush_tail(hipEvent_t gate) {
   if (!tail_pending) return FMR_OK;
   tail_pending = false;
-  const TailCtx &t = tail_job;
+  TailCtx t = tail_job;
+  if (!gate && t.can_split && !t.mono_enqueued && t.ev_mpx) {
+    // Drain (a synchronising call, no front end follows): the mono channel does not depend on the PLL -- it starts from the
+    // MPX, behind the tail of the call before (same stream, enqueued when this call's front end was), beside this call's
+    // PLL passes.  A caller that synchronises after every call gets its audio 0.1 ms earlier; a timed region of K calls
+    // ends that much earlier.  (In steady state the tail waits for the NEXT front end instead: see run_fm.)
+    HIPCHK(hipStreamWaitEvent(tail, t.ev_mpx, 0));
+    tail_channels(t, tail, 0, 1);
+    HIPCHK(hipEventRecord(ev_mono, tail));
+    t.mono_enqueued = true;
+  }
   HIPCHK(hipStreamWaitEvent(tail, ev_pll, 0));
   if (gate) HIPCHK(hipStreamWaitEvent(tail, gate, 0));
   if (int rc = tail_stage(t, tail)) return rc;
