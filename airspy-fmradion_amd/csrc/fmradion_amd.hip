@@ -1515,7 +1515,10 @@ int fmr_chain::run_if_stage(CallCtx &k) {
   if (!rms_in_disc) {
     timed("fm_block", [&] {
       // four outputs per lane; FM without the equaliser: the discriminator is its epilogue (k_disc is not launched)
-      constexpr int TL = 1024;
+      // tile length: 1024 outputs, or the longest IF block of the call rounded up to four when that is shorter
+      int tl = 4;
+      for (int b = 0; b < nb; b++) tl = std::max(tl, (k.t_if_len[b] + 3) & ~3);
+      const int TL = std::min(1024, tl);
       const size_t lds_fb = sizeof(float2) * (4 * (size_t)fm_block3_plane(ntaps - 1, TL) + ((size_t)ntaps + 4) / 2 + (size_t)(ntaps - 1) + TL);
       const bool blocked = fir_enable && ntaps >= 2 && lds_fb <= 60000 && !serial_mode;
       k.fir_disc = blocked && mode == FMR_MODE_FM && !enable_mpf;
@@ -1523,14 +1526,21 @@ int fmr_chain::run_if_stage(CallCtx &k) {
         hipLaunchKernelGGL(kern, dim3(nb, S), dim3(256), lds_fb, stream, ifbuf, if_stride, H_if, bt,
                            d_coeff.p, ntaps, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if, d_if_rms_blk.p,
                            disc_nf, disc_bound, d_dec.p, (long long)max_if, k.base, H_b + (long long)max_if, H_b,
-                           d_bb_mean_blk.p, d_bb_rms_blk.p, d_blk_ph.p);
+                           d_bb_mean_blk.p, d_bb_rms_blk.p, d_blk_ph.p, TL);
       };
       if (k.fir_disc) {
         go(k_fm_block3<256, true>);
         hipLaunchKernelGGL(k_disc_heads, dim3((nb + 255) / 256, S), dim3(256), 0, stream, bt, d_blk_ph.p, disc_bound, d_dec.p,
                            (long long)max_if, k.base, H_b + (long long)max_if, H_b, d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);
       }
-      else if (blocked) go(k_fm_block3<256, false>);
+      else if (blocked && mode == FMR_MODE_FM) go(k_fm_block3<256, false>);       // (FM with the equaliser behind the filter)
+      else if (blocked) {
+        // the 48 kHz modes: blocks of a few hundred samples behind 255 or 2049 taps, nearly every output a head output
+        constexpr int TL2 = 1024;
+        const size_t lds2 = sizeof(float2) * ((size_t)(ntaps - 1) + TL2) + sizeof(float) * (size_t)ntaps;
+        hipLaunchKernelGGL((k_fm_block2<256, TL2>), dim3(nb, S), dim3(256), lds2, stream, ifbuf, if_stride, H_if, bt,
+                           d_coeff.p, ntaps, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if, d_if_rms_blk.p);
+      }
       else
       hipLaunchKernelGGL(k_fm_block<256>, dim3(nb, S), dim3(256), 0, stream, ifbuf, if_stride, H_if, bt, d_coeff.p,
                          ntaps, (int)fir_enable, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if,

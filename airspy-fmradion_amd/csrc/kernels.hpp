@@ -1272,6 +1272,74 @@ __global__ __launch_bounds__(BLOCK) void k_fm_block(
   if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);
 }
 
+// K_blk v2 (round 2): the same arithmetic (identical operation order, bit-identical results) out of LDS, one output per
+// lane -- the kernel of the 48 kHz modes (AM, SSB, CW: 256-sample blocks, 255 / 2049 taps), where almost every output is a
+// head output and k_fm_block3 below measured 0.168 against this kernel's 0.145 ms per 2 M IF samples.  The block is walked in
+// tiles of TL outputs; a tile's window (order history samples + TL) and the coefficients are staged once, so a tap costs
+// two LDS reads instead of two cached global loads -- the AM / SSB filters have 255 / 2049 taps, and with the 48 kHz
+// modes' short blocks almost every output takes the sequential block-head path (hazard H1).
+template <int BLOCK, int TL>
+__global__ __launch_bounds__(BLOCK) void k_fm_block2(
+    const float2 *__restrict__ ifb, long long if_stride, int if_halo, BlockTab bt,
+    const float *__restrict__ coeff, int ntaps, int rms_after_fir,
+    float2 *__restrict__ firb, long long fir_stride, float *__restrict__ if_rms_blk) {
+  extern __shared__ float2 lds_fb[];
+  __shared__ float scratch[BLOCK / 64];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int n = bt.if_len[b];
+  if (n == 0) return;
+  const int order = ntaps - 1;
+  const int half_order = (order - 1) / 2;
+  float2 *xs = lds_fb;                                              // [order + TL]: xs[order + t] = x[i0 + t]
+  float *cs = reinterpret_cast<float *>(lds_fb + order + TL);       // [ntaps]
+  const float2 *x = ifb + (long long)s * if_stride + if_halo + bt.if_off[b];
+  float2 *y = firb + (long long)s * fir_stride + bt.if_off[b];
+  for (int k = threadIdx.x; k < ntaps; k += BLOCK) cs[k] = coeff[k];
+  float acc = 0.f;
+  for (int i0 = 0; i0 < n; i0 += TL) {
+    const int tn = min(TL, n - i0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < order + tn; k += BLOCK) xs[k] = x[i0 - order + k];    // (reaches into the prefix halo)
+    __syncthreads();
+    for (int t = threadIdx.x; t < tn; t += BLOCK) {
+      const int i = i0 + t;
+      const float2 *xl = xs + order + t;                            // xl[-j] = x[i - j]
+      float yr = 0.f, yi = 0.f;
+      if (i < order) {
+        // head: lags 1..order, state part first then in-block part (Filter.cpp:59-68)
+        for (int j = i + 1; j <= order; j++) {
+          const float2 tt = xl[-j];
+          const float c = cs[j];
+          yr += tt.x * c; yi += tt.y * c;
+        }
+        for (int j = 1; j <= i; j++) {
+          const float2 tt = xl[-j];
+          const float c = cs[j];
+          yr += tt.x * c; yi += tt.y * c;
+        }
+      } else {
+        // body: folded symmetric form incl. lag 0 (Filter.cpp:73-82)
+        for (int k = 0; k <= half_order; k++) {
+          const float2 a = xl[-k], bb = xl[-(order - k)];
+          const float c = cs[k];
+          yr += (a.x + bb.x) * c; yi += (a.y + bb.y) * c;
+        }
+        if ((order % 2) == 0) {
+          const float2 tt = xl[-(order / 2)];
+          const float c = cs[order / 2];
+          yr += tt.x * c; yi += tt.y * c;
+        }
+      }
+      const float2 o = make_float2(yr, yi);
+      y[i] = o;
+      const float2 v = rms_after_fir ? o : xl[0];
+      acc += v.x * v.x + v.y * v.y;
+    }
+  }
+  const float tot = block_sum<BLOCK>(acc, scratch);
+  if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);
+}
+
 // ---------------------------------------------------------------------------
 // K_fm_block3 (round 4): k_fm_block's arithmetic (identical operation order, bit-identical results) out of LDS -- the block
 // is walked in tiles, a tile's window (order history samples + the tile) and the coefficients are staged once; the AM / SSB
@@ -1331,7 +1399,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     float nf, float bound, float *__restrict__ dec, long long dec_stride,
     double *__restrict__ base, long long base_stride, int base_off,
     float *__restrict__ bb_mean_blk /* DISC: the block's sum of d without its first sample */,
-    float *__restrict__ bb_rms_blk /* DISC: the sum of d^2 likewise */, float *__restrict__ blk_ph /* [S][nb][2] */) {
+    float *__restrict__ bb_rms_blk /* DISC: the sum of d^2 likewise */, float *__restrict__ blk_ph /* [S][nb][2] */,
+    int tl /* tile length: a multiple of 4, <= 4 BLOCK; the host sizes the dynamic LDS for it (short blocks -- the 48 kHz
+              modes' 256 samples -- need a quarter of the 1024-output tile's LDS, i.e. four times the workgroups per CU) */) {
   typedef float v2f __attribute__((ext_vector_type(2)));
   constexpr int R = 4, TL = BLOCK * R;
   extern __shared__ float2 lds_fb[];
@@ -1342,19 +1412,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
   if (n == 0) return;
   const int order = ntaps - 1;
   const int half_order = (order - 1) / 2, npairs = half_order + 1;
-  const int PL = fm_block3_plane(order, TL);
+  const int PL = fm_block3_plane(order, tl);
   float2 *xs = lds_fb;                                              // [4 PL]: sample m of the window (x[i0 - order + m]) at XS(m)
   auto XS = [&](int m) -> float2 & { return xs[(m & 3) * PL + (m >> 2)]; };
   float *cs = reinterpret_cast<float *>(lds_fb + 4 * PL);           // [ntaps + 3 (+1)], 16-byte aligned
-  float2 *xlin = lds_fb + 4 * PL + ((ntaps + 3 + 1) / 2);           // [order + TL]: the same window in order, for the one-output code
+  float2 *xlin = lds_fb + 4 * PL + ((ntaps + 3 + 1) / 2);           // [order + tl]: the same window in order, for the one-output code
                                                                     // (lanes read consecutive samples there; in planes every read needs its own address arithmetic)
   const float2 *x = ifb + (long long)s * if_stride + if_halo + bt.if_off[b];
   float2 *y = firb + (long long)s * fir_stride + bt.if_off[b];
   for (int k = threadIdx.x; k < ntaps + 3; k += BLOCK) cs[k] = k < ntaps ? coeff[k] : 0.f;
   float acc = 0.f, vsum = 0.f, vsq = 0.f;
   float carry = 0.f;                                                // (lane BLOCK - 1: phase of the last output of the tile before)
-  for (int i0 = 0; i0 < n; i0 += TL) {
-    const int tn = min(TL, n - i0);
+  for (int i0 = 0; i0 < n; i0 += tl) {
+    const int tn = min(tl, n - i0);
     __syncthreads();
     if (DISC && i0 > 0 && threadIdx.x == BLOCK - 1) ph[0] = carry;
     for (int k = threadIdx.x; k < order + tn; k += BLOCK) { const float2 v = x[i0 - order + k]; XS(k) = v; xlin[k] = v; }    // (reaches into the prefix halo)
