@@ -338,7 +338,8 @@ struct fmr_chain {
                               std::strcmp(name, "disc") == 0 || std::strcmp(name, "ifr_fused") == 0 ||
                               std::strcmp(name, "blk_reduce") == 0 ||
                               (mode == FMR_MODE_FM && std::strcmp(name, "fm_block") == 0);   // FM with the IF FIR on
-    if (timing == 2 && stage_kernel) {
+    // mode 4: the same on every fourth call only (two event markers on the decoder stream cost 7-10 us of a 0.56 ms step)
+    if ((timing == 2 || (timing == 4 && (call_seq & 3ull) == 0)) && stage_kernel) {
       KernelTime kt{name, nullptr, nullptr};
       (void)hipEventCreate(&kt.a);
       (void)hipEventCreate(&kt.b);
@@ -2470,7 +2471,7 @@ int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap) {
   if (!c) return FMR_ERR_BAD_ARG;
   if (int rc = c->sync_all()) return rc;
   int n = 0;
-  if (c->timing == 2) {   // dominant kernel only: one entry per call since the last query
+  if (c->timing == 2 || c->timing == 4) {   // dominant kernel only: one entry per call since the last query
     for (auto &k : c->dom_times) {
       float t = 0.f;
       (void)hipEventElapsedTime(&t, k.a, k.b);

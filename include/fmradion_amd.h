@@ -219,8 +219,9 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
  * the most recent call (diagnostics; the extra events cost host time).  enable = 2: only the
  * kernels of the FIR + discriminator stage ("ifr_fused", or "ifr_decim" / "ifr_poly" / "disc", and the IF FIR
  * "fm_block" of an FM chain), one entry per launch accumulated until queried
- * (what bench.py uses inside its timed region).  Fills names/ms for up to cap entries,
- * returns the count. */
+ * (what bench.py uses inside its timed region); enable = 4: the same on every fourth call only (the two event
+ * markers of a stage kernel cost 7-10 us on the decoder stream: bench.py samples).  Fills names/ms for up to cap
+ * entries, returns the count. */
 int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap);
 void fmr_enable_kernel_timing(fmr_chain *c, int enable);
 
