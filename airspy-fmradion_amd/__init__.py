@@ -47,6 +47,7 @@ class Config(C.Structure):
         ("deemphasis_us", C.c_double), ("pilot_shift", C.c_int), ("multipath_stages", C.c_uint),
         ("max_block_len", C.c_size_t), ("max_blocks", C.c_int), ("nbfm_freq_dev", C.c_double),
         ("input_format", C.c_int), ("output_rate", C.c_double), ("resampler_class", C.c_int), ("struct_size", C.c_uint),
+        ("in_order", C.c_int),
     ]
 
 
@@ -194,7 +195,7 @@ class Chain:
     def __init__(self, mode=MODE_FM, input_rate=384000.0, enable_resampler=False, fourth_down=False,
                  fmfilter_enable=False, filter_coeff=None, stereo=True, deemphasis_us=50.0, pilot_shift=False,
                  multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0, nbfm_freq_dev=0.0, input_format=0,
-                 output_rate=0.0, resampler_class=RESAMPLER_FAST):
+                 output_rate=0.0, resampler_class=RESAMPLER_FAST, in_order=False):
         coeff = np.ascontiguousarray(DELAY_3TAPS if filter_coeff is None else filter_coeff, dtype=np.float32)
         self._coeff = coeff
         cfg = Config()
@@ -211,6 +212,7 @@ class Chain:
         cfg.output_rate = float(output_rate)
         cfg.resampler_class = int(resampler_class)
         cfg.struct_size = C.sizeof(Config)
+        cfg.in_order = int(bool(in_order))
         self.input_format = int(input_format)
         self.n_streams, self.mode, self.stereo = n_streams, mode, bool(stereo) and mode == MODE_FM
         self.h = C.c_void_p()

@@ -532,7 +532,7 @@ int fmr_chain::init(const fmr_config *c) {
   // Three, because a process gets four hardware queues from HIP, the host application's own stream included, and more
   // busy queues than that take turns on a pipe in slices of 3.55 ms (measured with four and five busy queues, with and
   // without stream priorities: one process in two then runs at 4-36 ms per step).
-  pipelined = mode == FMR_MODE_FM && c->enable_resampler != 0 && !env.serial && env.pipeline != 0;
+  pipelined = mode == FMR_MODE_FM && c->enable_resampler != 0 && !env.serial && env.pipeline != 0 && c->in_order == 0;
   HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
   if (pipelined) {

@@ -66,6 +66,8 @@ inline void fail(const char *what) {
 inline fmr_chain *make(const fmr_config &cfg0) {
   fmr_config cfg = cfg0;
   cfg.struct_size = sizeof(fmr_config);      // the header this translation unit was built against
+  cfg.in_order = 1;                          // every facade call goes through host buffers and synchronises: nothing for the
+                                             // pipelined chain to overlap (include/fmradion_amd.h)
   fmr_chain *c = nullptr;
   check(fmr_create(&cfg, &c), "fmr_create");
   return c;

@@ -359,7 +359,8 @@ def main():
                        multipath_stages=args.multipath_stages,
                        **({"fmfilter_enable": True, "filter_coeff": np.load(os.path.join(
                            ROOT, "tests", "golden", "filters", "jj1bdx_fm_384kHz_medium.npy"))} if args.if_filter else {}),
-                       resampler_class=fmr.RESAMPLER_R8B if args.resampler_class == "r8b" else fmr.RESAMPLER_FAST)
+                       resampler_class=fmr.RESAMPLER_R8B if args.resampler_class == "r8b" else fmr.RESAMPLER_FAST,
+                       in_order=(args.api_mode == "block"))      # the host-buffer call synchronises every time
     block_len = [blk] * B
     torch.cuda.synchronize()
 

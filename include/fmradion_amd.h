@@ -104,6 +104,11 @@ typedef struct {
    * grows at its end from version to version: fmr_create refuses a size it does not know instead of reading past a
    * shorter struct or misreading a longer one.  Zero-initialise the whole struct first (an unset field must read 0). */
   unsigned struct_size;
+  /* 1: one in-order launch chain per call instead of the pipelined one (front end of call N+1 behind the PLL stage of
+   * call N, audio tail a call behind).  For callers that synchronise after every call -- fmr_process / fmr_process_blocks
+   * through host buffers, the facade's FmDecoder::process -- the pipelined chain has nothing to overlap and pays for its
+   * stage hand-offs: 341 against 303 us per 65536-sample block.  Same audio, bit for bit.  0 (default): pipelined. */
+  int in_order;
 } fmr_config;
 
 /* Per-stream status after the most recent call (getters of FmDecode.h:77-105 /

@@ -8,7 +8,7 @@ import siggen
 fmr = importlib.import_module("airspy-fmradion_amd")
 blk, nblk = 65536, 200
 x = siggen.fm_stereo_iq(64 * blk, 10e6)
-ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=1)
+ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=1, in_order=True)
 for i in range(100):
     ch.process(x[(i % 64) * blk:(i % 64 + 1) * blk])
 t0 = time.perf_counter()
