@@ -228,9 +228,8 @@ struct fmr_chain {
   // fused front end (kernels_fused.hpp): stage A + stage B + discriminator in one persistent kernel
   bool fused_ok = false;               // the chain's shape fits (10 MS/s class, FM, cf32, no Fs/4)
   bool fused_disc_ok = false;          // ... and nothing sits between the resampler and the discriminator (no IF FIR, no equaliser)
-  FusedTaps fused_taps{};
   DevBuf<float> d_hB_last;             // stage-B tap row of position 47
-  DevBuf<float> d_fused_taps;          // device copy of fused_taps
+  DevBuf<unsigned short> d_fused_afragA;   // stage-A tap fragments (fp16 high / low terms, both parities)
   DevBuf<FusedPart> d_fused_part;
   int n_cu = 256;
   DevBuf<float> d_hBp;                 // zero-padded tap rows for v3
@@ -303,7 +302,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_taps.release(); d_fused_part.release(); d_afrag.release(); d_afrag5.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_afragA.release(); d_fused_part.release(); d_afrag.release(); d_afrag5.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -717,10 +716,10 @@ int fmr_chain::init(const fmr_config *c) {
           bool sym = rs.D == kFusedD && rs.NA == kFusedNA;
           for (int k = 0; sym && k < rs.NA / 2; k++) sym = (fa[k] == fa[rs.NA - 1 - k]);
           if (sym && mode == FMR_MODE_FM && in_fmt == 0 && !c->enable_fourth_down && !env.no_fused) {
-            for (int k = 0; k < FUSED_TAP_LEN; k++) fused_taps.h[k] = 0.f;
-            for (int k = 0; k < rs.NA; k++) fused_taps.h[FUSED_TAP_PAD + k] = fa[k];
             if ((rc = upload(d_hB_last, fb.data() + (size_t)phi[47] * rs.TB, (size_t)rs.TB))) return rc;
-            if ((rc = upload(d_fused_taps, fused_taps.h, (size_t)FUSED_TAP_LEN))) return rc;
+            { std::vector<unsigned short> fr((size_t)2 * 8 * 2 * 64 * 8);
+              fused_make_afragA<kFusedD, kFusedNA>(fa.data(), fr.data());
+              if ((rc = upload(d_fused_afragA, fr.data(), fr.size()))) return rc; }
             constexpr int kL = FusedShape<kFusedD, kFusedNA>::LDS_BYTES;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
@@ -1433,7 +1432,7 @@ int fmr_chain::run_tables(CallCtx &k) {
     constexpr int D = kFusedD, NA = kFusedNA;
     FusedArgs a{};
     a.iq = d_iq; a.iq_stride = (long long)stride; a.n_valid = N_in;
-    a.in_halo = d_in_halo.p; a.H_in = H_in; a.taps = d_fused_taps.p;
+    a.in_halo = d_in_halo.p; a.H_in = H_in; a.afragA = reinterpret_cast<const uint4 *>(d_fused_afragA.p); a.hA = d_hA.p; a.hB = d_hB.p;
     const long long n0 = (long long)rs.D * fused_geom.mA_prev - fused_geom.n_prev;
     const long long lo0 = n0 + rs.ca() - (NA - 1);
     const int par = (int)(((lo0 % 2) + 2) % 2);

@@ -29,8 +29,7 @@ struct Ctx {
   size_t max_in, max_mid, max_if;
   float2 *d_in_halo, *d_mid, *d_if_old, *d_if_new;
   float *d_hpA, *d_afrag;
-  FusedTaps taps;
-  unsigned long long *d_dbg = nullptr; float *d_taps = nullptr;
+  unsigned long long *d_dbg = nullptr; uint4 *d_afragA = nullptr; float *d_hAf = nullptr, *d_hBf = nullptr;
   long long wg_key = -1;
   double *d_base = nullptr; float *d_dec = nullptr, *d_hBlast = nullptr, *d_stats = nullptr; StreamState *d_st = nullptr; FusedPart *d_part = nullptr; int *d_tab = nullptr;
   bool epi = false, lean = false; int h_off_dev400 = 0; int nb = 0; std::vector<int> h_off, h_len; int *d_wgblk = nullptr;
@@ -47,11 +46,8 @@ static void setup(Ctx &c, size_t max_in) {
   std::vector<float> hp((size_t)rs.D * qa, 0.f);
   for (int k = 0; k < rs.NA; k++) hp[(size_t)(k % rs.D) * qa + k / rs.D] = fa[k];
   CK(hipMalloc(&c.d_hpA, hp.size() * 4)); CK(hipMemcpy(c.d_hpA, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
-  for (int k = 0; k < FUSED_TAP_LEN; k++) c.taps.h[k] = 0.f;
-  for (int k = 0; k < rs.NA; k++) {
-    c.taps.h[FUSED_TAP_PAD + k] = fa[k];
+  for (int k = 0; k < rs.NA; k++)
     if (fa[k] != fa[rs.NA - 1 - k]) { printf("stage-A taps are not symmetric at %d\n", k); exit(1); }
-  }
   std::vector<int> phi(rs.LB), off(rs.LB);
   for (long long q = 0; q < rs.LB; q++) { phi[q] = (int)((q * rs.MB) % rs.LB); off[q] = (int)((q * rs.MB) / rs.LB); }
   c.poly2_tile = (int)(64 * rs.MB + off[rs.LB - 1] + rs.TB) + 64;
@@ -70,10 +66,14 @@ static void setup(Ctx &c, size_t max_in) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 125, 210>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
   constexpr int kL = FusedShape<kFusedD, kFusedNA>::LDS_BYTES;
 #define SETATTR(P, A) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, P, A>), hipFuncAttributeMaxDynamicSharedMemorySize, kL))
-  SETATTR(0, 0); SETATTR(1, 0); SETATTR(0, 1); SETATTR(1, 1); SETATTR(0, 2); SETATTR(1, 2); SETATTR(0, 3); SETATTR(1, 3);
+  SETATTR(0, 0); SETATTR(1, 0); SETATTR(0, 512); SETATTR(1, 512); SETATTR(0, 2560); SETATTR(1, 2560); SETATTR(0, 1536); SETATTR(1, 1536); SETATTR(0, 64); SETATTR(1, 64); SETATTR(0, 128); SETATTR(1, 128); SETATTR(0, 256); SETATTR(1, 256); SETATTR(0, 448); SETATTR(1, 448); SETATTR(0, 46); SETATTR(1, 46); SETATTR(0, 54); SETATTR(1, 54); SETATTR(0, 39); SETATTR(1, 39); SETATTR(0, 1); SETATTR(1, 1); SETATTR(0, 2); SETATTR(1, 2); SETATTR(0, 3); SETATTR(1, 3);
   SETATTR(0, 4); SETATTR(1, 4); SETATTR(0, 7); SETATTR(1, 7); SETATTR(0, 5); SETATTR(1, 5); SETATTR(0, 6); SETATTR(1, 6);
   SETATTR(0, 14); SETATTR(1, 14); SETATTR(0, 22); SETATTR(1, 22); SETATTR(0, 32); SETATTR(1, 32); SETATTR(0, 36); SETATTR(1, 36); SETATTR(0, 38); SETATTR(1, 38); SETATTR(0, 37); SETATTR(1, 37); SETATTR(0, 35); SETATTR(1, 35);
-  CK(hipMalloc(&c.d_taps, FUSED_TAP_LEN * 4)); CK(hipMemcpy(c.d_taps, c.taps.h, FUSED_TAP_LEN * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&c.d_hAf, fa.size() * 4)); CK(hipMemcpy(c.d_hAf, fa.data(), fa.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&c.d_hBf, fb.size() * 4)); CK(hipMemcpy(c.d_hBf, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
+  { std::vector<unsigned short> fr(2 * 8 * 2 * 64 * 8);
+    fused_make_afragA<kFusedD, kFusedNA>(fa.data(), fr.data());
+    CK(hipMalloc(&c.d_afragA, fr.size() * 2)); CK(hipMemcpy(c.d_afragA, fr.data(), fr.size() * 2, hipMemcpyHostToDevice)); }
   CK(hipMalloc(&c.d_dbg, 32 * 8)); CK(hipMemset(c.d_dbg, 0, 32 * 8));
   CK(hipMalloc(&c.d_wgblk, 1024 * 4));
   CK(hipMalloc(&c.d_base, c.max_if * 8)); CK(hipMalloc(&c.d_dec, c.max_if * 4)); CK(hipMalloc(&c.d_st, sizeof(StreamState)));
@@ -120,7 +120,7 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
   constexpr int D = kFusedD, NA = kFusedNA;
   FusedArgs a{};
   a.iq = d_iq; a.iq_stride = (long long)c.max_in; a.n_valid = g.N_in;
-  a.in_halo = c.d_in_halo; a.H_in = c.H_in; a.taps = c.d_taps;
+  a.in_halo = c.d_in_halo; a.H_in = c.H_in; a.afragA = c.d_afragA; a.hA = c.d_hAf; a.hB = c.d_hBf;
   const long long n0 = (long long)rs.D * g.mA_prev - g.n_prev;
   const long long lo0 = n0 + rs.ca() - (NA - 1);
   const int par = (int)(((lo0 % 2) + 2) % 2);
@@ -343,6 +343,12 @@ int main(int argc, char **argv) {
   time_it("fused A+B+discriminator AS IN THE CHAIN (lean)", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
   time_it("lean, no global stores", bytes, [&] { launch_new<128>(c, g, d_iq, c.d_if_new, 256); });
   time_it("lean, no atan2", bytes, [&] { launch_new<64>(c, g, d_iq, c.d_if_new, 256); });
+  time_it("lean, no IF store (MPX f64 only, 8 B/sample)", bytes, [&] { launch_new<512>(c, g, d_iq, c.d_if_new, 256); });
+  time_it("lean, MPX f32 + |x|^2 f32 in one store (8 B/sample)", bytes, [&] { launch_new<512 + 2048>(c, g, d_iq, c.d_if_new, 256); });
+  c.lean = false;
+  time_it("no IF store, MPX as f32 (4 B/sample)", bytes, [&] { launch_new<512 + 1024>(c, g, d_iq, c.d_if_new, 256); });
+  c.lean = true;
+  for (int i = 0; i < 3; i++) time_it("fused A+B+discriminator AS IN THE CHAIN (lean)", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
   c.lean = false;
   time_it("fused A+B+discriminator, 256 workgroups", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
   time_it("fused A+B+discriminator, 248 workgroups", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 248); });
