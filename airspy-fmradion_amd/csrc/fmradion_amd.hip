@@ -169,7 +169,7 @@ struct fmr_chain {
   DevBuf<FusedPart> d_part_pp[kPipe];
   DevBuf<int> d_stereo_pp[kPipe];
   float2 *if_slot(int q) { return q ? d_if_pp[q].p : d_if.p; }
-  double *base_slot(int q) { return q ? d_base_pp[q].p : d_base.p; }
+  fm_mpx_t *base_slot(int q) { return reinterpret_cast<fm_mpx_t *>(q ? d_base_pp[q].p : d_base.p); }   // FM: the MPX as floats (the allocation is shared with the 48 kHz modes' double signal)
   double *raw_slot(int q) { return q ? d_raw_pp[q].p : d_raw.p; }
   FusedPart *part_slot(int q) { return q ? d_part_pp[q].p : d_fused_part.p; }
   int *stereo_slot(int q) { return q ? d_stereo_pp[q].p : d_stereo_blk.p; }
@@ -456,16 +456,20 @@ struct fmr_chain {
     std::function<void()> fe_post{};   // pipelined chain: the front-end stage's end-of-call kernel, when it is still to be launched
     long long count_mid_call{};        // stage-A outputs of this call
     // this call's slot of the rings the stages hand each other (plain chain: the one buffer of each kind)
-    double *base = nullptr, *raw = nullptr;
+    fm_mpx_t *base = nullptr;
+    double *raw = nullptr;
+    float *nrm = nullptr;              // fused front end with the discriminator epilogue: |x|^2 of the IF samples (in the IF slot's memory) instead of the IF samples
+    long long nrm_stride{};
     FusedPart *part = nullptr;
     int *stereo_blk = nullptr;
-    void add_halo(void *buf, long long stride_e, int H, long long N) {   // history to move to the buffer heads at the end of the call
-      if (H > 0 && N > 0) ht.d[ht.n++] = HaloDesc{(unsigned long long *)buf, stride_e, H, (int)N};
+    void add_halo(void *buf, long long stride_e, int H, long long N, int words = 2) {   // history to move to the buffer heads at the end of the call (words: 32-bit words per element)
+      if (H > 0 && N > 0) ht.d[ht.n++] = HaloDesc{(unsigned *)buf, stride_e * words, H * words, (int)N * words};
     }
   };
   // what the audio tail of one call needs, by value: in the pipelined chain the tail stage is enqueued a call later
   struct TailCtx {
-    double *base = nullptr, *raw = nullptr;
+    fm_mpx_t *base = nullptr;
+    double *raw = nullptr;
     int *stereo_blk = nullptr;
     long long N_if{}, N_au{}, a_top0{}, amA_prev{}, akB_prev{}, astride{};
     int nb{}, count_am{}, de_tout{}, dc_nc{}, nch{};
@@ -1088,7 +1092,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
   auto &audio_len = k.audio_len; auto &N_in = k.N_in; auto &t_if_off = k.t_if_off;
   auto &t_if_len = k.t_if_len; auto &N_if = k.N_if; auto &use_fused = k.use_fused; auto &fused_geom = k.fused_geom;
   auto &par = k.par; auto &ifbuf = k.ifbuf; auto &ht = k.ht;
-  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
+  auto add_halo = [&](void *buf, long long stride_e, int H, long long N, int words = 2) { k.add_halo(buf, stride_e, H, N, words); };
   // ------------------------------------------------------------------ front end
   long long count_mid_call = 0;
   N_if = 0;
@@ -1288,7 +1292,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
 int fmr_chain::finish_front_end_stage(CallCtx &k) {
   if (k.count_mid_call > 0) {
     HaloTable hm{};
-    hm.d[0] = HaloDesc{(unsigned long long *)d_mid.p, H_mid + (long long)max_mid, H_mid, (int)k.count_mid_call};
+    hm.d[0] = HaloDesc{(unsigned *)d_mid.p, 2 * (H_mid + (long long)max_mid), 2 * H_mid, 2 * (int)k.count_mid_call};
     hm.n = 1;
     hipLaunchKernelGGL(k_shift_halo<256>, dim3(1, S), dim3(256), 0, stream, hm);
   }
@@ -1413,9 +1417,9 @@ int fmr_chain::run_tables(CallCtx &k) {
     CarryTable ctab{};
     const long long bstr = H_b + (long long)max_if;
     const int np = (int)ring_prev_n;
-    ctab.d[ctab.n++] = CarryDesc{(const unsigned long long *)base_slot(ring_prev), (unsigned long long *)k.base, bstr, H_b, np};
-    if (stereo) ctab.d[ctab.n++] = CarryDesc{(const unsigned long long *)raw_slot(ring_prev), (unsigned long long *)k.raw, bstr, H_b, np};
-    if (fir_enable) ctab.d[ctab.n++] = CarryDesc{(const unsigned long long *)if_slot(ring_prev), (unsigned long long *)ifbuf, H_if + (long long)max_if, H_if, np};
+    ctab.d[ctab.n++] = CarryDesc{(const unsigned *)base_slot(ring_prev), (unsigned *)k.base, bstr, H_b, np};
+    if (stereo) ctab.d[ctab.n++] = CarryDesc{(const unsigned *)raw_slot(ring_prev), (unsigned *)k.raw, 2 * bstr, 2 * H_b, 2 * np};
+    if (fir_enable) ctab.d[ctab.n++] = CarryDesc{(const unsigned *)if_slot(ring_prev), (unsigned *)ifbuf, 2 * (H_if + (long long)max_if), 2 * H_if, 2 * np};
     hipLaunchKernelGGL(k_carry_halo<256>, dim3(ctab.n, S), dim3(256), 0, side, ctab);
   }
   // the decoder waits for the tables.  In the pipelined chain the front end shares its stream and must not: the wait is
@@ -1447,6 +1451,14 @@ int fmr_chain::run_tables(CallCtx &k) {
     a.mid = d_mid.p; a.mid_stride = (long long)(H_mid + max_mid); a.H_mid = H_mid;
     a.afrag = d_afrag.p; a.n_if = (int)N_if;
     a.out = ifbuf; a.out_stride = if_stride; a.out_off = H_if;
+    k.nrm = nullptr;
+    if (k.fused_disc && !debug_taps) {
+      // nobody but the AGC's state solve reads the IF behind the discriminator epilogue: it gets |x|^2 (4 B per sample, in the
+      // IF slot's memory) and the IF samples stay on chip
+      a.out = nullptr;
+      a.nrm = reinterpret_cast<float *>(ifbuf); a.nrm_stride = 2 * if_stride; a.nrm_off = 0;
+      k.nrm = a.nrm; k.nrm_stride = a.nrm_stride;
+    }
     a.n_tiles = fused_n_tiles;
     a.tiles_per_wg = fused_tiles_per_wg;
     const int grid = fused_grid;
@@ -1608,6 +1620,8 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     // With the PLL on, the side-stream AGC starts only after the PLL's first (Jacobian) integration pass: that
     // pass runs one wave per SIMD and every co-resident AGC wave stretches it (measured 118 -> 160 us).
     agc_deferred = agc_aside && stereo;
+    const float *const nrm_in = (agc_aside && !fir_enable) ? k.nrm : nullptr;     // (non-null: the front end stored |x|^2, not the IF samples)
+    const long long nrm_in_stride = k.nrm_stride;
     enqueue_agc = [=](hipEvent_t gate) -> int {
     if (agc_aside) {
       if (gate) {
@@ -1623,13 +1637,22 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     float *const gain_out = (agc_aside && !debug_taps) ? (float *)nullptr : d_gain.p;
     timed_on(as, "if_agc", [&] {
       for (int it = 0; it < agc_iters; it++) {
-        hipLaunchKernelGGL(k_agc_shoot<C_AGC>, dim3((agc_nc + 63) / 64, S), dim3(64), 0, as, xin, x_stride, x_off,
+        if (nrm_in)
+          hipLaunchKernelGGL((k_agc_shoot<C_AGC, float>), dim3((agc_nc + 63) / 64, S), dim3(64), 0, as, nrm_in, nrm_in_stride, 0,
+                             (int)N_if, gain_out, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
+                             agc_init, agc_max, agc_rate, d_flags.p);
+        else
+        hipLaunchKernelGGL((k_agc_shoot<C_AGC, float2>), dim3((agc_nc + 63) / 64, S), dim3(64), 0, as, xin, x_stride, x_off,
                            (int)N_if, gain_out, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            agc_init, agc_max, agc_rate, d_flags.p);
         hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64 * agc_nw), 0, as, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
                            d_state.p, d_flags.p, (mode == FMR_MODE_FM || mode == FMR_MODE_NBFM) ? (gain_out ? 1 : 2) : 0);
       }
-      hipLaunchKernelGGL(k_if_agc_fallback, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,
+      if (nrm_in)
+        hipLaunchKernelGGL(k_if_agc_fallback<float>, dim3((S + 63) / 64), dim3(64), 0, as, nrm_in, nrm_in_stride, 0, (int)N_if,
+                           gain_out, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
+      else
+      hipLaunchKernelGGL(k_if_agc_fallback<float2>, dim3((S + 63) / 64), dim3(64), 0, as, xin, x_stride, x_off, (int)N_if,
                          gain_out, (long long)max_if, d_state.p, S, agc_init, agc_max, agc_rate, d_flags.p);
     });
     if (agc_aside) { HIPCHK(hipEventRecord(ev_agc, side2)); ev_agc_live = true; }
@@ -1762,7 +1785,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   auto &if_stride = k.if_stride; auto &rms_in_disc = k.rms_in_disc; auto &xin = k.xin; auto &x_stride = k.x_stride;
   auto &x_off = k.x_off; auto &disc_gain = k.disc_gain; auto &agc_on_side = k.agc_on_side;
   auto &agc_deferred = k.agc_deferred; auto &enqueue_agc = k.enqueue_agc;
-  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
+  auto add_halo = [&](void *buf, long long stride_e, int H, long long N, int words = 2) { k.add_halo(buf, stride_e, H, N, words); };
   if (any_mpf) {
     const size_t lds3 = sizeof(float2) * ((size_t)mpf_N + FMR_MPF_CH + 8) + sizeof(float) * (FMR_MPF_CH / 4 + 2) +
                         sizeof(float2) * (2 * 4 * 4 + FMR_MPF_CH);
@@ -1805,7 +1828,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   const long long de_stride = H_a + (long long)max_if;     // de-emphasised copies feeding the audio resampler
   if (!k.fused_disc && !k.fir_disc)     // (the fused front end's / the IF filter's discriminator epilogue has already written the MPX and the block statistics)
   timed("disc", [&] {
-    hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
+    hipLaunchKernelGGL((k_disc<256, fm_mpx_t>), dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, disc_gain,
                        (long long)max_if, any_mpf ? d_mpf.p : (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt,
                        disc_nf, disc_bound, d_dec.p, (long long)max_if, k.base, base_stride, H_b,
                        d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p, rms_in_disc ? d_if_rms_blk.p : (float *)nullptr);
@@ -1864,7 +1887,7 @@ int fmr_chain::run_fm(CallCtx &k) {
 
   if (!pipelined) {
     if (fir_enable) add_halo(ifbuf, if_stride, H_if, N_if);
-    add_halo(k.base, base_stride, H_b, N_if);
+    add_halo(k.base, base_stride, H_b, N_if, 1);
     if (stereo) add_halo(k.raw, base_stride, H_b, N_if);
   }       // (pipelined: the halos of the ring slots are carried over at the head of the next call, run_tables)
   if (!t.de_fused || debug_taps) {     // (the fused de-emphasis keeps the 384 kHz signal in LDS: these are taps then)
@@ -2036,12 +2059,12 @@ int fmr_chain::run_nbfm(CallCtx &k) {
   auto &nb = k.nb; auto &d_aud = k.d_aud; auto &astride = k.astride; auto &audio_len = k.audio_len;
   auto &t_au_len = k.t_au_len; auto &N_if = k.N_if; auto &ifbuf = k.ifbuf; auto &bt = k.bt;
   auto &if_stride = k.if_stride; auto &xin = k.xin; auto &x_stride = k.x_stride; auto &x_off = k.x_off;
-  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
+  auto add_halo = [&](void *buf, long long stride_e, int H, long long N, int words = 2) { k.add_halo(buf, stride_e, H, N, words); };
   // NbfmDecoder (NbfmDecode.cpp:47-96): discriminator on the AGC'd IF, statistics, 63-tap audio FIR (same
   // block-head path as the FM pilot cut: LowPassFilterFirAudio), -3 dB.  No resampling: audio block = IF block.
   const long long base_stride = H_b + (long long)max_if;
   timed("disc", [&] {
-    hipLaunchKernelGGL(k_disc<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
+    hipLaunchKernelGGL((k_disc<256, double>), dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
                        (long long)max_if, (float2 *)nullptr, (long long)max_if, d_mpf_ok.p, bt, disc_nf, disc_bound,
                        d_dec.p, (long long)max_if, d_base.p, base_stride, H_b, d_bb_mean_blk.p, d_bb_rms_blk.p,
                        d_state.p, (float *)nullptr);
@@ -2066,7 +2089,7 @@ int fmr_chain::run_am(CallCtx &k) {
   auto &nb = k.nb; auto &d_aud = k.d_aud; auto &astride = k.astride; auto &audio_len = k.audio_len;
   auto &t_au_len = k.t_au_len; auto &N_if = k.N_if; auto &ifbuf = k.ifbuf; auto &bt = k.bt;
   auto &if_stride = k.if_stride; auto &xin = k.xin; auto &x_stride = k.x_stride; auto &x_off = k.x_off;
-  auto add_halo = [&](void *buf, long long stride_e, int H, long long N) { k.add_halo(buf, stride_e, H, N); };
+  auto add_halo = [&](void *buf, long long stride_e, int H, long long N, int words = 2) { k.add_halo(buf, stride_e, H, N, words); };
   timed("am_demod", [&] {
     hipLaunchKernelGGL(k_am_demod<256>, dim3(nb, S), dim3(256), 0, stream, xin, x_stride, x_off, d_gain.p,
                        (long long)max_if, bt, (int)(mode != FMR_MODE_AM), d_dec.p, (long long)max_if, d_base.p,

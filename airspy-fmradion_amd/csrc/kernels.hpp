@@ -16,6 +16,10 @@
 #include <stdint.h>
 
 namespace fmr {
+// The MPX signal (discriminator output) in HBM for the FM decoder: the float the discriminator produces; FmDecode.cpp:143
+// widens it to double, which every consumer does when it loads it (bit-identical, half the bytes).
+typedef float fm_mpx_t;
+
 
 // ---------------------------------------------------------------------------
 // Per-stream state carried across launches ("per-stream PLL state carried
@@ -1140,11 +1144,11 @@ __global__ __launch_bounds__(256) void k_ifr_poly5h(
 // k_shift_halo : re-seat prefix halos at the end of a call.  All elements are
 // 8 bytes (float2 or double).  newhalo[i] = concat(halo,data)[i + N].
 // ---------------------------------------------------------------------------
-struct HaloDesc {
-  unsigned long long *buf;   // start of [halo | data] of stream 0
-  long long stride;          // elements between streams
+struct HaloDesc {           // (in 32-bit words: the host doubles stride, H and N for 8-byte elements)
+  unsigned *buf;             // start of [halo | data] of stream 0
+  long long stride;          // words between streams
   int H;                     // halo length
-  int N;                     // data elements appended in this call
+  int N;                     // data words appended in this call
 };
 #define FMR_MAX_HALO 12
 struct HaloTable { HaloDesc d[FMR_MAX_HALO]; int n; };
@@ -1152,11 +1156,11 @@ struct HaloTable { HaloDesc d[FMR_MAX_HALO]; int n; };
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_shift_halo(HaloTable tab) {
   const HaloDesc d = tab.d[blockIdx.x];
-  unsigned long long *b = d.buf + (long long)blockIdx.y * d.stride;
+  unsigned *b = d.buf + (long long)blockIdx.y * d.stride;
   if (d.N <= 0) return;
   for (int c = 0; c < d.H; c += BLOCK) {
     const int i = c + threadIdx.x;
-    unsigned long long v = 0;
+    unsigned v = 0;
     if (i < d.H) v = b[i + d.N];
     __syncthreads();
     if (i < d.H) b[i] = v;
@@ -1166,9 +1170,9 @@ __global__ __launch_bounds__(BLOCK) void k_shift_halo(HaloTable tab) {
 
 // Pipelined chain: the halo of a ring slot comes from the slot of the call before it -- dst[i] = concat(halo, data)_src[i + N],
 // i < H, src != dst (N = samples the previous call appended to src).
-struct CarryDesc {
-  const unsigned long long *src;
-  unsigned long long *dst;
+struct CarryDesc {          // (in 32-bit words, as HaloDesc)
+  const unsigned *src;
+  unsigned *dst;
   long long stride;
   int H, N;
 };
@@ -1176,8 +1180,8 @@ struct CarryTable { CarryDesc d[4]; int n; };
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_carry_halo(CarryTable tab) {
   const CarryDesc d = tab.d[blockIdx.x];
-  const unsigned long long *a = d.src + (long long)blockIdx.y * d.stride;
-  unsigned long long *b = d.dst + (long long)blockIdx.y * d.stride;
+  const unsigned *a = d.src + (long long)blockIdx.y * d.stride;
+  unsigned *b = d.dst + (long long)blockIdx.y * d.stride;
   for (int i = threadIdx.x; i < d.H; i += BLOCK) b[i] = a[i + d.N];
 }
 
@@ -1397,7 +1401,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     const float *__restrict__ coeff, int ntaps, int rms_after_fir,
     float2 *__restrict__ firb, long long fir_stride, float *__restrict__ if_rms_blk,
     float nf, float bound, float *__restrict__ dec, long long dec_stride,
-    double *__restrict__ base, long long base_stride, int base_off,
+    fm_mpx_t *__restrict__ base, long long base_stride, int base_off,
     float *__restrict__ bb_mean_blk /* DISC: the block's sum of d without its first sample */,
     float *__restrict__ bb_rms_blk /* DISC: the sum of d^2 likewise */, float *__restrict__ blk_ph /* [S][nb][2] */,
     int tl /* tile length: a multiple of 4, <= 4 BLOCK; the host sizes the dynamic LDS for it (short blocks -- the 48 kHz
@@ -1507,7 +1511,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             if (isnan(d)) d = 0.f;                                     // Utility.h:336-343
             const int i = i0 + t;
             dec[(long long)s * dec_stride + bt.if_off[b] + i] = d;
-            base[(long long)s * base_stride + base_off + bt.if_off[b] + i] = (double)d;
+            base[(long long)s * base_stride + base_off + bt.if_off[b] + i] = d;
             vsum += d;
             vsq += d * d;
           }
@@ -1527,7 +1531,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) v
 // the first sample of every block behind k_fm_block3<.., true>: its difference against the last phase of the block before
 // (or the carried phase, PhaseDiscriminator.cpp:33-46), the block's statistics, the phase the call leaves behind
 __global__ void k_disc_heads(BlockTab bt, const float *__restrict__ blk_ph, float bound,
-                             float *__restrict__ dec, long long dec_stride, double *__restrict__ base, long long base_stride,
+                             float *__restrict__ dec, long long dec_stride, fm_mpx_t *__restrict__ base, long long base_stride,
                              int base_off, float *__restrict__ bb_mean_blk, float *__restrict__ bb_rms_blk, StreamState *st) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
   if (b >= bt.nb) return;
@@ -1542,7 +1546,7 @@ __global__ void k_disc_heads(BlockTab bt, const float *__restrict__ blk_ph, floa
   if (d < -bound) d += 2 * bound;
   if (isnan(d)) d = 0.f;                                               // Utility.h:336-343
   dec[(long long)s * dec_stride + bt.if_off[b]] = d;
-  base[(long long)s * base_stride + base_off + bt.if_off[b]] = (double)d;
+  base[(long long)s * base_stride + base_off + bt.if_off[b]] = d;
   const long long bi = (long long)s * bt.nb + b;
   bb_mean_blk[bi] = (bb_mean_blk[bi] + d) / (float)(unsigned)n;
   bb_rms_blk[bi] = sqrtf((bb_rms_blk[bi] + d * d) / (float)(unsigned)n);
@@ -2319,13 +2323,13 @@ __device__ __forceinline__ float2 disc_src(const float2 *xs, const float *gs, co
   return make_float2(v.x * g, v.y * g);
 }
 
-template <int BLOCK>
+template <int BLOCK, class MPX /* fm_mpx_t for FM, double for NBFM (whose audio path reads it as it is) */>
 __global__ __launch_bounds__(BLOCK) void k_disc(
     const float2 *__restrict__ xin, long long x_stride, int x_off,
     const float *__restrict__ gain, long long g_stride,
     const float2 *__restrict__ mpfb, long long m_stride, const int *__restrict__ mpf_ok,
     BlockTab bt, float nf, float bound, float *__restrict__ dec, long long dec_stride,
-    double *__restrict__ base, long long base_stride, int base_off,
+    MPX *__restrict__ base, long long base_stride, int base_off,
     float *__restrict__ bb_mean_blk, float *__restrict__ bb_rms_blk, StreamState *st,
     float *__restrict__ if_rms_blk /* non-null: also the IF RMS of the block (k_fm_block's job when no IF FIR runs) */) {
   __shared__ float scratch[BLOCK / 64];
@@ -2362,7 +2366,7 @@ __global__ __launch_bounds__(BLOCK) void k_disc(
     if (d < -bound) d += 2 * bound;
     if (isnan(d)) d = 0.f;                                        // Utility.h:336-343
     dec[(long long)s * dec_stride + off + i] = d;
-    base[(long long)s * base_stride + base_off + off + i] = (double)d;
+    base[(long long)s * base_stride + base_off + off + i] = (MPX)d;
     vsum += d;
     vsq += d * d;
     if (i == n - 1) {
@@ -2579,7 +2583,7 @@ __device__ __forceinline__ float fast_atan2f_dev(float y, float x, const float *
 }
 
 __global__ __launch_bounds__(64) void k_pll(
-    const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt,
+    const fm_mpx_t *__restrict__ base, long long base_stride, int base_off, BlockTab bt,
     double *__restrict__ raw, long long raw_stride, int raw_off, const float *__restrict__ atan_tab,
     PllConst pc, int pilot_shift, int *__restrict__ stereo_blk, StreamState *st, int n_streams) {
   __shared__ float tab[257];
@@ -2588,7 +2592,7 @@ __global__ __launch_bounds__(64) void k_pll(
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_streams) return;
   StreamState &S = st[s];
-  const double *xin = base + (long long)s * base_stride + base_off;
+  const fm_mpx_t *xin = base + (long long)s * base_stride + base_off;
   double *out = raw + (long long)s * raw_stride + raw_off;
   double phase = S.pll_phase, freq = S.pll_freq, freq_err = S.pll_freq_err, level = S.pll_level;
   double i1 = S.bq_i_x1, i2 = S.bq_i_x2, q1 = S.bq_q_x1, q2 = S.bq_q_x2, lf1 = S.lf_x1;

@@ -47,7 +47,8 @@ struct FusedArgs {
   float2 *out; long long out_stride; int out_off;             // IF buffer ([halo | data])
   int n_tiles; int tiles_per_wg;                              // macro tiles of the call and their split over workgroups
   // discriminator epilogue (base == nullptr: IF only)
-  double *base; long long base_stride; int base_off;          // MPX as doubles ([halo | data]), FmDecode.cpp:143
+  fm_mpx_t *base; long long base_stride; int base_off;        // MPX ([halo | data]), FmDecode.cpp:143
+  float *nrm; long long nrm_stride; int nrm_off;              // |x|^2 of the IF samples for the AGC's state solve (then `out` may be null: nobody reads the IF)
   float *dec; long long dec_stride;                           // float copy of the discriminator output (debug tap), may be null
   float nf, bound;                                            // PhaseDiscriminator.cpp:28-30
   StreamState *st;                                            // disc_save in, disc_save_next / disc_save_valid out
@@ -459,9 +460,9 @@ template <int MT0, int ABL = 0>
 __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const float2 *stage, int kb, int tile_g, int &blk,
                                                 FusedBlkWin &win, float prev0, float save0, float2 *os, int lane) {
   typedef float v4f __attribute__((ext_vector_type(4)));
-  typedef double v2d __attribute__((ext_vector_type(2)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
   typedef v4f __attribute__((aligned(8))) v4f_u;
-  typedef v2d __attribute__((aligned(8))) v2d_u;
+  typedef v2f __attribute__((aligned(4))) v2f_u;
   const int idx0 = 128 * MT0, k0 = kb + idx0;
   if (k0 >= a.n_if || k0 + 128 <= 0) return;
   const v4f xx = reinterpret_cast<const v4f *>(stage + idx0)[lane];
@@ -483,20 +484,20 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
   };
   const float d0 = diff(ph0, pv0), d1 = diff(ph1, pv1);
   const bool va = ka >= 0 && ka < a.n_if, vc = kc >= 0 && kc < a.n_if;
-  double *bs = a.base + (long long)s * a.base_stride + a.base_off;
+  fm_mpx_t *bs = a.base + (long long)s * a.base_stride + a.base_off;
+  float *ns = a.nrm ? a.nrm + (long long)s * a.nrm_stride + a.nrm_off : nullptr;
+  const float e0 = x0.x * x0.x + x0.y * x0.y, e1 = x1.x * x1.x + x1.y * x1.y;
   if (!((ABL & 128) && d0 != 12345.f)) {
     if (va && vc) {
-      v4f_u *po = reinterpret_cast<v4f_u *>(os + ka);
-      v2d_u *pb = reinterpret_cast<v2d_u *>(bs + ka);
-      const v2d dd = {(double)d0, (double)d1};
-      if (!(ABL & 512)) __builtin_nontemporal_store(xx, po);
-      if (ABL & 1024) { typedef float v2f_ __attribute__((ext_vector_type(2))); __builtin_nontemporal_store((v2f_){d0, d1}, reinterpret_cast<v2f_ *>(a.dec + (long long)s * a.dec_stride + ka)); }
-      else if (ABL & 2048) { __builtin_nontemporal_store((v4f){d0, d1, xx.x * xx.x + xx.y * xx.y, xx.z * xx.z + xx.w * xx.w}, po); }
-      else __builtin_nontemporal_store(dd, pb);
-      if (a.dec && !(ABL & 1024)) { float *pd = a.dec + (long long)s * a.dec_stride + ka; pd[0] = d0; pd[1] = d1; }
+      // 8 bytes per IF sample in the product configuration (MPX + |x|^2): what the stores cost is their bytes -- every one
+      // queues behind the loader's DMA (tools/bench_fused.hip: 16 B per sample 27 us of the launch, 8 B 10 us, 4 B 4 us)
+      __builtin_nontemporal_store((v2f){d0, d1}, reinterpret_cast<v2f_u *>(bs + ka));
+      if (ns) __builtin_nontemporal_store((v2f){e0, e1}, reinterpret_cast<v2f_u *>(ns + ka));
+      if (os) __builtin_nontemporal_store(xx, reinterpret_cast<v4f_u *>(os + ka));
+      if (a.dec) { float *pd = a.dec + (long long)s * a.dec_stride + ka; pd[0] = d0; pd[1] = d1; }
     } else {
-      if (va) { os[ka] = x0; bs[ka] = (double)d0; if (a.dec) a.dec[(long long)s * a.dec_stride + ka] = d0; }
-      if (vc) { os[kc] = x1; bs[kc] = (double)d1; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
+      if (va) { bs[ka] = d0; if (ns) ns[ka] = e0; if (os) os[ka] = x0; if (a.dec) a.dec[(long long)s * a.dec_stride + ka] = d0; }
+      if (vc) { bs[kc] = d1; if (ns) ns[kc] = e1; if (os) os[kc] = x1; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
     }
   }
   if (ka == a.n_if - 1) { a.st[s].disc_save_next = ph0; a.st[s].disc_save_valid = 1; }
@@ -560,7 +561,7 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
   FusedB<MT0, 1> b;
   b.load(a.afrag, lane);
   if (FUSED_B_PRIO) __builtin_amdgcn_s_setprio(FUSED_B_PRIO);
-  float2 *os = a.out + (long long)s * a.out_stride + a.out_off;
+  float2 *os = a.out ? a.out + (long long)s * a.out_stride + a.out_off : nullptr;     // (null: MPX + |x|^2 only)
   fused_barrier();
   int p = 1000 * t3, q = 0;
   int kb = a.kb_ref + 384 * i0;                      // call-relative IF index of the first staged sample

@@ -54,26 +54,29 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 // ---------------------------------------------------------------------------
 #define FMR_DE_WARMUP 768
 template <int C>
-__global__ void k_deemph_par(const double *__restrict__ in0, const double *__restrict__ in1, long long in_stride,
+__global__ void k_deemph_par(const fm_mpx_t *__restrict__ in0 /* MPX */, const double *__restrict__ in1 /* L-R */, long long in_stride,
                              int in_off, double *__restrict__ out0, double *__restrict__ out1, long long out_stride,
                              int out_off, int n, double b0, double a1, int filt0, int filt1) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y, ch = blockIdx.z;
   const int start = t * C;
   if (start >= n) return;
-  const double *x = (ch ? in1 : in0) + (long long)s * in_stride + in_off;
   double *y = (ch ? out1 : out0) + (long long)s * out_stride + out_off;
   const int end = min(start + C, n);
-  if (!(ch ? filt1 : filt0)) {
-    for (int i = start; i < end; i++) y[i] = x[i];
-    return;
-  }
-  double w = 0.0;
-  serial_prefetch<8>(x, start - FMR_DE_WARMUP, start, [&](int, double v) { w = v - a1 * w; });
-  serial_prefetch<8>(x, start, end, [&](int i, double v) {
-    w = v - a1 * w;
-    y[i] = b0 * w;      // b1 == 0
-  });
+  auto run = [&](auto *x) {
+    if (!(ch ? filt1 : filt0)) {
+      for (int i = start; i < end; i++) y[i] = (double)x[i];
+      return;
+    }
+    double w = 0.0;
+    serial_prefetch<8>(x, start - FMR_DE_WARMUP, start, [&](int, double v) { w = v - a1 * w; });
+    serial_prefetch<8>(x, start, end, [&](int i, double v) {
+      w = v - a1 * w;
+      y[i] = b0 * w;      // b1 == 0
+    });
+  };
+  if (ch) run(in1 + (long long)s * in_stride + in_off);
+  else run(in0 + (long long)s * in_stride + in_off);
 }
 
 // ---------------------------------------------------------------------------
@@ -98,7 +101,7 @@ __device__ __forceinline__ int de_idx(int j) { return j + (j >> 4); }   // one p
 // 4 accumulation chains over one shared run of NA + 3 D samples (17 LDS reads per output instead of NA).
 template <int BLOCK, int NA_T, int D_T>
 __global__ __launch_bounds__(BLOCK) void k_deemph_decim(
-    const double *__restrict__ in0, const double *__restrict__ in1, long long in_stride, int in_off, int n_if,
+    const fm_mpx_t *__restrict__ in0 /* MPX */, const double *__restrict__ in1 /* L-R */, long long in_stride, int in_off, int n_if,
     double b0, double a1, DeScan sc, int filt0, int filt1,
     const double *__restrict__ hA, int NA, int D, long long top0, int count, int tout,
     double *__restrict__ y0, double *__restrict__ y1, long long y_stride, int y_off,
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(BLOCK) void k_deemph_decim(
   const int m0 = blockIdx.x * tout;
   const int cnt = min(tout, count - m0);
   if (cnt <= 0) return;
-  const double *x = (ch ? in1 : in0) + (long long)s * in_stride + in_off;
+  const fm_mpx_t *x0 = in0 + (long long)s * in_stride + in_off;
+  const double *x1 = in1 + (long long)s * in_stride + in_off;
   double *dbg = ch ? dbg1 : dbg0;
   const long long lo = top0 + (long long)m0 * D - (NA - 1);
   long long hi = top0 + (long long)(m0 + cnt - 1) * D;
@@ -118,10 +122,12 @@ __global__ __launch_bounds__(BLOCK) void k_deemph_decim(
   const int n_t = (int)(hi - r0 + 1);                       // <= BLOCK * FMR_DE_LPL (host-checked)
   {   // all FMR_DE_LPL loads of a lane are in flight before the first LDS write (one memory latency per tile)
     double stage[FMR_DE_LPL];
+    if (ch) {      // (block-uniform; one loop per input type keeps the loads free of a branch inside the loop)
 #pragma unroll
-    for (int u = 0; u < FMR_DE_LPL; u++) {
-      const int j = tid + u * BLOCK;
-      stage[u] = (j < n_t) ? x[r0 + j] : 0.0;
+      for (int u = 0; u < FMR_DE_LPL; u++) { const int j = tid + u * BLOCK; stage[u] = (j < n_t) ? x1[r0 + j] : 0.0; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < FMR_DE_LPL; u++) { const int j = tid + u * BLOCK; stage[u] = (j < n_t) ? (double)x0[r0 + j] : 0.0; }
     }
 #pragma unroll
     for (int u = 0; u < FMR_DE_LPL; u++) de_xs[de_idx(tid + u * BLOCK)] = stage[u];
@@ -385,24 +391,29 @@ __global__ void k_dc_pass2_mux(const double *__restrict__ p0, const double *__re
 // ---------------------------------------------------------------------------
 // IF AGC by Newton multiple shooting.  nodes[c] = gain at the start of chunk c.
 // ---------------------------------------------------------------------------
-template <int C>
-__global__ void k_agc_shoot(const float2 *__restrict__ x, long long x_stride, int x_off, int n,
+// Input of the AGC recurrence: the IF samples, or -- FM without the equaliser behind the fused front end, where the gain is
+// solved for its carried state only and nobody else reads the IF -- |x|^2 as the front end's epilogue stored it (4 instead
+// of 8 bytes per IF sample through HBM, both ways).  (g x)^2 + (g y)^2 against g^2 (x^2 + y^2): a few float ulps of the
+// squared magnitude, 1e-11 of the gain's factor z -- far inside the dead zone the reference's own gain wanders in.
+__device__ __forceinline__ float agc_nrm(float2 v, float g) { const float xr = v.x * g, xi = v.y * g; return xr * xr + xi * xi; }
+__device__ __forceinline__ float agc_nrm(float e, float g) { return (g * g) * e; }
+template <int C, class XT>
+__global__ void k_agc_shoot(const XT *__restrict__ x, long long x_stride, int x_off, int n,
                             float *__restrict__ gain, long long g_stride, const float *__restrict__ nodes,
                             float *__restrict__ G, double *__restrict__ M, int nc, float initial_gain, float max_gain,
                             float rate, const IterFlags *__restrict__ fl) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   if (c >= nc || fl[s].agc_converged) return;
-  const float2 *xs = x + (long long)s * x_stride + x_off;
+  const XT *xs = x + (long long)s * x_stride + x_off;
   float *gs = gain ? gain + (long long)s * g_stride : nullptr;   // null: nobody reads the per-sample gains (FM without the
   const int i0 = c * C, i1 = min(i0 + C, n);                      // equaliser: atan2 does not see them) -- only the state carries
   float g = nodes[(long long)s * (nc + 1) + c];
   double dg = 1.0;
   const double r = (double)rate;
-  serial_prefetch<8>(xs, i0, i1, [&](int i, float2 v) {
+  serial_prefetch<8>(xs, i0, i1, [&](int i, XT v) {
     if (gs) gs[i] = g;
-    const float xr = v.x * g, xi = v.y * g;
-    const float nrm = xr * xr + xi * xi;
+    const float nrm = agc_nrm(v, g);
     const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
     const float gn = g * z;
     // d(g z)/dg = z + g dz/dg = z - 2 r nrm   (nrm ~ g^2)
@@ -541,21 +552,21 @@ __global__ void k_iter_begin(IterFlags *fl, float *__restrict__ agc_nodes, int a
 }
 
 // serial fallback wrapper: only when the iteration did not converge
-__global__ void k_if_agc_fallback(const float2 *__restrict__ x, long long x_stride, int x_off, int n,
+template <class XT>
+__global__ void k_if_agc_fallback(const XT *__restrict__ x, long long x_stride, int x_off, int n,
                                   float *__restrict__ gain, long long g_stride, StreamState *st, int n_streams,
                                   float initial_gain, float max_gain, float rate, IterFlags *fl) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_streams || fl[s].agc_converged) return;
   fl[s].agc_fallback = 1;
-  const float2 *xs = x + (long long)s * x_stride + x_off;
+  const XT *xs = x + (long long)s * x_stride + x_off;
   float *gs = gain ? gain + (long long)s * g_stride : nullptr;
   float g = st[s].agc_gain;
   const double r = (double)rate;
   for (int i = 0; i < n; i++) {
-    const float2 v = xs[i];
+    const XT v = xs[i];
     if (gs) gs[i] = g;
-    const float xr = v.x * g, xi = v.y * g;
-    const float nrm = xr * xr + xi * xi;
+    const float nrm = agc_nrm(v, g);
     const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
     g *= z;
     if (!isfinite(g)) g = initial_gain;
@@ -958,7 +969,7 @@ __device__ __forceinline__ void pll_round_check(IterFlags &F, PllSync &Y, double
 // with row-contiguous instructions (half a wave per chunk), every lane then walks its own row, the results overwrite
 // the inputs in place, and the tile leaves the same way.  No global access inside the sample loop.
 template <bool JAC, bool WOUT>
-__global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ base, long long base_stride, int base_off, ChunkTab ct,
+__global__ __launch_bounds__(64) void k_pll_shoot(const fm_mpx_t *__restrict__ base, long long base_stride, int base_off, ChunkTab ct,
                             double *__restrict__ raw, long long raw_stride, int raw_off,
                             const float *__restrict__ atan_tab, PllConst pc, int pilot_shift,
                             const double *__restrict__ nodes, double *__restrict__ G, double *__restrict__ M,
@@ -986,7 +997,7 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
   int nmax = n;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-  const double *xb = base + (long long)s * base_stride + base_off;
+  const fm_mpx_t *xb = base + (long long)s * base_stride + base_off;
   double *ob = raw + (long long)s * raw_stride + raw_off;
   double rmax = 0.0;
   PllRegs S;
@@ -1021,7 +1032,7 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const double *__restrict__ bas
       for (int u = 0; u < NLD; u++) {
         const int jj = j0 + 2 * u + half;
         const int o0 = s_off[jj], last = o0 + s_len[jj] - 1;
-        v[u] = xb[max(0, min(o0 + t0 + l5, last))];
+        v[u] = (double)xb[max(0, min(o0 + t0 + l5, last))];
       }
 #pragma unroll
       for (int u = 0; u < NLD; u++) xs[(j0 + 2 * u + half) * TP + l5] = v[u];
@@ -1656,7 +1667,7 @@ __global__ void k_pll_blocks(BlockTab bt, ChunkTab ct, const double *__restrict_
 }
 
 __global__ __launch_bounds__(64) void k_pll_finish(
-    const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt, ChunkTab ct,
+    const fm_mpx_t *__restrict__ base, long long base_stride, int base_off, BlockTab bt, ChunkTab ct,
     const float *__restrict__ atan_tab, PllConst pc, int pilot_shift, const double *__restrict__ nodes,
     const double *__restrict__ G, const int *__restrict__ ck_wraps, const unsigned long long *__restrict__ ck_mask,
     int mask_words, const int *__restrict__ blk_wraps, const double *__restrict__ blk_level,
@@ -1825,7 +1836,7 @@ __global__ __launch_bounds__(64) void k_pll_finish(
 // wraps and PPS bookkeeping are scalar branches.  Everything else is the reference's arithmetic as in pll_step<false>.
 template <bool PILOT_SHIFT>
 __global__ __launch_bounds__(64) void k_pll_fallback(
-    const double *__restrict__ base, long long base_stride, int base_off, BlockTab bt,
+    const fm_mpx_t *__restrict__ base, long long base_stride, int base_off, BlockTab bt,
     double *__restrict__ raw, long long raw_stride, int raw_off, const float *__restrict__ atan_tab,
     PllConst pc, int *__restrict__ stereo_blk, StreamState *st, int n_streams, IterFlags *fl) {
   __shared__ float tab[257];
@@ -1845,7 +1856,7 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
   long long wr = 0, ns = 0;
   double ph_start = S.pll_phase;
   bool favg_locked = (S.lock_cnt >= pc.lock_delay);
-  const double *xin = base + (long long)s * base_stride + base_off;
+  const fm_mpx_t *xin = base + (long long)s * base_stride + base_off;
   double *out = raw + (long long)s * raw_stride + raw_off;
   const double two_pi = 2.0 * 3.14159265358979323846;
   const PllRot rot = pll_rot_make(pc);
@@ -1863,7 +1874,7 @@ __global__ __launch_bounds__(64) void k_pll_fallback(
     const int pps_blk_start = n_pps;
     for (int i0 = 0; i0 < n; i0 += 64) {
       const int cnt = min(64, n - i0);
-      const double xv = (lane < cnt) ? xin[off + i0 + lane] : 0.0;
+      const double xv = (lane < cnt) ? (double)xin[off + i0 + lane] : 0.0;
       double psin, pcos;
       pll_sincos(phase, psin, pcos);           // exact at the head of every run of 64 samples
       double ov = 0.0;

@@ -31,7 +31,7 @@ struct Ctx {
   float *d_hpA, *d_afrag;
   unsigned long long *d_dbg = nullptr; uint4 *d_afragA = nullptr; float *d_hAf = nullptr, *d_hBf = nullptr;
   long long wg_key = -1;
-  double *d_base = nullptr; float *d_dec = nullptr, *d_hBlast = nullptr, *d_stats = nullptr; StreamState *d_st = nullptr; FusedPart *d_part = nullptr; int *d_tab = nullptr;
+  float *d_base = nullptr, *d_nrm = nullptr; float *d_dec = nullptr, *d_hBlast = nullptr, *d_stats = nullptr; StreamState *d_st = nullptr; FusedPart *d_part = nullptr; int *d_tab = nullptr;
   bool epi = false, lean = false; int h_off_dev400 = 0; int nb = 0; std::vector<int> h_off, h_len; int *d_wgblk = nullptr;
   int poly2_tile;
 };
@@ -66,7 +66,7 @@ static void setup(Ctx &c, size_t max_in) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 125, 210>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
   constexpr int kL = FusedShape<kFusedD, kFusedNA>::LDS_BYTES;
 #define SETATTR(P, A) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, P, A>), hipFuncAttributeMaxDynamicSharedMemorySize, kL))
-  SETATTR(0, 0); SETATTR(1, 0); SETATTR(0, 512); SETATTR(1, 512); SETATTR(0, 2560); SETATTR(1, 2560); SETATTR(0, 1536); SETATTR(1, 1536); SETATTR(0, 64); SETATTR(1, 64); SETATTR(0, 128); SETATTR(1, 128); SETATTR(0, 256); SETATTR(1, 256); SETATTR(0, 448); SETATTR(1, 448); SETATTR(0, 46); SETATTR(1, 46); SETATTR(0, 54); SETATTR(1, 54); SETATTR(0, 39); SETATTR(1, 39); SETATTR(0, 1); SETATTR(1, 1); SETATTR(0, 2); SETATTR(1, 2); SETATTR(0, 3); SETATTR(1, 3);
+  SETATTR(0, 0); SETATTR(1, 0); SETATTR(0, 64); SETATTR(1, 64); SETATTR(0, 128); SETATTR(1, 128); SETATTR(0, 256); SETATTR(1, 256); SETATTR(0, 448); SETATTR(1, 448); SETATTR(0, 46); SETATTR(1, 46); SETATTR(0, 54); SETATTR(1, 54); SETATTR(0, 39); SETATTR(1, 39); SETATTR(0, 1); SETATTR(1, 1); SETATTR(0, 2); SETATTR(1, 2); SETATTR(0, 3); SETATTR(1, 3);
   SETATTR(0, 4); SETATTR(1, 4); SETATTR(0, 7); SETATTR(1, 7); SETATTR(0, 5); SETATTR(1, 5); SETATTR(0, 6); SETATTR(1, 6);
   SETATTR(0, 14); SETATTR(1, 14); SETATTR(0, 22); SETATTR(1, 22); SETATTR(0, 32); SETATTR(1, 32); SETATTR(0, 36); SETATTR(1, 36); SETATTR(0, 38); SETATTR(1, 38); SETATTR(0, 37); SETATTR(1, 37); SETATTR(0, 35); SETATTR(1, 35);
   CK(hipMalloc(&c.d_hAf, fa.size() * 4)); CK(hipMemcpy(c.d_hAf, fa.data(), fa.size() * 4, hipMemcpyHostToDevice));
@@ -76,7 +76,7 @@ static void setup(Ctx &c, size_t max_in) {
     CK(hipMalloc(&c.d_afragA, fr.size() * 2)); CK(hipMemcpy(c.d_afragA, fr.data(), fr.size() * 2, hipMemcpyHostToDevice)); }
   CK(hipMalloc(&c.d_dbg, 32 * 8)); CK(hipMemset(c.d_dbg, 0, 32 * 8));
   CK(hipMalloc(&c.d_wgblk, 1024 * 4));
-  CK(hipMalloc(&c.d_base, c.max_if * 8)); CK(hipMalloc(&c.d_dec, c.max_if * 4)); CK(hipMalloc(&c.d_st, sizeof(StreamState)));
+  CK(hipMalloc(&c.d_base, c.max_if * 4)); CK(hipMalloc(&c.d_nrm, c.max_if * 4)); CK(hipMalloc(&c.d_dec, c.max_if * 4)); CK(hipMalloc(&c.d_st, sizeof(StreamState)));
   CK(hipMemset(c.d_st, 0, sizeof(StreamState)));
   CK(hipMalloc(&c.d_part, (c.max_if / 128 + 16) * sizeof(FusedPart))); CK(hipMalloc(&c.d_tab, 2 * 4096 * 4)); CK(hipMalloc(&c.d_stats, 3 * 4096 * 4));
   { std::vector<float> row(fb.begin() + (size_t)phi[47] * rs.TB, fb.begin() + (size_t)(phi[47] + 1) * rs.TB);
@@ -139,6 +139,7 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
   a.dbg = c.d_dbg;
   if (c.epi) {
     a.base = c.d_base; a.base_stride = (long long)c.max_if; a.base_off = 0; a.dec = c.lean ? nullptr : c.d_dec; a.dec_stride = (long long)c.max_if;
+    if (c.lean) { a.out = nullptr; a.nrm = c.d_nrm; a.nrm_stride = (long long)c.max_if; a.nrm_off = 0; }      // the product configuration: MPX + |x|^2, no IF samples
     if (c.lean && c.nb > 400) a.part_from = c.h_off_dev400;     // as in the chain: no debug copy, block sums only where k_stats reads them
     a.nf = (float)((75000.0 / 384000.0) * 2.0 * M_PI); a.bound = (float)(1.0 / ((75000.0 / 384000.0) * 2.0));
     a.st = c.d_st; a.hB_last = c.d_hBlast; a.part = c.d_part; a.if_off = c.d_tab; a.if_len = c.d_tab + 4096; a.nb = c.nb;
@@ -170,7 +171,7 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
 static void halo_updates(Ctx &c, const CallGeom &g, const float2 *d_iq) {
   hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, 1), dim3(256), 0, 0, c.d_in_halo, c.H_in, d_iq, (long long)c.max_in, g.N_in);
   HaloTable ht{};
-  ht.d[0] = HaloDesc{(unsigned long long *)c.d_mid, c.H_mid + (long long)c.max_mid, c.H_mid, g.count_mid};
+  ht.d[0] = HaloDesc{(unsigned *)c.d_mid, 2 * (c.H_mid + (long long)c.max_mid), 2 * c.H_mid, 2 * g.count_mid};
   ht.n = 1;
   hipLaunchKernelGGL(k_shift_halo<256>, dim3(1, 1), dim3(256), 0, 0, ht);
 }
@@ -289,9 +290,9 @@ int main(int argc, char **argv) {
     CK(hipDeviceSynchronize());
     CK(hipGetLastError());
     c.epi = false;
-    std::vector<float2> xif(g3.N_if); std::vector<double> bse(g3.N_if); std::vector<float> dc(g3.N_if), stats(3 * 4096);
+    std::vector<float2> xif(g3.N_if); std::vector<float> bse(g3.N_if); std::vector<float> dc(g3.N_if), stats(3 * 4096);
     CK(hipMemcpy(xif.data(), c.d_if_new + c.H_if, g3.N_if * 8, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(bse.data(), c.d_base, g3.N_if * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(bse.data(), c.d_base, g3.N_if * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(dc.data(), c.d_dec, g3.N_if * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(stats.data(), c.d_stats, stats.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(&st, c.d_st, sizeof st, hipMemcpyDeviceToHost));
@@ -343,11 +344,6 @@ int main(int argc, char **argv) {
   time_it("fused A+B+discriminator AS IN THE CHAIN (lean)", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
   time_it("lean, no global stores", bytes, [&] { launch_new<128>(c, g, d_iq, c.d_if_new, 256); });
   time_it("lean, no atan2", bytes, [&] { launch_new<64>(c, g, d_iq, c.d_if_new, 256); });
-  time_it("lean, no IF store (MPX f64 only, 8 B/sample)", bytes, [&] { launch_new<512>(c, g, d_iq, c.d_if_new, 256); });
-  time_it("lean, MPX f32 + |x|^2 f32 in one store (8 B/sample)", bytes, [&] { launch_new<512 + 2048>(c, g, d_iq, c.d_if_new, 256); });
-  c.lean = false;
-  time_it("no IF store, MPX as f32 (4 B/sample)", bytes, [&] { launch_new<512 + 1024>(c, g, d_iq, c.d_if_new, 256); });
-  c.lean = true;
   for (int i = 0; i < 3; i++) time_it("fused A+B+discriminator AS IN THE CHAIN (lean)", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
   c.lean = false;
   time_it("fused A+B+discriminator, 256 workgroups", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
