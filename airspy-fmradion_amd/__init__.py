@@ -16,6 +16,11 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "libfmradion_amd.so")
+# The same sources with -DFMR_AB_PARTNERS: the product plus the slower forms two GPU tests compare it with (the PLL's
+# seven-launch Newton round, FMR_PLL_V1) and a test hook (FMR_TEST_AGC_LATE).  Loaded only by chains that are created while
+# one of those switches is set; the product library does not carry them.
+LIB_PATH_AB = os.path.join(_DIR, "libfmradion_amd_ab.so")
+AB_SWITCHES = ("FMR_PLL_V1", "FMR_TEST_AGC_LATE")
 SRC = os.path.join(_DIR, "csrc", "fmradion_amd.hip")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -31,7 +36,7 @@ EXPORTS = [
     "fmr_get_pps_events", "fmr_get_multipath_coefficients", "fmr_debug_read", "fmr_get_kernel_times",
     "fmr_probe_read_bandwidth", "fmr_get_kernel_trace",
     "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert", "fmr_design_taps", "fmr_design_taps_class",
-    "fmr_host_alloc", "fmr_host_free",
+    "fmr_host_alloc", "fmr_host_free", "fmr_create_sized", "fmr_get_status_sized",
 ]
 
 
@@ -72,29 +77,35 @@ class PpsEvent(C.Structure):
 
 
 def build_library(force=False, verbose=False):
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP library (and its A/B partner build) in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     import glob
     deps = sorted(glob.glob(os.path.join(_DIR, "csrc", "*")))      # every header of the translation unit
     deps.append(os.path.join(os.path.dirname(_DIR), "include", "fmradion_amd.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    procs = []
+    for path, extra in ((LIB_PATH, []), (LIB_PATH_AB, ["-DFMR_AB_PARTNERS"])):
+        if not force and os.path.exists(path) and all(os.path.getmtime(path) >= os.path.getmtime(d) for d in deps):
+            continue
+        cmd = ["hipcc"] + HIPCC_FLAGS + extra + ["-o", path, SRC]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise FmrError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
-    L = C.CDLL(LIB_PATH)
+def lib(ab=False):
+    """The product library; ab=True: its A/B partner build (tests only)."""
+    if ab in _libs:
+        return _libs[ab]
+    path = LIB_PATH_AB if ab else LIB_PATH
+    if not os.path.exists(path):
+        raise FmrError(f"{path} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    L = C.CDLL(path)
     vp, u32p, fp, dp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_double)
     L.fmr_create.restype = C.c_int
     L.fmr_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
@@ -134,7 +145,7 @@ def lib():
     L.fmr_design_taps_class.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, dp, C.c_longlong, C.POINTER(C.c_longlong)]
     L.fmr_filter_table.restype = C.c_int
     L.fmr_filter_table.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int)]
-    _lib = L
+    _libs[ab] = L
     return L
 
 
@@ -196,6 +207,7 @@ class Chain:
                  fmfilter_enable=False, filter_coeff=None, stereo=True, deemphasis_us=50.0, pilot_shift=False,
                  multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0, nbfm_freq_dev=0.0, input_format=0,
                  output_rate=0.0, resampler_class=RESAMPLER_FAST, in_order=False):
+        self._L = lib(ab=any(k in os.environ for k in AB_SWITCHES))
         coeff = np.ascontiguousarray(DELAY_3TAPS if filter_coeff is None else filter_coeff, dtype=np.float32)
         self._coeff = coeff
         cfg = Config()
@@ -216,14 +228,14 @@ class Chain:
         self.input_format = int(input_format)
         self.n_streams, self.mode, self.stereo = n_streams, mode, bool(stereo) and mode == MODE_FM
         self.h = C.c_void_p()
-        rc = lib().fmr_create(C.byref(cfg), C.byref(self.h))
+        rc = self._L.fmr_create(C.byref(cfg), C.byref(self.h))
         if rc != OK:
             self.h = None
-            raise FmrError(f"fmr_create failed ({rc}): {lib().fmr_last_error().decode()}")
+            raise FmrError(f"fmr_create failed ({rc}): {self._L.fmr_last_error().decode()}")
 
     def close(self):
-        if getattr(self, "h", None) and _lib is not None:
-            _lib.fmr_destroy(self.h)
+        if getattr(self, "h", None) and getattr(self, "_L", None) is not None:
+            self._L.fmr_destroy(self.h)
         self.h = None
 
     def __del__(self):
@@ -231,11 +243,11 @@ class Chain:
 
     def _chk(self, rc):
         if rc < 0:
-            raise FmrError(f"fmradion_amd error {rc}: {lib().fmr_last_error().decode()}")
+            raise FmrError(f"fmradion_amd error {rc}: {self._L.fmr_last_error().decode()}")
         return rc
 
     def resampler_info(self):
-        return {k: lib().fmr_resampler_info(self.h, i) for i, k in enumerate(["D", "NA", "LB", "MB", "TB", "LT"])}
+        return {k: self._L.fmr_resampler_info(self.h, i) for i, k in enumerate(["D", "NA", "LB", "MB", "TB", "LT"])}
 
     # --- host-buffer API ---------------------------------------------------------
     def process(self, iq):
@@ -243,7 +255,7 @@ class Chain:
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         out = np.empty(2 * (len(iq) + 64), dtype=np.float64)
         n = C.c_size_t()
-        self._chk(lib().fmr_process(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), len(iq),
+        self._chk(self._L.fmr_process(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), len(iq),
                                     out.ctypes.data_as(C.POINTER(C.c_double)), len(out), C.byref(n)))
         return out[:n.value].copy()
 
@@ -261,7 +273,7 @@ class Chain:
         audio = np.zeros((self.n_streams, acap), dtype=np.float64)
         alen = np.zeros(len(bl), dtype=np.uint32)
         u32p = C.POINTER(C.c_uint32)
-        self._chk(lib().fmr_process_blocks(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), iq.shape[1],
+        self._chk(self._L.fmr_process_blocks(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), iq.shape[1],
                                            bl.ctypes.data_as(u32p), len(bl),
                                            audio.ctypes.data_as(C.POINTER(C.c_double)), acap,
                                            alen.ctypes.data_as(u32p)))
@@ -272,7 +284,7 @@ class Chain:
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         out = np.empty_like(iq)
         idx = C.c_uint(index)
-        self._chk(lib().fmr_fourth_convert(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), len(iq),
+        self._chk(self._L.fmr_fourth_convert(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), len(iq),
                                            out.ctypes.data_as(C.POINTER(C.c_float)), int(up), C.byref(idx)))
         return out, idx.value
 
@@ -280,7 +292,7 @@ class Chain:
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         out = np.empty(len(iq) + 64, dtype=np.complex64)
         n = C.c_size_t()
-        self._chk(lib().fmr_resample(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), len(iq),
+        self._chk(self._L.fmr_resample(self.h, iq.ctypes.data_as(C.POINTER(C.c_float)), len(iq),
                                      out.ctypes.data_as(C.POINTER(C.c_float)), len(out), C.byref(n)))
         return out[:n.value].copy()
 
@@ -289,39 +301,39 @@ class Chain:
         bl = np.ascontiguousarray(block_len, dtype=np.uint32)
         alen = np.zeros(len(bl), dtype=np.uint32)
         u32p = C.POINTER(C.c_uint32)
-        self._chk(lib().fmr_process_blocks_device(self.h, C.c_void_p(d_iq_ptr), stream_stride,
+        self._chk(self._L.fmr_process_blocks_device(self.h, C.c_void_p(d_iq_ptr), stream_stride,
                                                   bl.ctypes.data_as(u32p), len(bl), C.c_void_p(d_audio_ptr),
                                                   audio_stride, alen.ctypes.data_as(u32p), int(sync)))
         return alen
 
     def synchronize(self):
-        self._chk(lib().fmr_synchronize(self.h))
+        self._chk(self._L.fmr_synchronize(self.h))
 
     # --- getters -----------------------------------------------------------------------
     def status(self, stream=0):
         st = Status()
-        self._chk(lib().fmr_get_status(self.h, stream, C.byref(st)))
+        self._chk(self._L.fmr_get_status(self.h, stream, C.byref(st)))
         return st
 
     def pps_events(self, stream=0):
         ev = (PpsEvent * 64)()
-        n = self._chk(lib().fmr_get_pps_events(self.h, stream, ev, 64))
+        n = self._chk(self._L.fmr_get_pps_events(self.h, stream, ev, 64))
         return [(e.pps_index, e.sample_index, e.block_position, e.block) for e in ev[:min(n, 64)]]
 
     def multipath_coefficients(self, stream=0):
         buf = np.empty(2 * 1300, dtype=np.float32)
-        n = self._chk(lib().fmr_get_multipath_coefficients(self.h, stream, buf.ctypes.data_as(C.POINTER(C.c_float)), len(buf)))
+        n = self._chk(self._L.fmr_get_multipath_coefficients(self.h, stream, buf.ctypes.data_as(C.POINTER(C.c_float)), len(buf)))
         return buf[:2 * n].view(np.complex64).copy()
 
     def debug_read(self, which, stream=0, cap=1 << 24):
         dt = {0: np.complex64, 1: np.float32, 2: np.float64, 3: np.float64, 4: np.float32, 5: np.uint64}[which]
         buf = np.empty(cap, dtype=dt)
-        n = self._chk(lib().fmr_debug_read(self.h, stream, which, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+        n = self._chk(self._L.fmr_debug_read(self.h, stream, which, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
         return buf[:n].copy()
 
     def enable_kernel_timing(self, mode=1):
         """0 off, 1 every kernel of the last call, 2 the dominant kernel only (accumulated over calls)."""
-        lib().fmr_enable_kernel_timing(self.h, int(mode))
+        self._L.fmr_enable_kernel_timing(self.h, int(mode))
 
     def kernel_trace(self, cap=1 << 16):
         """After enable_kernel_timing(3): [(name, stream, start_ms, end_ms)] of every instrumented kernel since then."""
@@ -329,7 +341,7 @@ class Chain:
         st = (C.c_int * cap)()
         t0 = (C.c_float * cap)()
         t1 = (C.c_float * cap)()
-        L = lib()
+        L = self._L
         L.fmr_get_kernel_trace.restype = C.c_int
         L.fmr_get_kernel_trace.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
         n = self._chk(L.fmr_get_kernel_trace(self.h, names, st, t0, t1, cap))
@@ -338,5 +350,5 @@ class Chain:
     def kernel_times(self, cap=4096):
         names = (C.c_char_p * cap)()
         ms = (C.c_float * cap)()
-        n = self._chk(lib().fmr_get_kernel_times(self.h, names, ms, cap))
+        n = self._chk(self._L.fmr_get_kernel_times(self.h, names, ms, cap))
         return [(names[i].decode(), ms[i]) for i in range(min(n, cap))]

@@ -65,7 +65,7 @@ constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 512, K_A
 #endif
 constexpr int C_PLL_MIN = FMR_C_PLL_MIN;   // smallest PLL chunk (capacity); the actual length is c_pll
 constexpr long long kSmallCall = 8192;   // IF samples: calls up to this size enqueue fewer spare Newton rounds
-constexpr unsigned kAgcWaitTicks = 50000000u;   // 0.5 s of the 100 MHz clock: how long k_mpf3 waits for a chunk's gains (the AGC
+constexpr unsigned kAgcWaitTicks = 50000000u;   // 0.5 s of the 100 MHz clock: how long k_mpf4 waits for a chunk's gains (the AGC
                                                 // kernel beside it is three times faster than the equaliser: it never waits in practice)
 constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 4;   // PLL: 2 rounds in lock, 2 spare (an unused round is three launches that return at once: ~6 us measured)
 
@@ -97,29 +97,32 @@ struct EnvKnobs {
   int pipeline = -1;            // FMR_PIPELINE=0/1   the three stages of a call (front end | PLL | audio tail) of consecutive calls
                                 //                    beside each other (1, the default for FM chains with the resampler) or one
                                 //                    in-order chain per call (0: the form the tests compare the product with)
-  bool mpf3 = false;            // FMR_MPF3=1         equaliser: the round-3 kernel (four waves meet in every group) instead of chain + helpers
-  int c_pll = 0;                // FMR_C_PLL=<n>      PLL chunk length (32 .. 128; default: the chain's own choice)
-  bool agc_first = false;       // FMR_AGC_FIRST=1    equaliser: the AGC kernel in front of it instead of beside it (tools/mpf_rate.py times each alone)
-  bool mpf_account = false;     // FMR_MPF_ACCOUNT=1  equaliser kernel with cycle stamps at its phase boundaries (fmr_debug_read 5)
+#ifdef FMR_AB_PARTNERS
   int test_agc_late = 0;        // FMR_TEST_AGC_LATE=ms test hook (equaliser chain): the AGC kernel beside the equaliser starts this late; -1: never
-  bool r8b_f32 = false;         // FMR_R8B_F32=1      R8B class: stage B as the f32 MFMA product (k_ifr_poly5) instead of the fp16
-                                //                    three-product form (tests: the two against each other)
+#endif
   int fe_cus = 0;               // FMR_FE_CUS=n       pipelined chain: workgroups (= CUs) the persistent front-end kernel takes
                                 //                    (0: all but one per XCD)
   bool debug_taps = false;      // FMR_DEBUG_TAPS=1   keep intermediate signals readable through fmr_debug_read
   bool host_prof = false;       // FMR_HOST_PROF=1    host enqueue time per call on stderr
   bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end (tests: fused vs three-kernel property test)
+#ifdef FMR_AB_PARTNERS          // (libfmradion_amd_ab.so only: the slower forms two GPU tests compare the product with, and a test hook)
   bool pll_v1 = false;          // FMR_PLL_V1         seven launches per Newton round of the PLL instead of three: no hand-off
                                 //                    between workgroups inside a launch (tests: bit-equality stress test)
+#else
+  static constexpr bool pll_v1 = false;
+  static constexpr int test_agc_late = 0;
+#endif
   double pll_rtol = -1.0;       // FMR_PLL_RTOL       PLL acceptance threshold (< 0 = default)
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
   void load() {
-    serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS"); r8b_f32 = on("FMR_R8B_F32"); mpf_account = on("FMR_MPF_ACCOUNT"); agc_first = on("FMR_AGC_FIRST");
-    if (const char *e = getenv("FMR_C_PLL")) c_pll = atoi(e); mpf3 = on("FMR_MPF3");
+    serial = on("FMR_SERIAL"); debug_taps = on("FMR_DEBUG_TAPS");
     auto num = [](const char *n, int dflt) { const char *e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
-    pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0); test_agc_late = num("FMR_TEST_AGC_LATE", 0);
-    host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED"); pll_v1 = set("FMR_PLL_V1");
+    pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0);
+    host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED");
+#ifdef FMR_AB_PARTNERS
+    test_agc_late = num("FMR_TEST_AGC_LATE", 0); pll_v1 = set("FMR_PLL_V1");
+#endif
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
   }
 };
@@ -202,7 +205,6 @@ struct fmr_chain {
   // FM with the equaliser: the serial IF AGC runs beside the equaliser kernel, which follows its progress counter
   // (IF samples of this call whose gain is in HBM, per stream; zeroed at the head of every call)
   DevBuf<unsigned long long> d_agc_progress;
-  DevBuf<unsigned long long> d_mpf_dbg;          // FMR_MPF_ACCOUNT=1: cycle sums of k_mpf3's phases (fmr_debug_read 5)
   std::vector<unsigned> agc_timeouts_seen;      // per stream: StreamState::agc_sync_timeouts already reported
   bool agc_beside_mpf = false;
   DevBuf<int> d_bphi, d_boff;          // stage-B per-position tap phase / sample offset (k_ifr_poly2)
@@ -216,9 +218,6 @@ struct fmr_chain {
   int in_fmt = 0, in_bps = 8;          // source sample format (fmr_config.input_format) and its bytes per IQ sample
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
-  bool poly5 = false;                  // stage-B v5 (f32 MFMA, 48/125 with any TB: the R8B class); its k-steps: poly5_nks
-  int poly5_nks = 0;
-  DevBuf<float> d_afrag5;
   bool poly5h = false;                 // ... on the fp16 matrix cores, three-product split (k_ifr_poly5h): the form that runs
   int poly5h_nkb = 0;
   float poly5h_inv_scale = 1.f;
@@ -282,6 +281,7 @@ struct fmr_chain {
   std::vector<KernelTime> trace;        // mode 3
   std::vector<int> trace_stream;        //   0 decoder, 1 side, 2 side2, 3 front end, 4 tail
   hipEvent_t trace_base = nullptr;
+  static constexpr size_t kMaxTrace = 1u << 16;      // event pairs kept until fmr_get_kernel_trace fetches them (further kernels run untraced)
 
   ~fmr_chain() {
 #ifdef FMR_PLL_TRACE
@@ -292,17 +292,21 @@ struct fmr_chain {
       if (FILE *f = fopen(getenv("FMR_PLL_TRACE_OUT"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
 #endif
-    if (stream) (void)flush_tail(nullptr);
+    // a tail stage that was never enqueued (an asynchronous last call nobody synchronised) is dropped, not launched: its
+    // output mux would write into the caller's audio buffer, which the caller may have freed by now
+    tail_pending = false;
     for (hipStream_t st : {stream, side, side2, tail}) if (st) (void)hipStreamSynchronize(st);
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
+    for (auto &k : trace) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
+    if (trace_base) (void)hipEventDestroy(trace_base);
     for (auto &k : dom_times) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     d_in.release(); d_in_halo.release(); d_mid.release(); d_if.release(); d_fir.release();
-    d_mpf.release(); d_mpf_coeff.release(); d_mpf_state.release(); d_gain.release(); d_dec.release(); d_agc_progress.release(); d_mpf_dbg.release();
+    d_mpf.release(); d_mpf_coeff.release(); d_mpf_state.release(); d_gain.release(); d_dec.release(); d_agc_progress.release();
     d_hA.release(); d_hB.release(); d_coeff.release(); d_atan.release(); d_if_rms_blk.release();
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_afragA.release(); d_fused_part.release(); d_afrag.release(); d_afrag5.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_afragA.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -348,7 +352,7 @@ struct fmr_chain {
       dom_times.push_back(kt);
       return;
     }
-    if (timing == 3) {      // trace: every instrumented kernel of every call since the mode was switched on, with its stream
+    if (timing == 3 && trace.size() < kMaxTrace) {      // trace: every instrumented kernel of every call since the mode was switched on, with its stream
       if (!trace_base) { (void)hipEventCreate(&trace_base); (void)hipEventRecord(trace_base, st); }
       KernelTime kt{name, nullptr, nullptr};
       (void)hipEventCreate(&kt.a);
@@ -382,7 +386,7 @@ struct fmr_chain {
     }
     return FMR_OK;
   }
-  // Equaliser chain: k_mpf3 counts the waits for the AGC kernel it gave up (StreamState::agc_sync_timeouts).  Called by
+  // Equaliser chain: k_mpf4 counts the waits for the AGC kernel it gave up (StreamState::agc_sync_timeouts).  Called by
   // the entry points that synchronise: a new time-out is an error of that call (its audio is void).
   int check_agc_sync() {
     if (!enable_mpf || !d_agc_progress.p) return FMR_OK;
@@ -488,6 +492,7 @@ struct fmr_chain {
   void tail_channels(const TailCtx &t, hipStream_t st, int ch_base, int nch_l);
   int tail_stage(const TailCtx &t, hipStream_t ts);
   int flush_tail(hipEvent_t gate);
+  int enqueue_tail(hipEvent_t gate);
   int run_front_end(CallCtx &k);
   int finish_front_end_stage(CallCtx &k);
   int run_tables(CallCtx &k);
@@ -652,25 +657,13 @@ int fmr_chain::init(const fmr_config *c) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
         }
         if (rs.LB == 48 && rs.MB == 125 && rs.TB != 210 && (rs.TB & 1) == 0) {
-          // any other stage-B length at 48 / 125 (R8B class: TB = 3122): dense MFMA product, A fragments streamed through LDS
-          constexpr int KC = FMR_POLY5_KC;
-          const int nks = (((off[47] + rs.TB + 3) / 4 + KC - 1) / KC) * KC;
-          const size_t lds5 = sizeof(float2) * (size_t)((((int)tl + 64 + 127) / 128) * 128 + FMR_POLY5_WAVES * 8 * 48) + sizeof(float) * 2 * KC * 3 * 64;
-          if (lds5 <= 160 * 1024) {
-            std::vector<float> af((size_t)nks * 3 * 64, 0.f);
-            for (int ks = 0; ks < nks; ks++)
-              for (int mt = 0; mt < 3; mt++)
-                for (int l = 0; l < 64; l++) {
-                  const int pp = 16 * mt + (l & 15), m = 4 * ks + (l >> 4), j = m - off[pp];
-                  if (j >= 0 && j < rs.TB) af[((size_t)ks * 3 + mt) * 64 + l] = fb[(size_t)phi[pp] * rs.TB + j];
-                }
-            if ((rc = upload(d_afrag5, af.data(), af.size()))) return rc;
+          // any other stage-B length at 48 / 125 (R8B class: TB = 3122): dense product on the fp16 matrix cores, A fragments
+          // streamed through LDS (k_ifr_poly5h)
+          {
             poly2_tile = (int)tl + 64;
-            poly5 = true; poly5_nks = nks;
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly5<48, 125>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
             // the fp16 three-product form (k_ifr_poly5h): A fragments [k-block of 32 taps][row tile][h | l][lane][8], the
             // taps scaled by the power of two that puts the largest into [512, 1024)
-            if (!env.r8b_f32) {
+            {
               constexpr int KCH = FMR_POLY5H_KCH;
               const int nkb = (((off[47] + rs.TB + 31) / 32 + KCH - 1) / KCH) * KCH;
               double tmax = 0.0;
@@ -766,7 +759,6 @@ int fmr_chain::init(const fmr_config *c) {
     st.af_gain = 1.0;
   }
   if ((rc = upload(d_state, h_state.data(), h_state.size()))) return rc;
-  if (env.c_pll >= C_PLL_MIN && env.c_pll <= 128) c_pll = env.c_pll;
   max_ck = max_if / (size_t)c_pll + (size_t)max_blocks + 2;
   tab_ints = 5 * (size_t)max_blocks + 3 * max_ck + (size_t)max_blocks + 1 + kMaxFusedWg;   // tail: first block of each fused workgroup
   HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * tab_ints));
@@ -921,7 +913,6 @@ int fmr_chain::init(const fmr_config *c) {
     if ((rc = d_mpf_state.alloc((size_t)S * mpf_N))) return rc;
     if (enable_mpf && (rc = d_mpf.alloc((size_t)S * max_if))) return rc;
     if (enable_mpf && (rc = d_agc_progress.alloc((size_t)S))) return rc;
-    if (enable_mpf && env.mpf_account && (rc = d_mpf_dbg.alloc(16))) return rc;
   } else if (mode == FMR_MODE_NBFM) {
     nbfm_freq_dev = (c->nbfm_freq_dev > 0) ? c->nbfm_freq_dev : 8000.0;  // NbfmDecode.h:39 freq_dev_normal
     agc_init = 1.0f; agc_max = 100000.0f; agc_rate = 0.0001f;           // NbfmDecode.cpp:43
@@ -1070,7 +1061,7 @@ int fmr_chain::run(const float2 *d_iq, size_t stride, const uint32_t *block_len,
   k.audio_len = audio_len; k.N_in = N_in; k.slot = slot; k.h_tab = h_tab; k.d_tab_slot = d_tab_slot;
   k.t_if_off = t_if_off; k.t_if_len = t_if_len; k.t_au_off = t_au_off; k.t_au_len = t_au_len; k.t_mpf = t_mpf;
   if (int rc = run_front_end(k)) return rc;
-  if (k.done) return FMR_OK;
+  if (k.done) return flush_tail(nullptr);     // (nothing to decode: a pending tail refers to a table slot this call's successors will reuse)
   k.base = base_slot(k.par); k.raw = raw_slot(k.par); k.part = part_slot(k.par); k.stereo_blk = stereo_slot(k.par);
   hp1 = std::chrono::steady_clock::now();
   if (int rc = run_tables(k)) return rc;
@@ -1201,11 +1192,6 @@ int fmr_chain::run_front_end(CallCtx &k) {
                              fes, d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag5h.p,
                              poly5h_nkb, poly5h_inv_scale, rs.TB, kB_prev, (int)N_if, ifbuf, (long long)(H_if + max_if), H_if,
                              poly2_tile, tiles);
-        else if (poly5)
-          hipLaunchKernelGGL((k_ifr_poly5<48, 125>), dim3(std::min(tiles, n_cu), S), dim3(64 * FMR_POLY5_WAVES),
-                             sizeof(float2) * (size_t)(((poly2_tile + 127) / 128) * 128 + FMR_POLY5_WAVES * 8 * 48) + sizeof(float) * 2 * FMR_POLY5_KC * 3 * 64,
-                             fes, d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag5.p,
-                             poly5_nks, rs.TB, kB_prev, (int)N_if, ifbuf, (long long)(H_if + max_if), H_if, poly2_tile, tiles);
         else if (poly4)
           hipLaunchKernelGGL((k_ifr_poly4<48, 125, 210>), dim3(std::min(tiles, 512), S), dim3(256),
                              sizeof(float2) * (size_t)(((poly2_tile + 127) / 128) * 128 + 4 * 8 * 48), fes, d_mid.p,
@@ -1581,15 +1567,17 @@ int fmr_chain::run_if_stage(CallCtx &k) {
                        pll_tick2_per_stream);
   // With the equaliser on, the AGC'd amplitude feeds the constant-modulus error, and
   // the equaliser kernel is the serial bottleneck anyway: use the exact serial AGC.
-  if (enable_mpf && !serial_mode && mode == FMR_MODE_FM && !env.agc_first) {
-    // beside the equaliser, which consumes the gains as they are published (k_if_agc / k_mpf3, kernels.hpp)
+  if (enable_mpf && !serial_mode && mode == FMR_MODE_FM) {
+    // beside the equaliser, which consumes the gains as they are published (k_if_agc_wave / k_mpf4, kernels.hpp)
     // (the progress words count the samples of THIS call: zeroed here, in front of both kernels -- a call that failed
     // half way cannot leave a count behind that a later call would take for its own)
     HIPCHK(hipMemsetAsync(d_agc_progress.p, 0, sizeof(unsigned long long) * (size_t)S, stream));
     HIPCHK(hipEventRecord(ev_if, stream));
     HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
+#ifdef FMR_AB_PARTNERS
     if (env.test_agc_late > 0)      // test hook: the AGC kernel starts this many milliseconds late
       hipLaunchKernelGGL(k_hold_stream, dim3(1), dim3(1), 0, side2, (unsigned long long)env.test_agc_late * 100000ull);
+#endif
     timed_on(side2, "if_agc", [&] {
       if (env.test_agc_late >= 0)   // (test hook, < 0: the AGC kernel is not launched at all)
       hipLaunchKernelGGL(k_if_agc_wave, dim3(S), dim3(64), 0, side2, xin, x_stride, x_off, (int)N_if, d_gain.p,
@@ -1719,9 +1707,11 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
           if ((rc_agc = enqueue_agc(gate))) return;
           if (split_mono) mono_aside();
         }
+#ifdef FMR_AB_PARTNERS
         if (env.pll_v1)
           hipLaunchKernelGGL(k_pll_check, dim3(S), dim3(1024), 0, stream, d_flags.p, S, 1.0, d_pll_gres.p, ngrp,
                              (int)(it > 0), d_pll_wgr.p, (nck + 63) / 64, pll_rtol);
+#endif
         if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
         if (!env.pll_v1) {
           sub(ps, "pll_up", [&] {
@@ -1736,6 +1726,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
           });
           continue;
         }
+#ifdef FMR_AB_PARTNERS
         hipLaunchKernelGGL(k_pll_nodes_a, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                            nck, d_pll_PQ.p, d_flags.p);
         hipLaunchKernelGGL(k_pll_nodes_a2, dim3(ngrp2, S), dim3(64), 0, stream, d_pll_PQ.p, ngrp, d_pll_PQ2.p,
@@ -1746,6 +1737,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
                            d_pll_dstart.p, d_flags.p);
         hipLaunchKernelGGL(k_pll_nodes_c, dim3(ngrp, S), dim3(64), 0, stream, d_pll_nodes.p, d_pll_G.p, d_pll_M.p,
                            nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
+#endif
       }
       if (pilot_shift)
         hipLaunchKernelGGL(k_pll_fallback<true>, dim3(S), dim3(64), 0, ps, k.base, base_stride, H_b, bt,
@@ -1787,16 +1779,8 @@ int fmr_chain::run_fm(CallCtx &k) {
   auto &agc_deferred = k.agc_deferred; auto &enqueue_agc = k.enqueue_agc;
   auto add_halo = [&](void *buf, long long stride_e, int H, long long N, int words = 2) { k.add_halo(buf, stride_e, H, N, words); };
   if (any_mpf) {
-    const size_t lds3 = sizeof(float2) * ((size_t)mpf_N + FMR_MPF_CH + 8) + sizeof(float) * (FMR_MPF_CH / 4 + 2) +
-                        sizeof(float2) * (2 * 4 * 4 + FMR_MPF_CH);
     timed("mpf", [&] {
-      auto go = [&](auto kern, int threads, size_t bytes) {
-        hipLaunchKernelGGL(kern, dim3(S), dim3(threads), bytes, stream, xin, x_stride, x_off, d_gain.p, (long long)max_if,
-                           bt, d_mpf.p, (long long)max_if, d_mpf_coeff.p, d_mpf_state.p, mpf_N, mpf_ref,
-                           d_mpf_ok.p, d_state.p, agc_beside_mpf ? d_agc_progress.p : (const unsigned long long *)nullptr,
-                           kAgcWaitTicks, d_mpf_dbg.p);
-      };
-      // the chain-and-helpers form (k_mpf4: no barrier inside a chunk); FMR_MPF3=1 keeps the four-waves-meet-per-group form
+      // the chain-and-helpers form (k_mpf4: no barrier inside a chunk)
       constexpr int NG4 = FMR_MPF_CH / 4 + 2;
       const int tpl4 = mpf_N <= 320 ? 5 : mpf_N <= 640 ? 10 : 20;
       const size_t lds4 = sizeof(float2) * ((size_t)mpf_N + FMR_MPF_CH + 8) + sizeof(float) * NG4 + sizeof(float2) * FMR_MPF_CH +
@@ -1809,13 +1793,9 @@ int fmr_chain::run_fm(CallCtx &k) {
                            d_mpf_ok.p, d_state.p, agc_beside_mpf ? d_agc_progress.p : (const unsigned long long *)nullptr,
                            kAgcWaitTicks);
       };
-      if (env.mpf_account && mpf_N <= 64 * 5) go(k_mpf3<4, 5, true>, 256, lds3);        // cycle account (tools/mpf_account.py)
-      else if (!env.mpf3 && mpf_N <= 64 * 5) go4(k_mpf4<5>);
-      else if (!env.mpf3 && mpf_N <= 64 * 10) go4(k_mpf4<10>);
-      else if (!env.mpf3 && mpf_N <= 64 * 20) go4(k_mpf4<20>);                                     // N <= 1280
-      else if (mpf_N <= 64 * 5) go(k_mpf3<4, 5>, 256, lds3);
-      else if (mpf_N <= 64 * 10) go(k_mpf3<4, 10>, 256, lds3);
-      else if (mpf_N <= 64 * 20) go(k_mpf3<4, 20>, 256, lds3);
+      if (mpf_N <= 64 * 5) go4(k_mpf4<5>);
+      else if (mpf_N <= 64 * 10) go4(k_mpf4<10>);
+      else if (mpf_N <= 64 * 20) go4(k_mpf4<20>);                                     // N <= 1280
       else set_err("equaliser length out of range");
     });
   }
@@ -2032,6 +2012,12 @@ int fmr_chain::tail_stage(const TailCtx &t, hipStream_t ts) {
 int fmr_chain::flush_tail(hipEvent_t gate) {
   if (!tail_pending) return FMR_OK;
   tail_pending = false;
+  const int rc = enqueue_tail(gate);
+  if (rc != FMR_OK)      // the slot of the ring must still be released, or the calls that reuse it wait for a mark that never comes
+    hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, tail, &h_marks[1], tail_job.seq);
+  return rc;
+}
+int fmr_chain::enqueue_tail(hipEvent_t gate) {
   TailCtx t = tail_job;
   if (!gate && t.can_split && !t.mono_enqueued && t.ev_mpx) {
     // Drain (a synchronising call, no front end follows): the mono channel does not depend on the PLL -- it starts from the
@@ -2141,6 +2127,20 @@ extern "C" {
 
 const char *fmr_last_error(void) { return g_err.c_str(); }
 const char *fmr_version(void) { return "fmradion_amd 0.4 (gfx950)"; }
+
+int fmr_create_sized(const fmr_config *cfg, size_t cfg_size, fmr_chain **out) {
+  if (!cfg || !out) return FMR_ERR_BAD_ARG;
+  *out = nullptr;
+  if (cfg_size > sizeof(fmr_config)) {
+    set_err("fmr_create_sized: the caller's fmr_config has %zu bytes, this library's %zu: the caller is newer than the library", cfg_size, sizeof(fmr_config));
+    return FMR_ERR_BAD_ARG;
+  }
+  fmr_config full;
+  memset(&full, 0, sizeof full);               // fields the caller's header does not have: 0 = "as before"
+  memcpy(&full, cfg, cfg_size);
+  if (cfg_size >= offsetof(fmr_config, struct_size) + sizeof(unsigned)) full.struct_size = 0;     // (stated through the argument)
+  return fmr_create(&full, out);
+}
 
 int fmr_create(const fmr_config *cfg, fmr_chain **out) {
   if (!cfg || !out) return FMR_ERR_BAD_ARG;
@@ -2336,6 +2336,13 @@ static int fetch_state(fmr_chain *c) {
   return FMR_OK;
 }
 
+int fmr_get_status_sized(fmr_chain *c, int stream, void *st, size_t st_size) {
+  fmr_status full;
+  const int rc = fmr_get_status(c, stream, &full);
+  if (rc == FMR_OK && st) memcpy(st, &full, st_size < sizeof full ? st_size : sizeof full);      // never past the caller's struct
+  return st ? rc : FMR_ERR_BAD_ARG;
+}
+
 int fmr_get_status(fmr_chain *c, int stream, fmr_status *st) {
   if (!c || !st || stream < 0 || stream >= c->S) return FMR_ERR_BAD_ARG;
   const int rc = fetch_state(c);
@@ -2403,10 +2410,6 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
   case 2: src = c->d_raw_de.p ? c->d_raw_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 3: src = c->d_base_de.p ? c->d_base_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 4: src = (c->d_gain.p && c->gain_valid) ? c->d_gain.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
-  case 5:      // FMR_MPF_ACCOUNT=1: nine 64-bit counters (cycle sums of the five phases of a group, [8] = groups)
-    if (!c->d_mpf_dbg.p || cap_bytes < 9 * 8) return FMR_ERR_BAD_ARG;
-    HIPCHK(hipMemcpy(out, c->d_mpf_dbg.p, 9 * 8, hipMemcpyDeviceToHost));
-    return 9;
   default: return FMR_ERR_BAD_ARG;
   }
   if (!src) return FMR_ERR_BAD_ARG;

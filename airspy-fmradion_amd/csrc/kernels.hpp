@@ -55,7 +55,7 @@ struct StreamState {
   // MultipathFilter (MultipathFilter.cpp:59-75)
   double mpf_error;
   unsigned mpf_resets;
-  unsigned agc_sync_timeouts;    // k_mpf3 gave up waiting for the AGC kernel beside it (protocol error: reported, fmr_status)
+  unsigned agc_sync_timeouts;    // k_mpf4 gave up waiting for the AGC kernel beside it (protocol error: reported, fmr_status)
   // AmDecoder: AfSimpleAgc gain, dc block, de-emphasis
   double af_gain, am_dc_x1, am_dc_x2, am_de_x1;
   double am_de_x1_next, am_dc_x1_next, am_dc_x2_next;    // staged by the time-parallel AM tail, committed once it has converged
@@ -783,129 +783,6 @@ __global__ __launch_bounds__(256, 2) void k_ifr_poly4(
 }
 
 // ---------------------------------------------------------------------------
-// k_ifr_poly5 : the 48 / 125 polyphase stage for ANY (even) TB as a dense f32 MFMA product -- the stage B of the R8B
-// resampler class (TB = 3122: r8b::CDSPResampler24's 2 % transition band at 180 dB, sfmbase/IfResampler.cpp:25-29).
-// k_ifr_poly4 keeps the 63 A fragments of a row tile in registers; here a row tile has (41 + TB) / 4 ~ 790 of them,
-// so the A fragments stream through LDS in chunks of KC k-steps (1 KB LDS-DMA pieces, double buffered, fetched once
-// per workgroup and used by its four waves) while the tile's window of the mid signal stays in LDS:
-//   tile = 64 periods = 3072 IF samples; window = 64 x 125 + 41 + TB mid samples (89 KB at TB = 3122)
-//   wave w: column tiles w and w + 4 (8 periods x (re, im) each) x three row tiles = six accumulators, six MFMAs per
-//           k-step on one B read per column tile and one A read per row tile -- MFMA-bound by construction
-//           (FMR_POLY5_WAVES = 8, one column tile per wave and two waves per SIMD: 2.1 instead of 0.68 ms)
-// fp32 accuracy: a sum of 3122 products carried in one fp32 accumulator drifts by ~sqrt(3122) ulp; the accumulators are
-// therefore flushed into a second set every KC k-steps (64 taps), which bounds the error of each partial sum.
-// afrag layout: [k-step][row tile][lane], zero outside a row's band and in the padding up to a multiple of KC k-steps.
-// ---------------------------------------------------------------------------
-#define FMR_POLY5_KC 32
-#ifndef FMR_POLY5_WAVES
-#define FMR_POLY5_WAVES 4      // waves per workgroup: 4 = two column tiles (8 periods each) per wave, one wave per SIMD; 8 (one tile per wave, two waves per SIMD) measured 3x slower
-#endif
-template <int LB, int MB>
-__global__ __launch_bounds__(64 * FMR_POLY5_WAVES) void k_ifr_poly5(
-    const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
-    const float *__restrict__ afrag, int n_ks, int TB, long long k0, int count, float2 *__restrict__ out,
-    long long out_stride, int out_off, int tile_len, int n_tiles) {
-  static_assert(LB == 48, "three 16-row tiles");
-  constexpr int KC = FMR_POLY5_KC, MT = LB / 16, CH = KC * MT * 64;          // floats per A chunk
-  constexpr int NWV = FMR_POLY5_WAVES, NT = 64 * NWV, NH = 8 / NWV;           // column tiles (8 periods each) per wave
-  static_assert(NWV == 4 || NWV == 8, "64 periods per tile");
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  extern __shared__ __attribute__((aligned(16))) float2 lds_b5[];
-  const int x_len = ((tile_len + 127) / 128) * 128;          // the x region holds whole 1 KB wave chunks
-  float2 *stage = lds_b5 + x_len;                            // NWV waves x (8 periods x LB) float2
-  float *abuf = reinterpret_cast<float *>(stage + NWV * 8 * LB);   // [2][CH]
-  const int s = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = lane & 15, kq = lane >> 4;
-  const int W = TB >> 1;
-  const float2 *ms = mid + (long long)s * mid_stride;
-  float2 *os = out + (long long)s * out_stride + out_off;
-  float2 *mystage = stage + wave * (8 * LB);
-  const int n_chunks = n_ks / KC;
-  // A chunk c -> buffer c & 1: CH floats = CH / 256 one-KB pieces, wave w issues pieces w, w + NWV, ...
-  auto fetch_a = [&](int c) {
-    const float *src = afrag + (size_t)c * CH;
-    float *dst = abuf + (c & 1) * CH;
-    for (int p = wave; p < CH / 256; p += NWV)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 256 + lane * 4),
-                                       (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
-  };
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long long P0 = k0 / LB + (long long)tile * 64;
-    const long long a0 = P0 * MB - W + 1;
-    __syncthreads();                                          // previous tile fully consumed
-    const long long src0 = a0 - mid_abs0;
-    if (src0 >= 0 && src0 + x_len <= mid_valid) {
-      const float2 *src = ms + src0;
-      for (int c = wave; c < x_len / 128; c += NWV)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c * 128 + lane * 2),
-                                         (__attribute__((address_space(3))) void *)(lds_b5 + c * 128), 16, 0, 0);
-    } else {
-      for (int i = tid; i < x_len; i += NT) {                 // (zeros up to x_len: the padded k-steps multiply them by zero taps)
-        const long long idx = a0 + i - mid_abs0;
-        lds_b5[i] = (i < tile_len && idx >= 0 && idx < mid_valid) ? ms[idx] : make_float2(0.f, 0.f);
-      }
-    }
-    fetch_a(0);
-    const float *xf = reinterpret_cast<const float *>(lds_b5);
-    const float *xb[NH];
-#pragma unroll
-    for (int h = 0; h < NH; h++) xb[h] = xf + 2 * (((wave + NWV * h) * 8 + (n >> 1)) * MB + kq) + (n & 1);
-    v4f acc[NH][MT], tot[NH][MT];
-#pragma unroll
-    for (int h = 0; h < NH; h++)
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++) tot[h][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < n_chunks; c++) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of chunk c (and of the window) have landed
-      __syncthreads();                                        // ... and everybody's; chunk c - 1's buffer is free
-      if (c + 1 < n_chunks) fetch_a(c + 1);
-      const float *ab = abuf + (c & 1) * CH + lane;
-#pragma unroll
-      for (int h = 0; h < NH; h++)
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) acc[h][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < KC; k++) {
-        const int ks = c * KC + k;
-        float b[NH];
-#pragma unroll
-        for (int h = 0; h < NH; h++) b[h] = xb[h][8 * ks];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-          const float a = ab[(k * MT + mt) * 64];
-#pragma unroll
-          for (int h = 0; h < NH; h++) acc[h][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[h], acc[h][mt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < NH; h++)
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) tot[h][mt] += acc[h][mt];
-    }
-    // D[row = 4 kq + v][col = n] -> position p = 16 mt + 4 kq + v of period q0 + n/2, component n & 1
-#pragma unroll
-    for (int h = 0; h < NH; h++) {
-      const int q0 = (wave + NWV * h) * 8;
-      float *sf = reinterpret_cast<float *>(mystage);
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * LB + 16 * mt + 4 * kq + v) + (n & 1)] = tot[h][mt][v];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave writes and reads its own staging area
-      const long long kb = (P0 + q0) * LB - k0;               // local output index of the staged run
-#pragma unroll
-      for (int t = 0; t < (8 * LB) / 64; t++) {
-        const int idx = t * 64 + lane;
-        const long long k = kb + idx;
-        if (k >= 0 && k < count) os[k] = mystage[idx];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // k_ifr_poly5h : the same dense product on the fp16 matrix cores -- v_mfma_f32_16x16x32_f16, 16 x the f32 MFMA rate --
 // with BOTH operands split in two fp16 terms, x = h + l, and three products per tile (hh + hl + lh; ll is 2^-22 of the
 // result): 16 / 3 of the f32 rate with fp32-class accuracy.  What makes the split safe for any signal level:
@@ -1594,7 +1471,7 @@ __global__ __launch_bounds__(BLOCK) void k_finetune(float2 *__restrict__ buf, lo
 // progress != nullptr (FM with the equaliser, round 3): the equaliser kernel runs BESIDE this one on another stream and
 // consumes the gains as they appear -- every gain is stored write-through (agent scope) and, every 256 samples, the
 // count of finished samples of THIS call is published in progress[s] (zeroed at the head of the call) behind a vmcnt(0)
-// wait.  k_mpf3 polls it before it loads a chunk.  A serial recurrence of 80 ns per sample in front of a serial
+// wait.  k_mpf4 polls it before it loads a chunk.  A serial recurrence of 80 ns per sample in front of a serial
 // recurrence of 240 ns per sample was a quarter of the call (12.9 of 52 ms per 161 k IF samples).
 __global__ void k_if_agc(const float2 *__restrict__ x, long long x_stride, int x_off, int n,
                          float *__restrict__ gain, long long g_stride, StreamState *st, int n_streams,
@@ -1712,18 +1589,19 @@ __global__ __launch_bounds__(64) void k_if_agc_wave(const float2 *__restrict__ x
   if (progress && n == 0 && lane == 0) __hip_atomic_store(progress + s, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef FMR_AB_PARTNERS
 // test hook (FMR_TEST_AGC_LATE): keeps a stream busy for `ticks` of the 100 MHz clock, so that the AGC kernel behind it
 // starts late and the equaliser beside it has to wait (tests/test_gpu_configs.py)
 __global__ void k_hold_stream(unsigned long long ticks) {
   const unsigned long long t_lim = wall_clock64() + ticks;
   while (wall_clock64() < t_lim) __builtin_amdgcn_s_sleep(64);
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // K_mpf : MultipathFilter (MultipathFilter.cpp:92-197), constant-modulus NLMS.  Serial over samples (taps depend on
-// previous outputs); the update cadence restarts in every block (hazard H2).  The product form is k_mpf3 below
-// (four waves per stream); rounds 1 and 2 also carried a one-wave form with the taps in LDS (74 ms per 161 k IF samples)
-// and one with the taps in registers (65.7 ms) -- removed in round 3, the measurements are in DESIGN.md.
+// previous outputs); the update cadence restarts in every block (hazard H2).  The product form is k_mpf4 below
+// (a chain wave and three helpers); the earlier forms and their measurements are in NOTEBOOK.md.
 // ---------------------------------------------------------------------------
 #define FMR_MPF_CH 2048
 // Wave sum without the LDS crossbar: four DPP steps sum each row of 16 lanes (quad_perm xor 1, xor 2, then the
@@ -1746,19 +1624,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 
 
 
-// ---------------------------------------------------------------------------
-// K_mpf v3: FOUR waves per stream.  The recurrence is a chain of ~N_if / 4 dependent steps (dot products -> error ->
-// coefficient update), and one wave issues an instruction only every 5-8 cycles when each waits for the one before:
-// what a step costs is its instruction count on the slowest wave.  So the step is spread over 16 rows of 16 lanes:
-//   * wave w owns taps 16 w + 64 j + (lane & 15); its row r = lane >> 4 computes the dot product of output r of the
-//     group (the four outputs behind an update share their coefficients, MultipathFilter.cpp:176,186) over the wave's
-//     taps -- every coefficient is held (and updated identically) by the four rows of its wave;
-//   * a row's sum is four DPP steps on one complex value; the four waves meet through 32 floats of LDS and ONE barrier
-//     per group (double buffered);
-//   * mu = 0.1 / (|state|^2 + 1e-10) (:130) depends on the input alone: all update positions of a chunk are evaluated
-//     in parallel before the chain starts, which takes the window energy reduction and an fp64 division out of it.
-// Complex multiply-accumulates are two v_pk_fma_f32 with op_sel / neg_lo (same rounding as the four fmaf of k_mpf2).
-// ---------------------------------------------------------------------------
+// Complex multiply-accumulates are two v_pk_fma_f32 with op_sel / neg_lo (same rounding as four fmaf).
 __device__ __forceinline__ void mpf_cmac(float __attribute__((ext_vector_type(2))) &acc, float2 sv, float2 cv) {
   typedef float v2f __attribute__((ext_vector_type(2)));
   const v2f s = {sv.x, sv.y}, c = {cv.x, cv.y};
@@ -1777,224 +1643,9 @@ __device__ __forceinline__ float row_sum_dpp(float v) {        // every lane of 
   return v;
 }
 
-// DBG: cycle account of a group (tools/mpf_account.py): s_memtime stamps at the phase boundaries, each behind a wait for
-// what the phase started (so the phases do not overlap as they do in the product: the sum is an upper bound of the group),
-// sums over all groups of the call in dbg[0..7], the group count in dbg[8].
-template <int NW, int TPLR, bool DBG = false>
-__global__ __launch_bounds__(64 * NW) void k_mpf3(
-    const float2 *__restrict__ xin, long long x_stride, int x_off,
-    const float *__restrict__ gain, long long g_stride, BlockTab bt,
-    float2 *__restrict__ out, long long out_stride, float2 *__restrict__ coeff_g,
-    float2 *__restrict__ state_g, int N, int ref, int *__restrict__ mpf_ok, StreamState *st,
-    const unsigned long long *__restrict__ progress = nullptr, unsigned wait_ticks = 0u,
-    unsigned long long *__restrict__ dbg = nullptr) {
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  constexpr int NT = 64 * NW, SL = 16 * NW;      // SL: taps per slice j (one per row lane of every wave)
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tgroups = 0, tmark = 0;
-  auto stamp = [&](int slot) {
-    if (!DBG) return;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const unsigned long long now = __builtin_readcyclecounter();
-    if (slot >= 0) tacc[slot] += now - tmark;
-    tmark = now;
-  };
-  extern __shared__ float2 lds_m[];
-  float2 *xw = lds_m;                                                     // [N + CH + 8]
-  float *smu = reinterpret_cast<float *>(xw + N + FMR_MPF_CH + 8);        // [CH / 4 + 2]
-  float2 *exch = reinterpret_cast<float2 *>(smu + FMR_MPF_CH / 4 + 2);    // [2][NW][4]
-  float2 *yo = exch + 2 * NW * 4;                                         // [CH] outputs of the chunk
-  const int s = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = lane >> 4, r16 = lane & 15;
-  const float2 *xs = xin + (long long)s * x_stride + x_off;
-  const float *gs = gain + (long long)s * g_stride;
-  float2 *os = out + (long long)s * out_stride;
-  float2 *cg = coeff_g + (long long)s * N;
-  float2 *sg = state_g + (long long)s * N;
-  float2 c[TPLR];
-#pragma unroll
-  for (int j = 0; j < TPLR; j++) { const int i = SL * j + 16 * w + r16; c[j] = (i < N) ? cg[i] : make_float2(0.f, 0.f); }
-  int ic[TPLR];                 // tap index, clamped for the lanes past the last tap (their coefficient stays zero)
-  bool valid[TPLR], isref[TPLR];
-#pragma unroll
-  for (int j = 0; j < TPLR; j++) { const int i = SL * j + 16 * w + r16; valid[j] = i < N; isref[j] = i == ref; ic[j] = min(i, N - 1); }
-  double err_last = st[s].mpf_error;
-  unsigned resets = st[s].mpf_resets;
-  int buf = 0;
-  bool gave_up = false;
-  for (int b = 0; b < bt.nb; b++) {
-    const int n = bt.if_len[b];
-    int ok = 1;
-    if (n == 0 || !bt.mpf_active[b]) {
-      if (tid == 0) mpf_ok[(long long)s * bt.nb + b] = 0;
-      continue;
-    }
-    const int off = bt.if_off[b];
-    for (int i = tid; i < N; i += NT) xw[i] = sg[i];
-    __syncthreads();
-    for (int c0 = 0; c0 < n && ok; c0 += FMR_MPF_CH) {
-      const int cn = min(FMR_MPF_CH, n - c0);
-      if (progress && !gave_up) {
-        // the AGC kernel runs beside this one (k_if_agc): wait until it has published the gains of this chunk.  Bounded in
-        // TIME (wait_ticks of the 100 MHz clock): a protocol error -- the AGC kernel not resident, not launched -- must
-        // not hang the GPU.  It does not pass silently either: the stream's time-out counter goes up, the host turns it
-        // into an error at its next synchronising call (fmr_chain::check_agc_sync), and the rest of the call stops
-        // waiting (the gains it reads are then whatever the buffer holds: the audio of this call is void).
-        if (tid == 0) {
-          const unsigned long long need = (unsigned long long)(off + c0 + cn);
-          const unsigned long long t_lim = wall_clock64() + wait_ticks;
-          bool there = false;
-          for (;;) {
-            if (__hip_atomic_load(progress + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) { there = true; break; }
-            if (wall_clock64() > t_lim) break;
-            __builtin_amdgcn_s_sleep(8);
-          }
-          if (!there) { st[s].agc_sync_timeouts++; exch[0].x = 1.f; } else exch[0].x = 0.f;
-        }
-        __syncthreads();
-        gave_up = exch[0].x != 0.f;
-        __syncthreads();
-      }
-      for (int i = tid; i < cn; i += NT) {
-        const float2 v = xs[off + c0 + i];
-        const float g = progress ? __hip_atomic_load(gs + off + c0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gs[off + c0 + i];
-        xw[N + i] = make_float2(v.x * g, v.y * g);
-      }
-      if (tid < 8) xw[N + cn + tid] = make_float2(0.f, 0.f);      // slack read by the last (partial) group
-      __syncthreads();
-      // mu of every update position of the chunk: q = q0 + 4 u, window xw[q + 1 .. q + N]
-      const int q0 = (4 - (c0 & 3)) & 3;
-      const int nu = (q0 < cn) ? (cn - q0 + 3) / 4 : 0;
-      for (int u = tid; u < nu; u += NT) {
-        const float2 *wv = xw + q0 + 4 * u + 1;
-        double e = 0.0;
-        for (int i = 0; i < N; i++) { const float2 v = wv[i]; e += (double)(v.x * v.x + v.y * v.y); }
-        smu[u] = (float)(0.1 / ((double)(float)e + 1e-10));        // :130
-      }
-      __syncthreads();
-      int pushed = 0, stored = 0, q = 0;
-      // group = the outputs up to and including the next update sample (block index = 0 mod 4)
-      auto group_len = [&](int qq) { const int jg = c0 + qq; return min(((jg + 3) & ~3) - jg + 1, cn - qq); };
-      while (q < cn) {
-        const int glen = group_len(q);
-        const int qlast = q + glen - 1;
-        // state after the push of sample q+t = xw[q+t+1 .. q+t+N]; y = sum state[i]*coeff[i] (V9); this row: t = row.
-        // All LDS reads first (lanes past the last tap read a clamped address against a zero coefficient), then the
-        // multiply-accumulates on two chains: no branch and one wait inside the step.
-        stamp(-1);
-        float2 sv[TPLR], sl[TPLR];                              // sl: state values of the group's LAST output (update operand)
-#pragma unroll
-        for (int j = 0; j < TPLR; j++) { sv[j] = xw[q + 1 + row + ic[j]]; sl[j] = xw[qlast + 1 + ic[j]]; }
-        if (DBG) {
-#pragma unroll
-          for (int j = 0; j < TPLR; j++) { asm volatile("" : "+v"(sv[j].x), "+v"(sv[j].y), "+v"(sl[j].x), "+v"(sl[j].y)); }
-        }
-        stamp(0);                                               // 0: the ten LDS reads of the state window
-        v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < TPLR; j++) mpf_cmac((j & 1) ? acc1 : acc0, sv[j], c[j]);
-        const v2f acc = acc0 + acc1;
-        float ax = row_sum_dpp(acc.x), ay = row_sum_dpp(acc.y);
-        if (DBG) asm volatile("" : "+v"(ax), "+v"(ay));
-        stamp(1);                                               // 1: complex MACs + DPP row sums
-        float2 y[4];
-        if (NW == 1) {                                          // one wave: the four row sums travel through SGPRs
-#pragma unroll
-          for (int t = 0; t < 4; t++)
-            y[t] = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), 16 * t)),
-                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), 16 * t)));
-        } else {
-          if (r16 == 0) exch[(buf * NW + w) * 4 + row] = make_float2(ax, ay);
-          __syncthreads();
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            float2 p = exch[(buf * NW + 0) * 4 + t];
-#pragma unroll
-            for (int ww = 1; ww < NW; ww++) { const float2 e = exch[(buf * NW + ww) * 4 + t]; p.x += e.x; p.y += e.y; }
-            y[t] = p;
-          }
-          buf ^= 1;
-        }
-        if (DBG) { asm volatile("" : "+v"(y[0].x), "+v"(y[1].x), "+v"(y[2].x), "+v"(y[3].x)); }
-        stamp(2);                                               // 2: exchange between the waves (LDS write, barrier, reads, adds)
-        bool fin = true;
-#pragma unroll
-        for (int t = 0; t < 4; t++) fin = fin && (t >= glen || (isfinite(y[t].x) && isfinite(y[t].y)));
-        if (!fin) {                                             // :182-184: stop at the first non-finite output
-          int bad = 3;
-#pragma unroll
-          for (int t = 3; t >= 0; t--)
-            if (t < glen && (!isfinite(y[t].x) || !isfinite(y[t].y))) bad = t;
-          pushed = q + bad + 1; ok = 0; break;
-        }
-        pushed = q + glen;
-        {                                                       // outputs leave through LDS, one coalesced copy per chunk:
-          const float2 yv = tid == 0 ? y[0] : tid == 1 ? y[1] : tid == 2 ? y[2] : y[3];   // a global store per step would
-          if (tid < glen) yo[q + tid] = yv;                     // put its round trip (vmcnt) into the chain
-          stored = q + glen;
-        }
-        stamp(3);                                               // 3: finite checks + the outputs into LDS
-        if ((((c0 + qlast) & 3) == 0)) {                        // :176,186
-          const float2 yl = glen == 1 ? y[0] : glen == 2 ? y[1] : glen == 3 ? y[2] : y[3];
-          const double env = (double)(yl.x * yl.x + yl.y * yl.y);
-          const double error = 1.0 - env;
-          const float mu = smu[(qlast - q0) >> 2];
-          const float factor = (float)(error * (double)mu);         // :133
-          const float fr = factor * yl.x, fi = factor * yl.y;
-#pragma unroll
-          for (int j = 0; j < TPLR; j++) {                            // V10: a tap is only ever touched by its owners
-            float2 cv = c[j];
-            cv.x += sl[j].x * fr + sl[j].y * fi;
-            cv.y += sl[j].x * fi - sl[j].y * fr;
-            if (isref[j]) cv = make_float2(1.f, 0.f);                // :158
-            c[j] = valid[j] ? cv : c[j];
-          }
-          err_last = error;
-          if (!isfinite(error)) { ok = 0; break; }                   // :190-192
-        }
-        if (DBG) {
-#pragma unroll
-          for (int j = 0; j < TPLR; j++) asm volatile("" : "+v"(c[j].x), "+v"(c[j].y));
-        }
-        stamp(4);                                               // 4: error, factor, coefficient update
-        tgroups++;
-        q += glen;
-      }
-      // new state = last N entries pushed so far
-      __syncthreads();
-      for (int i = tid; i < stored; i += NT) os[off + c0 + i] = yo[i];
-      constexpr int TPS = (SL * TPLR + NT - 1) / NT;
-      float2 tmp[TPS];
-#pragma unroll
-      for (int j = 0; j < TPS; j++) { const int i = tid + NT * j; tmp[j] = (i < N) ? xw[pushed + i] : make_float2(0.f, 0.f); }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < TPS; j++) { const int i = tid + NT * j; if (i < N) xw[i] = tmp[j]; }
-      __syncthreads();
-    }
-    for (int i = tid; i < N; i += NT) sg[i] = xw[i];
-    if (!ok) {
-      // FmDecode.cpp:117-123: re-initialise the taps, block falls back to the AGC output
-#pragma unroll
-      for (int j = 0; j < TPLR; j++) { const int i = SL * j + 16 * w + r16; c[j] = make_float2(i == ref ? 1.f : 0.f, 0.f); }
-      resets++;
-    }
-    if (tid == 0) mpf_ok[(long long)s * bt.nb + b] = ok;
-    __syncthreads();
-  }
-  if (row == 0) {
-#pragma unroll
-    for (int j = 0; j < TPLR; j++) { const int i = SL * j + 16 * w + r16; if (i < N) cg[i] = c[j]; }
-  }
-  if (tid == 0) { st[s].mpf_error = err_last; st[s].mpf_resets = resets; }
-  if (DBG && dbg && tid == 0 && s == 0) {
-    for (int i = 0; i < 6; i++) dbg[i] += tacc[i];
-    dbg[8] += tgroups;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // K_mpf v4 (round 4): a CHAIN wave and three HELPER waves, no barrier inside a chunk.
-// The cycle account of k_mpf3 (tools/mpf_account.py: 2100 cycles per group of four samples, of which the ten LDS reads
+// The cycle account of round 3's kernel (four waves that met in every group; profiles/r04_mpf_account.txt: 2100 cycles per group of four samples, of which the ten LDS reads
 // and the complex MACs are 150; the exchange between the four waves through LDS and a barrier, the error / factor chain
 // and the coefficient update the rest) says what a group costs is not its arithmetic but that four waves meet in every
 // group -- and that a single wave issues one instruction every four to five cycles whatever its kind, so the chain's
@@ -2022,7 +1673,7 @@ __global__ __launch_bounds__(64 * NW) void k_mpf3(
 //     pointer is a FLAT instruction, 400 cycles each on LDS.
 // Summation order of a dot product: per lane two chains over its taps (j even / odd), then the wave sum; the update is
 // fused multiply-adds where the reference rounds the products first -- as far from the reference's VOLK kernels as
-// k_mpf3's order was, and within the same tolerances (hazard H7).
+// round 3's order was, and within the same tolerances (hazard H7).
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) int fmr_lds_int;
 typedef float fmr_v2f __attribute__((ext_vector_type(2)));
@@ -2131,7 +1782,7 @@ __global__ __launch_bounds__(256) void k_mpf4(
     __syncthreads();
     for (int c0 = 0; c0 < n && ok; c0 += CH) {
       const int cn = min(CH, n - c0);
-      if (progress && !gave_up) {       // (the AGC kernel beside this one: see k_mpf3)
+      if (progress && !gave_up) {       // (the AGC kernel beside this one: k_if_agc_wave)
         if (tid == 0) {
           const unsigned long long need = (unsigned long long)(off + c0 + cn);
           const unsigned long long t_lim = wall_clock64() + wait_ticks;
@@ -2434,13 +2085,6 @@ struct FusedPart {
   int blk[2];            // block of the samples before / after the cut (-1: none)
   float sum[2][3];       // sum d, sum d^2 (discriminator output), sum |x|^2 (IF) of each piece
 };
-
-// Pipelined chain with the fused front end: the discriminator's carried phase (m_save_value) belongs to the front-end
-// stage and is committed on its stream (k_stats, which does it for the in-order chain, runs a stage later).
-__global__ void k_disc_commit(StreamState *st, int n_streams) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < n_streams && st[s].disc_save_valid) { st[s].disc_save = st[s].disc_save_next; st[s].disc_save_valid = 0; }
-}
 
 // Pipelined chain, everything the front-end stage carries into its next call in ONE launch (a launch on the critical stream
 // costs a few microseconds whatever it does): blockIdx.x = 0 the input history (k_update_in_halo, cf32), 1 the stage-B

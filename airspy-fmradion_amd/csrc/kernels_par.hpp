@@ -1182,6 +1182,7 @@ __device__ __forceinline__ void pll_stage_group(const double *__restrict__ m, co
   }
 }
 
+#ifdef FMR_AB_PARTNERS      // seven launches per Newton round (round 1): the partner tests/test_gpu_pll_forms.py compares the product with
 __global__ __launch_bounds__(64) void k_pll_nodes_a(const double *__restrict__ nodes, const double *__restrict__ G,
                                                     const double *__restrict__ M, int nck,
                                                     double *__restrict__ PQ, const IterFlags *__restrict__ fl) {
@@ -1212,6 +1213,7 @@ __global__ __launch_bounds__(64) void k_pll_nodes_a(const double *__restrict__ n
   }
   if (act) PQ[(((long long)s * gridDim.x + grp) * 7 + i) * 8 + k] = val;
 }
+#endif
 
 // Phase A2: compose FMR_NODE_GRP2 consecutive level-1 group maps (already in [P|q] form)
 // into one level-2 map; same lane layout as phase A.
@@ -1230,6 +1232,7 @@ __device__ __forceinline__ void pll_stage_pq(const double *pq, int g0, int n, in
   for (int u = 0; u < NL; u++) { const int idx = lane + 64 * u; if (idx < FMR_NODE_GRP2 * 56) sp[idx] = tmp[u]; }
 }
 
+#ifdef FMR_AB_PARTNERS      // seven launches per Newton round (round 1): the partner tests/test_gpu_pll_forms.py compares the product with
 __global__ __launch_bounds__(64) void k_pll_nodes_a2(const double *__restrict__ PQ1, int ngrp1,
                                                      double *__restrict__ PQ2, const IterFlags *__restrict__ fl) {
   __shared__ double sp[FMR_NODE_GRP2 * 56];
@@ -1256,8 +1259,10 @@ __global__ __launch_bounds__(64) void k_pll_nodes_a2(const double *__restrict__ 
   }
   if (act) PQ2[(((long long)s * gridDim.x + grp) * 7 + i) * 8 + k] = val;
 }
+#endif
 
 // Phase C2: from the start delta of a level-2 group, the start deltas of its level-1 groups
+#ifdef FMR_AB_PARTNERS      // seven launches per Newton round (round 1): the partner tests/test_gpu_pll_forms.py compares the product with
 __global__ __launch_bounds__(64) void k_pll_nodes_c2(const double *__restrict__ PQ1, int ngrp1,
                                                      const double *__restrict__ dstart2, double *__restrict__ dstart1,
                                                      const IterFlags *__restrict__ fl) {
@@ -1287,10 +1292,12 @@ __global__ __launch_bounds__(64) void k_pll_nodes_c2(const double *__restrict__ 
   __syncthreads();
   for (int idx = i; idx < (g1 - g0) * 7; idx += 64) ds[(long long)g0 * 7 + idx] = sd[idx];
 }
+#endif
 
 // Phase B: delta at the start of every group (one wave per stream, lane i = component i);
 // the rows of the group maps are fetched two batches ahead of the dependent chain.
 struct PqRow { double v[8]; };
+#ifdef FMR_AB_PARTNERS      // seven launches per Newton round (round 1): the partner tests/test_gpu_pll_forms.py compares the product with
 __global__ __launch_bounds__(64) void k_pll_nodes_b(const double *__restrict__ PQ, int ngrp,
                                                     double *__restrict__ dstart, const IterFlags *__restrict__ fl) {
   const int s = blockIdx.x, i = threadIdx.x;
@@ -1332,11 +1339,13 @@ __global__ __launch_bounds__(64) void k_pll_nodes_b(const double *__restrict__ P
     run(g0 + NB, B);
   }
 }
+#endif
 
 // Phase C: propagate inside every group, update the nodes, record the scaled residual.  Jacobians, mismatches and
 // old node values of the group are staged through LDS first (as in phase A; all old values are read before any node
 // is rewritten: chunk c reads node c+1 and writes node c+1, a group only touches its own nodes); the new nodes leave
 // through LDS too, as one coalesced block.
+#ifdef FMR_AB_PARTNERS      // seven launches per Newton round (round 1): the partner tests/test_gpu_pll_forms.py compares the product with
 __global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, const double *__restrict__ G,
                                                     const double *__restrict__ M, int nck,
                                                     const double *__restrict__ dstart, IterFlags *fl,
@@ -1392,6 +1401,7 @@ __global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, 
   if (act) gr[i] = resid;
   if (i == 7) gr[7] = rmax;
 }
+#endif
 
 // Round bookkeeping, launched right after every integration pass: one 1024-thread block per stream
 // reduces (a) the per-workgroup boundary mismatches r of that pass and (b) the per-group Newton
@@ -1399,6 +1409,7 @@ __global__ __launch_bounds__(64) void k_pll_nodes_c(double *__restrict__ nodes, 
 // to rtol by itself, or if the node update that produced its start nodes was already below tol
 // (the nodes are then better than tol by the contraction factor).  Accepting here makes all node
 // kernels of this round no-ops.
+#ifdef FMR_AB_PARTNERS      // seven launches per Newton round (round 1): the partner tests/test_gpu_pll_forms.py compares the product with
 __global__ __launch_bounds__(1024) void k_pll_check(IterFlags *fl, int n_streams, double tol,
                                                     const double *__restrict__ grp_resid, int ngrp, int have_d,
                                                     const double *__restrict__ wg_r, int nwg, double rtol) {
@@ -1441,6 +1452,7 @@ __global__ __launch_bounds__(1024) void k_pll_check(IterFlags *fl, int n_streams
     }
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // The same round in three launches instead of seven (integration pass + bookkeeping, up-sweep, down-sweep).

@@ -39,7 +39,7 @@ AM_BLK, AM_FS = 2048, 384e3    # FileSource default block length (FileSource.h:3
 STAGE_KERNELS = ("ifr_fused", "ifr_decim", "ifr_poly", "fm_block", "disc")
 
 
-def synth_fm_stereo_torch(n, fs, stream_id, device, pilot=0.10):
+def synth_fm_stereo_torch(n, fs, stream_id, device, pilot=0.10, sigma=1e-3):
     """S-FMst generated on the GPU; same formula as tests/siggen.py, except that
     every tone is snapped to an integer number of cycles in the n-sample buffer, so that replaying
     the buffer step after step is one continuous stream (no pilot-phase jump at the seam)."""
@@ -60,7 +60,7 @@ def synth_fm_stereo_torch(n, fs, stream_id, device, pilot=0.10):
     del mpx, t
     g = torch.Generator(device=device)
     g.manual_seed(1 + stream_id)
-    noise = torch.randn(n, 2, dtype=torch.float32, device=device, generator=g) * 1e-3
+    noise = torch.randn(n, 2, dtype=torch.float32, device=device, generator=g) * sigma       # per component; carrier amplitude 0.3
     iq = torch.stack((0.3 * torch.cos(ph), 0.3 * torch.sin(ph)), dim=1).to(torch.float32) + noise
     return iq.contiguous()   # (n, 2) float32 == interleaved complex float
 
@@ -252,20 +252,51 @@ def self_launch(args):
         run_other_configs(n)           # each of them starts its own n ranks the same way
 
 
-def pin_rank_to_cores():
-    """One slice of the host's cores per local rank: a step is ~85 kernel launches from one host thread, and N ranks
-    enqueueing from the same few cores would contend (host_enqueue_ms_per_step is more than half of a step)."""
+def _gpu_numa_cores(local_rank):
+    """Cores of the NUMA node the rank's GPU hangs off (sysfs: the PCI device's numa_node and that node's cpulist), or None."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cores = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cores.update(range(int(a), int(b or a) + 1))
+        return sorted(cores)
+    except Exception:
+        return None
+
+
+def pin_rank_to_cores(use_gpu_topology=True):
+    """The rank's host thread on cores near its GPU: a step is ~95 kernel launches from one host thread, and N ranks enqueueing
+    from the same few cores would contend.  The cores of the GPU's NUMA node, shared evenly between the ranks whose GPUs sit on
+    the same node; an equal slice of the allowed cores when the topology cannot be read (or on CPU)."""
     lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     if lw <= 1 or not hasattr(os, "sched_setaffinity"):
-        return
+        return None
     try:
-        cores = sorted(os.sched_getaffinity(0))
-        per = len(cores) // lw
+        allowed = sorted(os.sched_getaffinity(0))
+        if use_gpu_topology:
+            near = [_gpu_numa_cores(r) for r in range(lw)]
+            if all(c for c in near):
+                mine = [c for c in near[lr] if c in allowed]
+                peers = [r for r in range(lw) if near[r] == near[lr]]          # ranks sharing this node
+                per = len(mine) // len(peers)
+                if per >= 1:
+                    i = peers.index(lr)
+                    os.sched_setaffinity(0, mine[i * per:(i + 1) * per])
+                    return "numa"
+        per = len(allowed) // lw
         if per >= 1:
-            os.sched_setaffinity(0, cores[lr * per:(lr + 1) * per])
+            os.sched_setaffinity(0, allowed[lr * per:(lr + 1) * per])
+            return "slice"
     except OSError:
         pass
+    return None
 
 
 def main():
@@ -302,6 +333,11 @@ def main():
                          "never the headline")
     ap.add_argument("--if-filter", action="store_true",
                     help="FM: the IF filter 'medium' (main.cpp -f medium) on; the fused front end then stores IF samples")
+    ap.add_argument("--sigma", type=float, default=1e-3,
+                    help="noise per I / Q component of the synthetic FM signal (carrier amplitude 0.3): 1e-3 = 46.5 dB C/N (default), "
+                         "1e-2 = 26.5 dB, 3e-2 = 17 dB -- what the PLL's Newton iteration needs on a noisier station (recurrences.pll_newton_rounds)")
+    ap.add_argument("--no-r8b-leg", action="store_true",
+                    help="default headline run only: skip the second, short region that times the reference-equivalent (R8B) resampler class")
     ap.add_argument("--all-configs", action="store_true",
                     help="after the headline line, print one line each for configs[2] (AM), configs[3] (-E 64), configs[4] "
                          "(32 streams per GPU) and the mono-station case, each with its own audio check and CPU baseline")
@@ -316,7 +352,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    pin_rank_to_cores()
+    pinned = pin_rank_to_cores(use_gpu_topology=not args.cpu_dry_run)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -329,7 +365,7 @@ def main():
     n = B * blk
 
     if args.cpu_dry_run:
-        return dry_run(args, rank, world, S, B, blk)
+        return dry_run(args, rank, world, S, B, blk, pinned)
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
@@ -339,7 +375,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     fmr = importlib.import_module("airspy-fmradion_amd")
-    synth = synth_am_torch if am else ((lambda n_, fs_, sid, d: synth_fm_stereo_torch(n_, fs_, sid, d, pilot=0.0)) if args.no_pilot else synth_fm_stereo_torch)
+    synth = synth_am_torch if am else (lambda n_, fs_, sid, d: synth_fm_stereo_torch(n_, fs_, sid, d, pilot=0.0 if args.no_pilot else 0.10, sigma=args.sigma))
     iq = torch.stack([synth(n, fs, rank * S + s, dev) for s in range(S)])  # (S, n, 2)
     max_au = int(n * (0.125 if am else 0.0048)) + 64
     audio = torch.zeros((S, (1 if am else 2) * max_au), dtype=torch.float64, device=dev)
@@ -513,6 +549,8 @@ def main():
         else:
             workload = ("configs[1]: single FM stereo stream per GPU, 10 MS/s complex-float IQ in HBM, "
                         "PilotPhaseLock on, IfResampler+FmDecoder -> f64 stereo 48 kHz")
+        if not am and args.sigma != 1e-3:
+            workload += " -- noise sigma %g per component (C/N %.1f dB)" % (args.sigma, 10 * np.log10(0.09 / (2 * args.sigma ** 2)))
         pmc_traffic = committed_pmc_traffic(dom_name, B, S, args) if not R8B else (None, None)
         mfma_roofline = None
         if R8B and stage_src.get("ifr_poly", 0) > 0:
@@ -520,13 +558,7 @@ def main():
             n_if = float(S) * n * info["LB"] / (info["MB"] * info["D"])                 # IF samples per launch
             flops = 2.0 * 2.0 * info["TB"] * n_if                                        # taps x (re, im) x multiply-add
             tf = flops / (stage_src["ifr_poly"] * 1e-3) / 1e12
-            f32_form = os.environ.get("FMR_R8B_F32", "")[:1] == "1"
-            if f32_form:
-                mfma_roofline = {"bound": "mfma", "kernel": "ifr_poly (k_ifr_poly5: stage B, %d taps per phase, f32 MFMA)" % info["TB"],
-                                 "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None,
-                                 "avg_launch_ms": round(stage_src["ifr_poly"], 5), "algorithmic_flops_per_launch": flops,
-                                 "peak_source": "MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate, 157.3 TFLOP/s"}
-            else:
+            if True:
                 # fp16 matrix cores, both operands split in two fp16 terms: THREE products (hh + hl + lh) per algorithmic one
                 mfma_roofline = {"bound": "mfma", "kernel": "ifr_poly (k_ifr_poly5h: stage B, %d taps per phase, v_mfma_f32_16x16x32_f16, "
                                                              "two-term fp16 split of both operands)" % info["TB"],
@@ -539,8 +571,8 @@ def main():
             "metric": ("IQ MS/s (AM, 384 kS/s in), whole job" if am else "IQ MS/s (FM stereo, 10 MS/s in), whole job"),
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "ranks_seen": world, "per_rank_ms_per_step": per_rank_ms,
-            "vs_baseline": None, "dtype": "f32 front end / f64 after the discriminator", "data": "synthetic",
+            "ranks_seen": world, "per_rank_ms_per_step": per_rank_ms, "host_thread_pinning": pinned,
+            "vs_baseline": None, "dtype": "f32 front end (stage A as a two-term fp16 split on the matrix cores, fp32 accumulate) / f64 after the discriminator", "data": "synthetic",
             "config": {"workload": workload,
                        "input_format": args.input_format, "streams_per_gpu": S, "blocks_per_step": B, "block_len": blk,
                        "samples_per_step_per_gpu": S * n, "per_gpu_msps": round(value / world, 3),
@@ -576,6 +608,10 @@ def main():
                             "af_tail_serial_fallback": st.af_agc_fallback},
         }
     ch.close()
+    headline = (not am and fmt == 0 and S == 1 and not R8B and not IF_FILTER and not args.multipath_stages and not args.no_pilot
+                and args.sigma == 1e-3)
+    if rank == 0 and world == 1 and headline and not args.no_r8b_leg:
+        out["r8b"] = r8b_leg(fmr, iq, audio, n, blk, B, local_rank)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -596,13 +632,74 @@ def main():
         run_other_configs(1)
 
 
+def r8b_leg(fmr, iq, audio, n, blk, B, device, steps=10, warmup=3):
+    """The same workload through the REFERENCE-EQUIVALENT resampler class (r8b::CDSPResampler24's default specification:
+    0.98 x Nyquist, stop band from Nyquist, 180 dB -- IfResampler.cpp:25-29), timed in a second, short region of the same
+    process and put into the headline line as `r8b`: the headline's FAST class is this project's own filter design, this is
+    what the reference builds.  Same input buffer, same step, audio of the first call against the r8brain-class oracle."""
+    import torch
+    global R8B
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=FS, enable_resampler=True, stereo=True, n_streams=1, max_block_len=blk, max_blocks=B,
+                   device=device, resampler_class=fmr.RESAMPLER_R8B)
+    block_len = [blk] * B
+
+    def step():
+        return ch.process_blocks_device(iq.data_ptr(), n, block_len, audio.data_ptr(), audio.shape[1], sync=False)
+
+    alen0 = step()
+    ch.synchronize()
+    nchk = min(B, 40)
+    got = audio[0, :int(alen0[:nchk].sum())].cpu().numpy().copy()
+    for _ in range(warmup):
+        step()
+    ch.synchronize()
+    ch.enable_kernel_timing(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ch.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    region = {}
+    for name, ms in ch.kernel_times():
+        region.setdefault(name, []).append(ms)
+    st = ch.status(0)
+    ravg = {k: float(np.mean(v)) for k, v in region.items()}
+    stage_ms = sum(ravg.get(k, 0.0) for k in STAGE_KERNELS)
+    info = ch.resampler_info()
+    ch.close()
+    was, R8B = R8B, True
+    try:
+        ifr, dec = _oracle_chain("fm", 0)
+    finally:
+        R8B = was
+    x = iq[0, :nchk * blk].cpu().numpy().view(np.complex64).reshape(-1)
+    ref = np.concatenate([dec.process(ifr.process(x[i:i + blk])) for i in range(0, len(x), blk)])
+    assert len(ref) == len(got), (len(ref), len(got))
+    err = float(np.sqrt(np.mean((got - ref) ** 2)))
+    assert err < 1e-5, f"R8B leg: audio RMS error {err} vs the r8brain-class oracle exceeds the north-star tolerance"
+    bytes_per_launch = 8.0 * n
+    return {"what": "the same step through the reference-equivalent resampler class (r8b::CDSPResampler24 defaults, IfResampler.cpp:25-29): "
+                    "second region of this process, %d steps after %d warm-up steps" % (steps, warmup),
+            "value": round(n * steps / dt / 1e6, 3), "unit": "MS/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "resampler": info,
+            "stage": {"ms": round(stage_ms, 5), "frac": round(bytes_per_launch / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if stage_ms > 0 else None,
+                      "kernels_ms": {k: round(ravg[k], 5) for k in STAGE_KERNELS if k in ravg}},
+            "pll_newton_rounds": st.pll_iterations, "pll_serial_fallback": st.pll_fallback,
+            "audio_check": {"audio_rms_err_vs_r8brain_class_oracle": float("%.3e" % err), "blocks_checked": nchk,
+                            "audio_samples_checked": len(ref), "tolerance": 1e-5}}
+
+
 # the other configurations of BASELINE.json (and the reference-equivalent resampler class), one line each, same run, same
 # box, never the headline
 OTHER_CONFIGS = [["--mode", "am", "--steps", "20", "--warmup", "3"],                                            # configs[2]
                  ["--multipath-stages", "64", "--blocks", "64", "--steps", "5", "--warmup", "3"],               # configs[3]
                  ["--streams", "32", "--blocks", "128", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],  # configs[4] shard
                  ["--resampler-class", "r8b", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],            # r8b::CDSPResampler24's filter
-                 ["--no-pilot", "--blocks", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]]        # mono station
+                 ["--no-pilot", "--blocks", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],        # mono station
+                 ["--sigma", "1e-2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],                     # 26.5 dB C/N: what the PLL's iteration needs there
+                 ["--sigma", "3e-2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]]                     # 17 dB C/N
 
 
 def run_other_configs(n_gpus):
@@ -656,7 +753,7 @@ def block_api(args, ch, iq, blk, fs, rank, world, am):
     ch.close()
 
 
-def dry_run(args, rank, world, S, B, blk):
+def dry_run(args, rank, world, S, B, blk, pinned=None):
     """Launch-contract check without a GPU (gloo): same rank/barrier/max-over-ranks/aggregate code shape as main(); the
     per-rank step is the CPU oracle on a tiny sample.  The line is marked as a dry run and is never a measurement."""
     import torch
@@ -703,7 +800,7 @@ def dry_run(args, rank, world, S, B, blk):
         cpu = None if args.no_cpu_baseline else cpu_baseline("fm", 0, seconds=0.5, max_procs=2)
         print(json.dumps({"metric": "IQ MS/s (FM stereo, 10 MS/s in), whole job", "value": round(total / dt / 1e6, 3), "unit": "MS/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-                          "ranks_seen": world, "per_rank_ms_per_step": per_rank_ms,
+                          "ranks_seen": world, "per_rank_ms_per_step": per_rank_ms, "host_thread_pinning": pinned,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "cpu oracle", "data": "DRY RUN (CPU oracle, gloo) -- not a measurement",
                           "config": {"workload": "dry run of the launch contract", "streams_per_gpu": S, "blocks_per_step": nb,
                                      "samples_per_step_per_gpu": S * nb * blk},

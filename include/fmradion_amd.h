@@ -142,6 +142,11 @@ typedef struct {
 typedef struct fmr_chain fmr_chain;
 
 int fmr_create(const fmr_config *cfg, fmr_chain **out);
+/* The same for a caller that may have been built against an OLDER header: cfg_size = sizeof(fmr_config) as the caller
+ * knows it.  The library reads exactly that many bytes (fields the caller does not have mean "as before") and refuses a
+ * size larger than its own.  fmr_create itself can only check the struct_size FIELD, which an older, shorter struct does
+ * not contain. */
+int fmr_create_sized(const fmr_config *cfg, size_t cfg_size, fmr_chain **out);
 void fmr_destroy(fmr_chain *c);
 const char *fmr_last_error(void);
 const char *fmr_version(void);
@@ -189,8 +194,16 @@ int fmr_process_blocks(fmr_chain *c, const float *iq, size_t stream_stride,
                        const uint32_t *block_len, int n_blocks, double *audio,
                        size_t audio_stride, uint32_t *audio_len);
 
-/* --- same with device-resident buffers (HBM in, HBM out); asynchronous on the
- * chain's HIP stream unless sync != 0. */
+/* --- same with device-resident buffers (HBM in, HBM out).
+ * sync != 0: returns with the audio of this call in d_audio.
+ * sync == 0: returns as soon as the call is enqueued.  THE AUDIO OF AN ASYNCHRONOUS CALL IS COMPLETE ONLY AFTER
+ * fmr_synchronize() (or a later call with sync != 0, or any getter: they synchronise).  In the pipelined chain (FM with
+ * the resampler, fmr_config.in_order == 0) the audio tail of call N is enqueued together with call N + 1 -- or by
+ * fmr_synchronize() -- on a stream of the chain's own: waiting on the device or on a stream of yours
+ * (hipDeviceSynchronize, a HIP event, torch.cuda.synchronize) does NOT make the last call's audio complete, because its
+ * tail may not have been launched yet.  d_iq, d_audio and audio_len must stay valid until that synchronisation; a chain
+ * destroyed before it drops the pending tail (nothing is written into d_audio after fmr_destroy returns).
+ * Set fmr_config.in_order = 1 for a chain whose every call is complete on the chain's stream order. */
 int fmr_process_blocks_device(fmr_chain *c, const float *d_iq,
                               size_t stream_stride, const uint32_t *block_len,
                               int n_blocks, double *d_audio, size_t audio_stride,
@@ -208,6 +221,9 @@ int fmr_resample(fmr_chain *c, const float *iq, size_t n, float *out_iq,
 int fmr_fourth_convert(fmr_chain *c, const float *iq, size_t n, float *out_iq, int up, unsigned *index);
 
 int fmr_get_status(fmr_chain *c, int stream, fmr_status *st);
+/* ... for a caller built against an older header: st_size = sizeof(fmr_status) as the caller knows it; the library never
+ * writes past it (fmr_status grows at its end). */
+int fmr_get_status_sized(fmr_chain *c, int stream, void *st, size_t st_size);
 /* PPS events of the most recent call (FmDecode.h:92); returns the count. */
 int fmr_get_pps_events(fmr_chain *c, int stream, fmr_pps_event *ev, int cap);
 /* get_multipath_coefficients (FmDecode.h:103): interleaved re,im; returns order */

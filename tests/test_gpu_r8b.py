@@ -141,23 +141,19 @@ def test_fast_class_product_against_the_r8brain_class_oracle(pilotcut):
     ch.close()
 
 
-def test_r8b_fp16_stage_b_against_the_f32_form(monkeypatch):
+def test_r8b_fp16_stage_b_strong_and_weak_signal():
     """Stage B of the R8B class runs on the fp16 matrix cores with both operands split in two fp16 terms (three products,
-    k_ifr_poly5h); FMR_R8B_F32=1 keeps the f32 MFMA product (k_ifr_poly5).  The two against each other and against the
-    oracle, on a strong and on a weak signal (the split is scaled per tile: the error must not depend on the level)."""
+    k_ifr_poly5h).  Against the oracle on a strong and on a weak signal: the split is scaled per tile, the error must not
+    depend on the level.  (Round 4 also compared it with an f32 MFMA form of the same kernel, 1e-6 apart; that partner is
+    gone from the library.)"""
     fs, blk, nblk = 10e6, 65536, 8
     for amp in (1.0, 1.0e-3):
         x = (siggen.fm_stereo_iq(nblk * blk, fs) * amp).astype(np.complex64)
-        got = {}
-        for f32 in ("0", "1"):
-            monkeypatch.setenv("FMR_R8B_F32", f32)
-            ch = fmr.Chain(mode=fmr.MODE_NONE, input_rate=fs, enable_resampler=True, max_block_len=blk,
-                           resampler_class=fmr.RESAMPLER_R8B)
-            got[f32] = np.concatenate([ch.resample(b) for b in siggen.blocks(x, blk)])
-            ch.close()
-        monkeypatch.delenv("FMR_R8B_F32")
+        ch = fmr.Chain(mode=fmr.MODE_NONE, input_rate=fs, enable_resampler=True, max_block_len=blk,
+                       resampler_class=fmr.RESAMPLER_R8B)
+        got = np.concatenate([ch.resample(b) for b in siggen.blocks(x, blk)])
+        ch.close()
         r = ora.IfResampler(fs, 384e3, 180.0, 0.98, True)
         ref = np.concatenate([r.process(b) for b in siggen.blocks(x, blk)])
-        assert len(got["0"]) == len(got["1"]) == len(ref)
-        assert rms(got["0"] - ref) / rms(ref) < 2e-6, (amp, rms(got["0"] - ref) / rms(ref))
-        assert rms(got["0"] - got["1"]) / rms(ref) < 1e-6
+        assert len(got) == len(ref)
+        assert rms(got - ref) / rms(ref) < 2e-6, (amp, rms(got - ref) / rms(ref))

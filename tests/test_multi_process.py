@@ -103,3 +103,27 @@ def test_bench_self_launch_two_ranks_gloo():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and len(out["per_rank_ms_per_step"]) == 2
     assert out["config"]["samples_per_step_per_gpu"] == 2 * 2 * 65536
     assert out["ms_per_step"] == pytest.approx(max(out["per_rank_ms_per_step"]), rel=1e-3)
+
+
+def test_bench_config5_shape_eight_ranks_gloo():
+    """BASELINE.json configs[4] as the driver will launch it on the 8-GPU node -- `bench.py --gpus 8 --streams 32`: 256
+    independent streams, 32 per rank -- through the self-launcher on CPU (gloo, --cpu-dry-run): eight ranks are started
+    and seen, every one contributes its 32 streams to the whole-job aggregate, and the ranks take disjoint slices of the
+    host's cores (the GPU path pins by NUMA node; the slices are the fallback this box can exercise)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--streams", "32",
+           "--blocks", "1", "--cpu-dry-run", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and len(out["per_rank_ms_per_step"]) == 8
+    assert out["scaling"] == "weak" and out["config"]["streams_per_gpu"] == 32
+    assert out["config"]["samples_per_step_per_gpu"] == 32 * 1 * 65536                    # 32 streams x 1 block per rank
+    assert out["value"] == pytest.approx(8 * 32 * 65536 / (out["ms_per_step"] * 1e-3) / 1e6, rel=1e-2)   # 256 streams in the aggregate
+    assert out["host_thread_pinning"] in ("slice", None)

@@ -37,7 +37,7 @@ timeout 120 tools/bench_fused.bin > gpurun_out/${tag}_fused_harness.log 2>&1
 timeout 120 python tools/step_timeline.py --show 2 --out gpurun_out/${tag}_step_timeline.txt > /dev/null 2>&1
 timeout 120 python tools/step_timeline.py --show 1 --r8b --out gpurun_out/${tag}_step_timeline_r8b.txt > /dev/null 2>&1
 timeout 120 python tools/step_timeline.py --show 1 --if-filter --out gpurun_out/${tag}_step_timeline_if_filter.txt > /dev/null 2>&1
-{ FMR_MPF_ACCOUNT=1 timeout 120 python tools/mpf_account.py; timeout 120 python tools/mpf_rate.py; FMR_AGC_FIRST=1 timeout 120 python tools/mpf_rate.py; FMR_MPF3=1 timeout 120 python tools/mpf_rate.py; } 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_mpf_account.txt
+{ timeout 120 python tools/mpf_rate.py < /dev/null; } 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_mpf_account.txt
 timeout 120 python tools/pll_mismatch.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_pll_mismatch.txt
 tail -3 gpurun_out/${tag}_pytest_gpu.log
 cat gpurun_out/${tag}_smoke.log | tail -2

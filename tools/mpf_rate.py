@@ -1,7 +1,6 @@
 """Rate of the equaliser chain alone: nanoseconds per group of four IF samples (one coefficient update,
 MultipathFilter.cpp:176,186) of k_mpf4, and per sample of the AGC kernel that feeds it, from the chain's own event pairs.
-FMR_AGC_FIRST=1 runs the AGC kernel in front of the equaliser instead of beside it (each timed alone); FMR_MPF3=1 times the
-round-3 kernel.  Usage (GPU box): python tools/mpf_rate.py"""
+Usage (GPU box): python tools/mpf_rate.py"""
 import importlib, os, sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import siggen
@@ -18,6 +17,5 @@ for i in range(128, nblk, batch):
     t = dict(ch.kernel_times())
     mpf.append(t.get("mpf", 0.0)); agc.append(t.get("if_agc", 0.0))
 n = (nblk - 128) * blk
-mode = "AGC in front" if os.environ.get("FMR_AGC_FIRST") else "AGC beside"
-kern = "k_mpf3" if os.environ.get("FMR_MPF3") else "k_mpf4"
+mode, kern = "AGC beside", "k_mpf4"
 print("%s, %s: equaliser %.0f ns per group of four samples; AGC kernel %.1f ns per sample" % (kern, mode, sum(mpf) * 1e6 / (n / 4.0), sum(agc) * 1e6 / n))
