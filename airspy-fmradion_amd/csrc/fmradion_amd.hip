@@ -229,6 +229,8 @@ struct fmr_chain {
   bool fused_disc_ok = false;          // ... and nothing sits between the resampler and the discriminator (no IF FIR, no equaliser)
   DevBuf<float> d_hB_last;             // stage-B tap row of position 47
   DevBuf<unsigned short> d_fused_afragA;   // stage-A tap fragments (fp16 high / low terms, both parities)
+  DevBuf<unsigned short> d_fused_afragB;   // stage-B tap fragments (fp16 high / low terms) and the inverse of their scale
+  float fused_hB_inv_scale = 1.f;
   DevBuf<FusedPart> d_fused_part;
   int n_cu = 256;
   DevBuf<float> d_hBp;                 // zero-padded tap rows for v3
@@ -306,7 +308,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_afragA.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -716,7 +718,10 @@ int fmr_chain::init(const fmr_config *c) {
             if ((rc = upload(d_hB_last, fb.data() + (size_t)phi[47] * rs.TB, (size_t)rs.TB))) return rc;
             { std::vector<unsigned short> fr((size_t)2 * 8 * 2 * 64 * 8);
               fused_make_afragA<kFusedD, kFusedNA>(fa.data(), fr.data());
-              if ((rc = upload(d_fused_afragA, fr.data(), fr.size()))) return rc; }
+              if ((rc = upload(d_fused_afragA, fr.data(), fr.size()))) return rc;
+              std::vector<unsigned short> frb((size_t)3 * 9 * 2 * 64 * 8);
+              fused_hB_inv_scale = fused_make_afragB(fb.data(), frb.data());
+              if ((rc = upload(d_fused_afragB, frb.data(), frb.size()))) return rc; }
             constexpr int kL = FusedShape<kFusedD, kFusedNA>::LDS_BYTES;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kL));
@@ -1435,7 +1440,7 @@ int fmr_chain::run_tables(CallCtx &k) {
     a.kb_ref = (int)(384 * T_first - fused_geom.kB_prev);
     a.count_mid = fused_geom.count_mid;
     a.mid = d_mid.p; a.mid_stride = (long long)(H_mid + max_mid); a.H_mid = H_mid;
-    a.afrag = d_afrag.p; a.n_if = (int)N_if;
+    a.afragB = reinterpret_cast<const uint4 *>(d_fused_afragB.p); a.hB_inv_scale = fused_hB_inv_scale; a.n_if = (int)N_if;
     a.out = ifbuf; a.out_stride = if_stride; a.out_off = H_if;
     k.nrm = nullptr;
     if (k.fused_disc && !debug_taps) {

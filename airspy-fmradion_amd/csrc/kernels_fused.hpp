@@ -42,7 +42,7 @@ struct FusedArgs {
   int kb_ref;                 // 384 T_first - kB_prev: call-relative IF index of the first sample of the first macro tile
   int count_mid;              // this call produces mid samples j = 0 .. count_mid-1
   float2 *mid; long long mid_stride; int H_mid;               // d_mid = [H_mid halo | data]; only the next call's halo is written
-  const float *afrag;                                         // stage-B A fragments (layout of k_ifr_poly4)
+  const uint4 *afragB; float hB_inv_scale;                     // stage-B tap fragments (fused_make_afragB) and the inverse of their scale
   int n_if;                                                   // this call produces IF samples 0 .. n_if-1
   float2 *out; long long out_stride; int out_off;             // IF buffer ([halo | data])
   int n_tiles; int tiles_per_wg;                              // macro tiles of the call and their split over workgroups
@@ -67,6 +67,13 @@ struct FusedArgs {
 // cycle counters only in the instrumented ablation builds (s_memtime costs ~100 cycles of latency per read)
 #ifndef FUSED_DMA_CAP
 #define FUSED_DMA_CAP 0      // > 0: the loader keeps at most this many DMA instructions outstanding (it then waits at s_waitcnt, not in the issue queue)
+#endif
+// The epilogue's stores are plain (write-back through L2), not non-temporal: with 8 bytes per IF sample left, letting L2 gather
+// the lines costs the input stream less than streaming them out in 512-byte pieces (tools/bench_fused.hip: 223 against 231 us).
+#ifdef FUSED_NT_STORES
+#define FUSED_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define FUSED_STORE(v, p) (*(p) = (v))
 #endif
 #ifndef FUSED_B_PRIO
 #define FUSED_B_PRIO 0       // s_setprio of the stage-B / epilogue waves
@@ -94,12 +101,15 @@ struct FusedShape {
   static_assert(PREPOS > 64 && PREPOS <= 128, "fused_fill / fused_copy_preroll handle the shared pieces in DMA instructions 0 and 1");
   static constexpr int NDMA = (NPOS + 63) / 64;
   static constexpr int NSLOT = 3, AHEAD = NSLOT - 1;   // ring slots; the loader runs AHEAD epochs in front of stage A
-  // mid ring: three macro-tile windows + mirror of the first 208 samples, as two planes (re | im) of MIDP floats -- a
-  // stage-A lane owns four consecutive outputs of one component (one 16-byte store); MIDP = 32 mod 64 puts the two
-  // components a stage-B read touches on different halves of the banks
-  static constexpr int MIDR = 3000, MIDM = 208, MIDP = 3232;
-  static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + 2 * MIDP * 4 + 384 * 8 + 64;
-  static_assert(MIDP >= MIDR + MIDM && (MIDP % 64) == 32 && (MIDR % 4) == 0 && (MIDM % 4) == 0 && (ME % 4) == 0, "mid ring");
+  // The mid signal between the stages: a ring of three macro-tile windows (3000 samples) in LDS as FOUR fp16 planes -- high
+  // and (2048 x) low term of the real and of the imaginary part, in that order -- because both stages run on the fp16 matrix
+  // cores (FusedMfmaA / FusedB16).  A stage-B column is a period of 125 mid samples; in the ring a period takes PSTR = 136
+  // positions (11 unused, zeroed once), so that every column starts on a 16-byte boundary of its plane AND the sixteen
+  // columns a quarter-wave reads at once (8 periods x 2 components, the planes 408 sixteen-byte units apart) fall on sixteen
+  // different bank quads: sample s of the ring sits at position s + 11 (s / 125).
+  static constexpr int MIDR = 3000, PSTR = 136, TILEP = 8 * PSTR, RINGP = 3 * TILEP, PLANE_BYTES = 2 * RINGP;
+  static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + 4 * PLANE_BYTES + 384 * 8 + 64;
+  static_assert((PLANE_BYTES / 16) % 16 == 8 && (RINGP % 8) == 0 && (MIDR % 4) == 0 && (ME % 4) == 0, "mid ring");
   static_assert(D == 10 && (RS % 2) == 0 && RS >= D * 496 + 256, "slot too small for the last column tile");
   static_assert((NA & 1) == 1, "type-I stage A");
   static_assert((AHEAD - 1) * NDMA <= 63, "vmcnt is a 6-bit counter");
@@ -110,6 +120,19 @@ struct FusedShape {
 // one barrier per epoch.  LDS traffic only: no wave waits here for its global stores, and the loader's DMA stays
 // in flight (a __syncthreads() would drain vmcnt)
 __device__ __forceinline__ void fused_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- the mid ring (FusedShape) --------------------------------------------------------------------------
+struct FusedRing {
+  using SH = FusedShape<kFusedD, kFusedNA>;
+  __device__ __forceinline__ static int pos_of(int s) { return s + 11 * (s / 125); }          // ring sample 0 .. 2999 -> position
+  // the value of ring sample s (any integer: wrapped) of component c as the matrix cores see it: high + low / 2048
+  __device__ __forceinline__ static float at(const unsigned char *ring, int c, int s) {
+    s %= SH::MIDR; if (s < 0) s += SH::MIDR;
+    const int p = pos_of(s);
+    const _Float16 *h = reinterpret_cast<const _Float16 *>(ring + c * SH::PLANE_BYTES), *l = reinterpret_cast<const _Float16 *>(ring + (2 + c) * SH::PLANE_BYTES);
+    return (float)h[p] + (float)l[p] * (1.0f / 2048.0f);
+  }
+};
 
 // ---- role: loader ---------------------------------------------------------------------------------------
 template <int D, int NA>
@@ -123,9 +146,11 @@ __device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, 
   const long long nb = a.nbase + (long long)D * jE;
   if (nb >= 0 && nb + SH::RS <= a.n_valid) {
     const float2 *src = xs + nb;
+    int issued = 0;
 #pragma unroll
     for (int c = 0; c < SH::NDMA; c++) {
       if (c == 0 && !whole) continue;
+      issued++;
       const int pos = 64 * c + lane;
       const int q = pos / (SH::PADP + 1), hole = (pos % (SH::PADP + 1)) == SH::PADP;
       const int piece = pos - q - hole;
@@ -134,7 +159,7 @@ __device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, 
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * piece),
                                          (__attribute__((address_space(3))) void *)(slot + 1024 * c), 16, 0, FUSED_DMA_AUX);
     }
-    return whole ? SH::NDMA : SH::NDMA - 1;
+    return issued;
   }
   // edge region (start / end of the call): guarded element loads, previous call's tail from in_halo, zeros elsewhere
   float4 *dst = reinterpret_cast<float4 *>(slot);
@@ -164,13 +189,13 @@ __device__ __forceinline__ void fused_copy_preroll(const unsigned char *cur, uns
   if (64 + lane < SH::PRE) dst[SH::pos_of_piece(64 + lane)] = src[SH::pos_of_piece(P0 + 64 + lane)];
 }
 
-// wait until at most `young` DMA instructions are outstanding (young = those issued for later epochs; a batch is
-// NDMA instructions -- the template argument -- or one more for a whole region)
-template <int NDMA>
-__device__ __forceinline__ void fused_wait_dma(int young) {
-  if (3 * NDMA <= 63 && young >= 3 * NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA <= 63 ? 3 * NDMA : 0) : "memory");
-  else if (2 * NDMA <= 63 && young >= 2 * NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA <= 63 ? 2 * NDMA : 0) : "memory");
-  else if (young >= NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+// wait until at most `young` DMA instructions are outstanding (young = those issued for later epochs), for the few batch sizes
+// the loader issues (a smaller constant is merely conservative)
+__device__ __forceinline__ void fused_wait_upto(int young) {
+  if (young >= 42) asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+  else if (young >= 41) asm volatile("s_waitcnt vmcnt(41)" ::: "memory");
+  else if (young >= 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+  else if (young >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -203,6 +228,9 @@ struct FusedMfmaA {
       const uint4 h = afragA[((par * NKT + kt) * 2 + 0) * 64 + lane], l = afragA[((par * NKT + kt) * 2 + 1) * 64 + lane];
       __builtin_memcpy(&ah[kt], &h, 16); __builtin_memcpy(&al[kt], &l, 16);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (see FusedB16::load)
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++) { asm volatile("" : "+v"(ah[kt])); asm volatile("" : "+v"(al[kt])); }
   }
   // Two samples of one component -> packed (high, 2048 x low) fp16 terms: high = rne(x), low = rne(2048 x - 2048 high) -- the
   // difference is formed inside the mixed-precision FMA, one rounding.  Four instructions per pair.
@@ -219,7 +247,7 @@ struct FusedMfmaA {
   }
   // one epoch: the unit's 256 outputs of component C from the slot.  ABL: 1 no arithmetic at all, 8 no LDS reads, 16 reads only
   template <int C, int PARITY, int ABL = 0>
-  __device__ __forceinline__ void run(const FusedArgs &a, int s, int jE, int pos0, const unsigned char *slot, float *midp,
+  __device__ __forceinline__ void run(const FusedArgs &a, int s, int jE, int pos0, const unsigned char *slot, unsigned char *ring,
                                       int unit, int lane) const {
     using SH = FusedShape<D, NA>;
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -309,11 +337,21 @@ struct FusedMfmaA {
         }
       }
     }
-    int pos = pos0 + jl0;            // a multiple of 4, like MIDR and MIDM: the four samples wrap (and mirror) together
+    int pos = pos0 + jl0;            // a multiple of 4, like MIDR: the four samples wrap together
     if (pos >= SH::MIDR) pos -= SH::MIDR;
-    float *mp = midp + C * SH::MIDP;
-    *reinterpret_cast<v4f *>(mp + pos) = yo;
-    if (pos < SH::MIDM) *reinterpret_cast<v4f *>(mp + pos + SH::MIDR) = yo;
+    {
+      // into the ring as fp16 terms (high, 2048 x low): what stage B multiplies.  The four samples may straddle the end of a
+      // period (125 is odd): four 2-byte stores per plane.
+      const int blk = pos / 125, r0 = pos - 125 * blk;
+      _Float16 *hp = reinterpret_cast<_Float16 *>(ring + C * SH::PLANE_BYTES), *lp = reinterpret_cast<_Float16 *>(ring + (2 + C) * SH::PLANE_BYTES);
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int pi = pos + v + 11 * blk + ((r0 + v >= 125) ? 11 : 0);
+        const _Float16 h = (_Float16)yo[v];
+        hp[pi] = h;
+        lp[pi] = (_Float16)((yo[v] - (float)h) * 2048.0f);
+      }
+    }
     // the next call's stage-B history: the last H_mid mid samples of this call, at their d_mid positions (k_shift_halo re-seats them)
     if (jE + SH::ME > a.count_mid - a.H_mid) {
 #pragma unroll
@@ -344,69 +382,138 @@ inline void fused_make_afragA(const float *hA, unsigned short *out /* 2 * 8 * 2 
         }
 }
 
-// ---- role: stage B (a quarter of the k-steps of a macro tile per epoch) -----------------------------------
-template <int MT0, int NMT>
-struct FusedB {
+// ---- role: stage B on the fp16 matrix cores (waves 1 .. 3: one row tile of 16 positions each) ---------------------------
+// IF sample (period P, position pp) = sum_j hB[phi(pp)][j] mid[window + 125 P + off(pp) + j]: rows = the 16 positions of the
+// wave's row tile, columns = 8 periods x (re, im), k = the POSITIONS of the ring from the row tile's first tap on (K0 = 0,
+// 40, 80: multiples of eight) -- nine k-tiles of 32 cover the 250 + 22 positions a row tile's band spans, the unused
+// positions between two periods meet zero taps.  Both operands in two fp16 terms, three products, three independent
+// accumulators (FusedMfmaA; the taps scaled by a power of two, FusedArgs::hB_inv_scale undoes it).  A B fragment is ONE
+// aligned 16-byte read per term: 18 reads and 27 MFMAs of 16 cycles per macro tile and wave, where the f32 form of rounds
+// 2-4 (v_mfma_f32_16x16x4_f32, one dependent chain, one 4-byte read per k-step) spent 63 reads and 63 MFMAs of 32 cycles --
+// measured ~80 cycles per k-step, 2500 cycles per epoch on the waves that also carry the discriminator epilogue.
+template <int MT0>
+struct FusedB16 {
   typedef float v4f __attribute__((ext_vector_type(4)));
-  using SHB = Poly4Shape<48, 125, 210>;
-  static constexpr int MIDP = FusedShape<kFusedD, kFusedNA>::MIDP;
-  float afr[NMT][SHB::NK];
-  v4f acc[NMT];
-  __device__ __forceinline__ void load(const float *afrag, int lane) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  using SH = FusedShape<kFusedD, kFusedNA>;
+  static constexpr int NKT = 9;
+  static constexpr int off(int pp) { return (pp * 125) / 48; }
+  static constexpr int K0 = (off(16 * MT0) / 8) * 8;
+  static_assert(off(16 * MT0 + 15) + 209 + 11 * ((off(16 * MT0 + 15) + 209) / 125) < K0 + 32 * NKT, "nine k-tiles hold the row tile's band");
+  h8 ah[NKT], al[NKT];
+  v4f acc0, acc1, acc2;
+  __device__ __forceinline__ void load(const uint4 *afragB, int lane) {
 #pragma unroll
-    for (int t = 0; t < NMT; t++)
+    for (int kt = 0; kt < NKT; kt++) {
+      const uint4 h = afragB[((MT0 * NKT + kt) * 2 + 0) * 64 + lane], l = afragB[((MT0 * NKT + kt) * 2 + 1) * 64 + lane];
+      __builtin_memcpy(&ah[kt], &h, 16); __builtin_memcpy(&al[kt], &l, 16);
+    }
+    // The fragments must not stay "results of loads in flight" in the compiler's books: inside the epoch loop it cannot
+    // tell them from the epilogue's stores (one counter, vmcnt) and would wait for vmcnt(0) -- i.e. for every store of the
+    // previous tile to be acknowledged by memory, microseconds under the input stream -- in front of the first MFMA of
+    // every phase (measured: 35 us of a 235 us launch).  Wait here, once, and hand the registers over through an empty asm.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < SHB::NK; i++) afr[t][i] = afrag[((MT0 + t) * SHB::NK + i) * 64 + lane];
+    for (int kt = 0; kt < NKT; kt++) { asm volatile("" : "+v"(ah[kt])); asm volatile("" : "+v"(al[kt])); }
   }
-  template <int KS0, int KS1>
-  __device__ __forceinline__ void run(const float *xb) {
+  template <int KT0, int KT1>
+  __device__ __forceinline__ void run(const unsigned char *ring, int base) {
+    h8 bh[KT1 - KT0], bl[KT1 - KT0];
 #pragma unroll
-    for (int ks = KS0; ks < KS1; ks++) {
-      const float b = xb[4 * ks];
+    for (int kt = KT0; kt < KT1; kt++) {
+      int pos = base + 32 * kt;
+      if (pos >= SH::RINGP) pos -= SH::RINGP;                       // (the last window runs over the end of the ring)
+      bh[kt - KT0] = *reinterpret_cast<const h8 *>(ring + 2 * pos);
+      bl[kt - KT0] = *reinterpret_cast<const h8 *>(ring + 2 * pos + 2 * SH::PLANE_BYTES);
+    }
 #pragma unroll
-      for (int t = 0; t < NMT; t++)
-        if (ks >= SHB::ks_lo(MT0 + t) && ks <= SHB::ks_hi(MT0 + t))
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[t][ks - SHB::ks_lo(MT0 + t)], b, acc[t], 0, 0, 0);
+    for (int kt = KT0; kt < KT1; kt++) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kt], bh[kt - KT0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kt], bl[kt - KT0], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kt], bh[kt - KT0], acc2, 0, 0, 0);
     }
   }
-  // phase q = 0 .. NPH-1 of the macro tile whose window starts at ring position p (NPH = epochs per tile).  The first
-  // phase shares its epoch with the epilogue of the previous tile, so it gets the fewest of the row tile's 63 live
-  // k-steps.  One accumulator, k ascending: bit-identical to k_ifr_poly4.
-  template <int NPH>
-  __device__ __forceinline__ void epoch(int q, int p, const float *midp, float2 *stage, int lane, const float *hB) {
-    static_assert(NMT == 1 && (NPH == 2 || NPH == 4), "one row tile per wave");
-    constexpr int LO = SHB::ks_lo(MT0), HI = SHB::ks_hi(MT0) + 1;
-    constexpr int C1 = LO + (NPH == 4 ? 6 : 16), C2 = LO + 25, C3 = LO + 44;
+  // The IF sample BEFORE the macro tile whose window starts at ring sample p -- position 47 of the period before it -- with
+  // exactly the arithmetic a tile computes it with (row tile 2, the column of period "-1"): a workgroup's first phase
+  // difference then does not depend on where the call was cut into workgroups (a plain tap loop differs from the matrix
+  // cores' summation by rounding).  The lanes that hold row 15 of column 0 / 1 store re / im into `out`.
+  __device__ __forceinline__ void sample_before(int p, const unsigned char *ring, float *out, int lane, const FusedArgs &a) {
+    static_assert(MT0 == 2, "position 47 is row 15 of row tile 2");
     const int n = lane & 15, kq = lane >> 4;
-    const float *xb = midp + (n & 1) * MIDP + p + (n >> 1) * 125 + kq;
+    int base = (p / 1000) * SH::TILEP + ((n >> 1) - 1) * SH::PSTR + K0 + 8 * kq;      // every column one period early
+    if (base < 0) base += SH::RINGP;
+    const unsigned char *plane = ring + (n & 1) * SH::PLANE_BYTES;
+    acc0 = acc1 = acc2 = (v4f){0.f, 0.f, 0.f, 0.f};
+    run<0, 4>(plane, base);
+    run<4, NKT>(plane, base);
+    const v4f y = (acc0 + (acc1 + acc2) * (1.0f / 2048.0f)) * a.hB_inv_scale;
+    float r = y[3];
+    if ((n >> 1) == 0 && kq == 3 && !__builtin_isfinite(r)) {          // (the tile's own repair path, for this one sample)
+      r = 0.f;
+      for (int j = 0; j < 210; j++) r = fmaf(a.hB_last[j], FusedRing::at(ring, n & 1, p - 3 + j), r);
+    }
+    if ((n >> 1) == 0 && kq == 3) out[n & 1] = r;
+  }
+  // phase q = 0 / 1 of the macro tile whose window starts at ring sample p (0, 1000 or 2000).  The first phase shares its
+  // epoch with the epilogue of the previous tile and takes four of the nine k-tiles.
+  template <int NPH>
+  __device__ __forceinline__ void epoch(int q, int p, const unsigned char *ring, float2 *stage, int lane, const FusedArgs &a) {
+    static_assert(NPH == 2, "two epochs per macro tile");
+    const int n = lane & 15, kq = lane >> 4;
+    const int base = (p / 1000) * SH::TILEP + (n >> 1) * SH::PSTR + K0 + 8 * kq;
+    const unsigned char *plane = ring + (n & 1) * SH::PLANE_BYTES;
     if (q == 0) {
-      acc[0] = (v4f){0.f, 0.f, 0.f, 0.f};
-      run<LO, C1>(xb);
-    } else if (NPH == 4 && q == 1) {
-      run<C1, C2>(xb);
-    } else if (NPH == 4 && q == 2) {
-      run<C2, C3>(xb);
+      acc0 = acc1 = acc2 = (v4f){0.f, 0.f, 0.f, 0.f};
+      run<0, 4>(plane, base);
     } else {
-      run<(NPH == 4 ? C3 : C1), HI>(xb);
+      run<4, NKT>(plane, base);
+      v4f y = (acc0 + (acc1 + acc2) * (1.0f / 2048.0f)) * a.hB_inv_scale;
       // exact-support repair, as in stage A: a non-finite mid sample has poisoned every row of the banded tile whose
       // k-range holds it.  Rare and wave-uniform: position pp of the period = the TB taps of its row over the mid ring.
-      if (__builtin_amdgcn_ballot_w64(!__builtin_isfinite(acc[0][0] + acc[0][1] + acc[0][2] + acc[0][3])) != 0) {
+      if (__builtin_amdgcn_ballot_w64(!__builtin_isfinite(y[0] + y[1] + y[2] + y[3])) != 0) {
 #pragma unroll 1
         for (int v = 0; v < 4; v++) {
-          const int pp = 16 * MT0 + 4 * kq + v, phi = (pp * 125) % 48, off = (pp * 125) / 48;
-          const float *xr = midp + (n & 1) * MIDP + p + (n >> 1) * 125 + off, *hr = hB + phi * 210;
+          const int pp = 16 * MT0 + 4 * kq + v, phi = (pp * 125) % 48, s0 = p + (n >> 1) * 125 + off(pp);
+          const float *hr = a.hB + phi * 210;
           float r = 0.f;
 #pragma unroll 1
-          for (int j = 0; j < 210; j++) r = fmaf(hr[j], xr[j], r);
-          acc[0][v] = r;
+          for (int j = 0; j < 210; j++) r = fmaf(hr[j], FusedRing::at(ring, n & 1, s0 + j), r);
+          y[v] = r;
         }
       }
       float *sf = reinterpret_cast<float *>(stage);
 #pragma unroll
-      for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * 48 + 16 * MT0 + 4 * kq + v) + (n & 1)] = acc[0][v];
+      for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * 48 + 16 * MT0 + 4 * kq + v) + (n & 1)] = y[v];
     }
   }
 };
+
+// Host side of FusedB16: the tap fragments [row tile][k-tile][high | low][lane][8 halves] (55 KB) and the power of two the
+// taps were scaled by.  hB: [48 phases][210 taps]; position pi of a period's window = K0 + 32 kt + 8 kq + e holds mid sample
+// m = 125 (pi / 136) + pi % 136 of the window (positions 125 .. 135 of every 136: none).
+inline float fused_make_afragB(const float *hB, unsigned short *out /* 3 * 9 * 2 * 64 * 8 */) {
+  float tmax = 0.f;
+  for (int i = 0; i < 48 * 210; i++) tmax = std::fmax(tmax, std::fabs(hB[i]));
+  int e2 = 0;
+  if (tmax > 0.f) (void)std::frexp(tmax, &e2);
+  const float sc = std::ldexp(1.0f, 10 - e2);               // tmax * sc in [512, 1024)
+  for (int mt = 0; mt < 3; mt++) {
+    const int K0 = (((16 * mt) * 125 / 48) / 8) * 8;
+    for (int kt = 0; kt < 9; kt++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int e = 0; e < 8; e++) {
+          const int pp = 16 * mt + (lane & 15), pi = K0 + 32 * kt + 8 * (lane >> 4) + e, rp = pi % 136;
+          const int m = 125 * (pi / 136) + rp, j = m - (pp * 125) / 48;
+          const float c = (rp < 125 && j >= 0 && j < 210) ? hB[((pp * 125) % 48) * 210 + j] * sc : 0.f;
+          const _Float16 h = (_Float16)c, l = (_Float16)((c - (float)h) * 2048.0f);
+          unsigned short hb, lb;
+          __builtin_memcpy(&hb, &h, 2); __builtin_memcpy(&lb, &l, 2);
+          out[((((size_t)mt * 9 + kt) * 2 + 0) * 64 + lane) * 8 + e] = hb;
+          out[((((size_t)mt * 9 + kt) * 2 + 1) * 64 + lane) * 8 + e] = lb;
+        }
+  }
+  return 1.0f / sc;
+}
 
 // A 64-entry window of the block table in registers (lane l: block base + l), so that the epilogue's walk along the
 // blocks costs v_readlane, not a global load: under the input stream a load takes microseconds.
@@ -491,8 +598,11 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
     if (va && vc) {
       // 8 bytes per IF sample in the product configuration (MPX + |x|^2): what the stores cost is their bytes -- every one
       // queues behind the loader's DMA (tools/bench_fused.hip: 16 B per sample 27 us of the launch, 8 B 10 us, 4 B 4 us)
-      __builtin_nontemporal_store((v2f){d0, d1}, reinterpret_cast<v2f_u *>(bs + ka));
-      if (ns) __builtin_nontemporal_store((v2f){e0, e1}, reinterpret_cast<v2f_u *>(ns + ka));
+      if (ABL & 1024) __builtin_nontemporal_store((v4f){d0, d1, e0, e1}, reinterpret_cast<v4f_u *>(ns + 2 * ka));      // (harness: what ONE 16-byte store costs)
+      else {
+      FUSED_STORE(((v2f){d0, d1}), reinterpret_cast<v2f_u *>(bs + ka));
+      if (ns && !(ABL & 512)) FUSED_STORE(((v2f){e0, e1}), reinterpret_cast<v2f_u *>(ns + ka));
+      }
       if (os) __builtin_nontemporal_store(xx, reinterpret_cast<v4f_u *>(os + ka));
       if (a.dec) { float *pd = a.dec + (long long)s * a.dec_stride + ka; pd[0] = d0; pd[1] = d1; }
     } else {
@@ -542,24 +652,10 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
   }
 }
 
-// normalised phase of IF sample k = (first sample of macro tile at ring window p) - 1: position 47 of the period before
-// the tile, a plain k-ordered fmaf chain over the TB taps of its row (bit-equal to the MFMA form), on lane 0
-__device__ __forceinline__ float fused_prev_phase(const FusedArgs &a, const float *midp, int p) {
-  float re = 0.f, im = 0.f;
-  int pos = p - 3; if (pos < 0) pos += 3000;           // mid sample 1000 T - 107 (the window starts at 1000 T - 104)
-  for (int j = 0; j < 210; j++) {
-    const float h = a.hB_last[j];
-    const float2 x = make_float2(midp[pos], midp[FusedShape<kFusedD, kFusedNA>::MIDP + pos]);
-    re = fmaf(h, x.x, re); im = fmaf(h, x.y, im);
-    if (++pos == 3000) pos = 0;
-  }
-  return fused_atan2(im, re) * (1.0f / a.nf);
-}
-
 template <int EPT, int LAG, int MT0, bool OFF, bool DBG, int ABL = 0>
-__device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, int t3, int nt, int NE, const float *midr, float2 *stage, int lane, int wave) {
-  FusedB<MT0, 1> b;
-  b.load(a.afrag, lane);
+__device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, int t3, int nt, int NE, const unsigned char *midr, float2 *stage, int lane, int wave) {
+  FusedB16<MT0> b;
+  b.load(a.afragB, lane);
   if (FUSED_B_PRIO) __builtin_amdgcn_s_setprio(FUSED_B_PRIO);
   float2 *os = a.out ? a.out + (long long)s * a.out_stride + a.out_off : nullptr;     // (null: MPX + |x|^2 only)
   fused_barrier();
@@ -570,13 +666,20 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
   float save0 = 0.f;
   FusedBlkWin win{};
   if (a.base) { save0 = a.st[s].disc_save; blk = a.wg_blk0[blockIdx.x]; win.load(a, blk, lane); }
+  // (as in FusedB16::load: nothing loaded before the loop may still count as "in flight" inside it, or its first use in
+  // every epoch waits for the epilogue's stores)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" : "+v"(save0), "+v"(win.end_l), "+v"(win.len_l));
+  blk = __builtin_amdgcn_readfirstlane(blk);
   unsigned long long busy = 0, t_begin = FUSED_CLK();
   for (int e = 0; e < NE; e++) {
     const unsigned long long tb = FUSED_CLK();
+    // the sample before this workgroup's first one: the previous call's (disc_save), or recomputed from the warm-up mid
+    // samples -- by the wave that owns position 47, one epoch before the wave that needs its phase reads it
+    if constexpr (MT0 == 2) { if (e == EPT + LAG && a.base && kb > 0) b.sample_before(p, midr, reinterpret_cast<float *>(stage + 384), lane, a); }
     if (e == EPT + 1 + LAG && a.base && MT0 == 0) {
-      // the sample before this workgroup's first one: previous call (disc_save), or recomputed from the warm-up mid samples
       if (kb <= 0) prev_tile = save0;
-      else { float v = 0.f; if (lane == 0) v = fused_prev_phase(a, midr, p); prev_tile = __shfl(v, 0, 64); }
+      else { const float2 xb = stage[384]; prev_tile = fused_atan2(xb.y, xb.x) * (1.0f / a.nf); }
     }
     if (e >= 2 * EPT + 1 + LAG && ((e - 1 - LAG) % EPT) == 0) {  // epilogue of the tile staged at the end of the previous epoch
       if (a.base) {
@@ -597,7 +700,7 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
       kb += 384; tile_g++;
     }
     if (!OFF && e >= EPT + 1 + LAG && e <= EPT * nt + EPT + LAG) {
-      b.template epoch<EPT>(q, p, midr, stage, lane, a.hB);
+      b.template epoch<EPT>(q, p, midr, stage, lane, a);
       if (++q == EPT) { q = 0; p = (p == 2000) ? 0 : p + 1000; }
     }
     if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -640,13 +743,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a) {
   using SH = FusedShape<D, NA>;
   constexpr bool DBG = (ABL & 32) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_f[];
-  float *midr = reinterpret_cast<float *>(lds_f + SH::NSLOT * SH::SLOT_BYTES);
-  float2 *stage = reinterpret_cast<float2 *>(midr + 2 * SH::MIDP);
+  unsigned char *midr = lds_f + SH::NSLOT * SH::SLOT_BYTES;
+  float2 *stage = reinterpret_cast<float2 *>(midr + 4 * SH::PLANE_BYTES);
   const int s = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int i0 = blockIdx.x * a.tiles_per_wg;
   const int i1 = min(i0 + a.tiles_per_wg, a.n_tiles);
   if (i0 >= i1) return;
+  // (the unused positions of the mid ring meet zero taps: they must hold finite numbers)
+  for (int i = threadIdx.x; i < 4 * SH::PLANE_BYTES / 16; i += FUSED_THREADS) reinterpret_cast<uint4 *>(midr)[i] = make_uint4(0u, 0u, 0u, 0u);
   const int nt = i1 - i0, NE = SH::EPT * nt + SH::EPT + 2, EA = SH::EPT * nt;       // EA = last stage-A epoch
   const int jE0 = a.j_ref + 1000 * i0;                         // first mid sample of epoch 0 (a macro tile = 1000 mid samples)
   const int pos00 = (a.pos_ref + 1000 * (i0 % 3)) % SH::MIDR;
@@ -668,7 +773,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a) {
     { int young = 0;
 #pragma unroll
       for (int k = 0; k < SH::AHEAD - 1; k++) young += cy[k];
-      fused_wait_dma<SH::NDMA - 1>(young); }               // the slot of epoch 0 has landed
+      fused_wait_upto(young); }               // the slot of epoch 0 has landed
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int slot = SH::AHEAD;
     unsigned long long busy = 0, t_begin = FUSED_CLK();
@@ -682,7 +787,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a) {
       int young = cn;
 #pragma unroll
       for (int k = 1; k < SH::AHEAD - 1; k++) young += cy[k];
-      fused_wait_dma<SH::NDMA - 1>(young);
+      fused_wait_upto(young);
 #pragma unroll
       for (int k = 0; k + 1 < SH::AHEAD - 1; k++) cy[k] = cy[k + 1];
       if (SH::AHEAD >= 2) cy[SH::AHEAD - 2] = cn;

@@ -29,7 +29,7 @@ struct Ctx {
   size_t max_in, max_mid, max_if;
   float2 *d_in_halo, *d_mid, *d_if_old, *d_if_new;
   float *d_hpA, *d_afrag;
-  unsigned long long *d_dbg = nullptr; uint4 *d_afragA = nullptr; float *d_hAf = nullptr, *d_hBf = nullptr;
+  unsigned long long *d_dbg = nullptr; uint4 *d_afragA = nullptr, *d_afragB = nullptr; float hB_inv_scale = 1.f; float *d_hAf = nullptr, *d_hBf = nullptr;
   long long wg_key = -1;
   float *d_base = nullptr, *d_nrm = nullptr; float *d_dec = nullptr, *d_hBlast = nullptr, *d_stats = nullptr; StreamState *d_st = nullptr; FusedPart *d_part = nullptr; int *d_tab = nullptr;
   bool epi = false, lean = false; int h_off_dev400 = 0; int nb = 0; std::vector<int> h_off, h_len; int *d_wgblk = nullptr;
@@ -66,17 +66,20 @@ static void setup(Ctx &c, size_t max_in) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 125, 210>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
   constexpr int kL = FusedShape<kFusedD, kFusedNA>::LDS_BYTES;
 #define SETATTR(P, A) CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_fused<kFusedD, kFusedNA, P, A>), hipFuncAttributeMaxDynamicSharedMemorySize, kL))
-  SETATTR(0, 0); SETATTR(1, 0); SETATTR(0, 64); SETATTR(1, 64); SETATTR(0, 128); SETATTR(1, 128); SETATTR(0, 256); SETATTR(1, 256); SETATTR(0, 448); SETATTR(1, 448); SETATTR(0, 46); SETATTR(1, 46); SETATTR(0, 54); SETATTR(1, 54); SETATTR(0, 39); SETATTR(1, 39); SETATTR(0, 1); SETATTR(1, 1); SETATTR(0, 2); SETATTR(1, 2); SETATTR(0, 3); SETATTR(1, 3);
+  SETATTR(0, 0); SETATTR(1, 0); SETATTR(0, 512); SETATTR(1, 512); SETATTR(0, 1024); SETATTR(1, 1024); SETATTR(0, 64); SETATTR(1, 64); SETATTR(0, 128); SETATTR(1, 128); SETATTR(0, 256); SETATTR(1, 256); SETATTR(0, 448); SETATTR(1, 448); SETATTR(0, 46); SETATTR(1, 46); SETATTR(0, 54); SETATTR(1, 54); SETATTR(0, 39); SETATTR(1, 39); SETATTR(0, 1); SETATTR(1, 1); SETATTR(0, 2); SETATTR(1, 2); SETATTR(0, 3); SETATTR(1, 3);
   SETATTR(0, 4); SETATTR(1, 4); SETATTR(0, 7); SETATTR(1, 7); SETATTR(0, 5); SETATTR(1, 5); SETATTR(0, 6); SETATTR(1, 6);
   SETATTR(0, 14); SETATTR(1, 14); SETATTR(0, 22); SETATTR(1, 22); SETATTR(0, 32); SETATTR(1, 32); SETATTR(0, 36); SETATTR(1, 36); SETATTR(0, 38); SETATTR(1, 38); SETATTR(0, 37); SETATTR(1, 37); SETATTR(0, 35); SETATTR(1, 35);
   CK(hipMalloc(&c.d_hAf, fa.size() * 4)); CK(hipMemcpy(c.d_hAf, fa.data(), fa.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&c.d_hBf, fb.size() * 4)); CK(hipMemcpy(c.d_hBf, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
   { std::vector<unsigned short> fr(2 * 8 * 2 * 64 * 8);
     fused_make_afragA<kFusedD, kFusedNA>(fa.data(), fr.data());
-    CK(hipMalloc(&c.d_afragA, fr.size() * 2)); CK(hipMemcpy(c.d_afragA, fr.data(), fr.size() * 2, hipMemcpyHostToDevice)); }
+    CK(hipMalloc(&c.d_afragA, fr.size() * 2)); CK(hipMemcpy(c.d_afragA, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+    std::vector<unsigned short> frb((size_t)3 * 9 * 2 * 64 * 8);
+    c.hB_inv_scale = fused_make_afragB(fb.data(), frb.data());
+    CK(hipMalloc(&c.d_afragB, frb.size() * 2)); CK(hipMemcpy(c.d_afragB, frb.data(), frb.size() * 2, hipMemcpyHostToDevice)); }
   CK(hipMalloc(&c.d_dbg, 32 * 8)); CK(hipMemset(c.d_dbg, 0, 32 * 8));
   CK(hipMalloc(&c.d_wgblk, 1024 * 4));
-  CK(hipMalloc(&c.d_base, c.max_if * 4)); CK(hipMalloc(&c.d_nrm, c.max_if * 4)); CK(hipMalloc(&c.d_dec, c.max_if * 4)); CK(hipMalloc(&c.d_st, sizeof(StreamState)));
+  CK(hipMalloc(&c.d_base, c.max_if * 4)); CK(hipMalloc(&c.d_nrm, c.max_if * 8 + 64)); CK(hipMalloc(&c.d_dec, c.max_if * 4)); CK(hipMalloc(&c.d_st, sizeof(StreamState)));
   CK(hipMemset(c.d_st, 0, sizeof(StreamState)));
   CK(hipMalloc(&c.d_part, (c.max_if / 128 + 16) * sizeof(FusedPart))); CK(hipMalloc(&c.d_tab, 2 * 4096 * 4)); CK(hipMalloc(&c.d_stats, 3 * 4096 * 4));
   { std::vector<float> row(fb.begin() + (size_t)phi[47] * rs.TB, fb.begin() + (size_t)(phi[47] + 1) * rs.TB);
@@ -134,7 +137,7 @@ static void launch_new(Ctx &c, const CallGeom &g, const float2 *d_iq, float2 *if
   a.kb_ref = (int)(384 * T_first - g.kB_prev);
   a.count_mid = g.count_mid;
   a.mid = c.d_mid; a.mid_stride = (long long)(c.H_mid + c.max_mid); a.H_mid = c.H_mid;
-  a.afrag = c.d_afrag; a.n_if = (int)g.N_if;
+  a.afragB = c.d_afragB; a.hB_inv_scale = c.hB_inv_scale; a.n_if = (int)g.N_if;
   a.out = ifbuf; a.out_stride = (long long)(c.H_if + c.max_if); a.out_off = c.H_if;
   a.dbg = c.d_dbg;
   if (c.epi) {
@@ -344,6 +347,8 @@ int main(int argc, char **argv) {
   time_it("fused A+B+discriminator AS IN THE CHAIN (lean)", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
   time_it("lean, no global stores", bytes, [&] { launch_new<128>(c, g, d_iq, c.d_if_new, 256); });
   time_it("lean, no atan2", bytes, [&] { launch_new<64>(c, g, d_iq, c.d_if_new, 256); });
+  time_it("lean, MPX store only (one 8-byte store per lane)", bytes, [&] { launch_new<512>(c, g, d_iq, c.d_if_new, 256); });
+  time_it("lean, one 16-byte store per lane (MPX + |x|^2 together)", bytes, [&] { launch_new<1024>(c, g, d_iq, c.d_if_new, 256); });
   for (int i = 0; i < 3; i++) time_it("fused A+B+discriminator AS IN THE CHAIN (lean)", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
   c.lean = false;
   time_it("fused A+B+discriminator, 256 workgroups", bytes, [&] { launch_new(c, g, d_iq, c.d_if_new, 256); });
