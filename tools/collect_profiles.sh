@@ -8,31 +8,33 @@ root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 cd "$root"
 mkdir -p gpurun_out
-[ "${2:-}" = "quick" ] || python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
-python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o ${tag} -- python bench.py --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_write.log 2>&1
+[ "${2:-}" = "quick" ] || timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1 < /dev/null
+timeout 400 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1 < /dev/null
+timeout 400 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err < /dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o ${tag} -- python bench.py --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1 < /dev/null
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch.log 2>&1 < /dev/null
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_write.log 2>&1 < /dev/null
 # tools/collect_profiles.sh <tag> quick: stop here (bench line, stats and PMC passes of the main configuration only;
 # the lines of the other configurations stay as the last full collection left them under gpurun_out/)
 if [ "${2:-}" = "quick" ]; then cut -c1-400 gpurun_out/${tag}_bench.json; exit 0; fi
 # the three-kernel front end (FMR_NO_FUSED=1) under the same counters, for the traffic comparison
-FMR_NO_FUSED=1 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_nofused.json 2> gpurun_out/${tag}_bench_nofused.err
-FMR_NO_FUSED=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch_nofused -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch_nofused.log 2>&1
-FMR_NO_FUSED=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write_nofused -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_write_nofused.log 2>&1
+FMR_NO_FUSED=1 timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_nofused.json 2> gpurun_out/${tag}_bench_nofused.err < /dev/null
+FMR_NO_FUSED=1 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch_nofused -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch_nofused.log 2>&1 < /dev/null
+FMR_NO_FUSED=1 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write_nofused -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_write_nofused.log 2>&1 < /dev/null
 # the other configs of BASELINE.json (lines only)
-python bench.py --streams 32 --blocks 128 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_config5_32streams.json 2>/dev/null
-python bench.py --multipath-stages 64 --blocks 64 --steps 5 --warmup 3 > gpurun_out/${tag}_bench_config4_E64.json 2>/dev/null
-python bench.py --multipath-stages 64 --streams 32 --blocks 64 --steps 3 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_config4_E64_32streams.json 2>/dev/null
+timeout 400 python bench.py --streams 32 --blocks 128 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_config5_32streams.json 2>/dev/null < /dev/null
+timeout 400 python bench.py --multipath-stages 64 --blocks 64 --steps 5 --warmup 3 > gpurun_out/${tag}_bench_config4_E64.json 2>/dev/null < /dev/null
+timeout 400 python bench.py --multipath-stages 64 --streams 32 --blocks 64 --steps 3 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_config4_E64_32streams.json 2>/dev/null < /dev/null
 for s in 128 256; do timeout 250 python bench.py --multipath-stages 64 --streams $s --blocks 64 --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_config4_E64_${s}streams.json 2>/dev/null < /dev/null; done
-python bench.py --mode am --steps 20 --warmup 3 > gpurun_out/${tag}_bench_config3_am.json 2>/dev/null
-python bench.py --mode am --streams 32 --blocks 1024 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_config3_am_32streams.json 2>/dev/null
-python bench.py --no-pilot --steps 3 --warmup 1 --blocks 256 --no-cpu-baseline > gpurun_out/${tag}_bench_no_pilot.json 2>/dev/null
+timeout 400 python bench.py --mode am --steps 20 --warmup 3 > gpurun_out/${tag}_bench_config3_am.json 2>/dev/null < /dev/null
+timeout 400 python bench.py --mode am --streams 32 --blocks 1024 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_config3_am_32streams.json 2>/dev/null < /dev/null
+timeout 400 python bench.py --no-pilot --steps 3 --warmup 1 --blocks 256 --no-cpu-baseline > gpurun_out/${tag}_bench_no_pilot.json 2>/dev/null < /dev/null
 for s in 64 256; do timeout 250 python bench.py --no-pilot --streams $s --blocks 32 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_no_pilot_${s}streams.json 2>/dev/null < /dev/null; done
 timeout 300 python bench.py --resampler-class r8b --steps 20 --warmup 3 > gpurun_out/${tag}_bench_r8b.json 2>/dev/null < /dev/null
 timeout 300 python bench.py --if-filter --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_if_filter.json 2>/dev/null < /dev/null
-timeout 120 tools/bench_fused.bin > gpurun_out/${tag}_fused_harness.log 2>&1
+for sg in 1e-2 3e-2; do timeout 200 python bench.py --sigma $sg --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_sigma_${sg}.json 2>/dev/null < /dev/null; done
+timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_driver_form.json 2>/dev/null < /dev/null
+timeout 120 tools/bench_fused.bin > gpurun_out/${tag}_fused_harness.log 2>&1 < /dev/null
 # the chain's own schedule trace, the equaliser's cycle account and rates, the PLL's mismatch history
 timeout 120 python tools/step_timeline.py --show 2 --out gpurun_out/${tag}_step_timeline.txt > /dev/null 2>&1
 timeout 120 python tools/step_timeline.py --show 1 --r8b --out gpurun_out/${tag}_step_timeline_r8b.txt > /dev/null 2>&1
