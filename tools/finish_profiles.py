@@ -85,7 +85,8 @@ alg = rf["algorithmic_bytes_per_launch"]
 o = lambda name: others.get(name) or {}
 nf = bench_line(g(f"{tag}_bench_nofused.json"))
 pm3 = json.load(open(prof(f"{tag}_pmc_traffic_three_kernel_front_end.json")))["kernels"] if os.path.exists(prof(f"{tag}_pmc_traffic_three_kernel_front_end.json")) else {}
-three = sum(v["hbm_bytes"] for k, v in pm3.items() if any(n in k for n in ("k_ifr_decim", "k_ifr_poly", "k_disc")))
+three = sum(v["hbm_bytes"] for k, v in pm3.items() if any(n in k for n in ("k_ifr_decim", "k_ifr_poly", "k_disc"))
+            and "k_ifr_poly5h" not in k and "k_ifr_decim2<128, 24" not in k)      # (the run's r8b leg has its own stage A / B kernels)
 gs = lambda v: f"{v / 1e3:.1f} GS/s" if v and v >= 1e4 else (f"{v / 1e3:.2f} GS/s" if v and v >= 1e3 else f"{v:.1f} MS/s")
 rs = summary["rocprofv3_stats"]
 rows = {
@@ -96,7 +97,7 @@ rows = {
     "same stage with the three-kernel front end (`FMR_NO_FUSED=1`, round 1's path, same box)":
         (f"{nf['roofline']['stage']['ms']:.3f} ms = {nf['roofline']['stage']['frac']:.3f}; whole job {gs(nf['value'])}" if nf else "not collected"),
     "PMC traffic of the stage (FETCH_SIZE×2 + WRITE_SIZE, separate passes)":
-        (f"{fk[0]['hbm_bytes'] / 1e9:.3f} GB per launch = {fk[0]['hbm_bytes'] / alg:.3f} × algorithmic ({fk[0]['read_bytes'] / 1e9:.3f} GB read, {fk[0]['write_bytes'] / 1e9:.3f} GB write: IF + f64 MPX)" if fk else "n/a")
+        (f"{fk[0]['hbm_bytes'] / 1e9:.3f} GB per launch = {fk[0]['hbm_bytes'] / alg:.3f} × algorithmic ({fk[0]['read_bytes'] / 1e9:.3f} GB read, {fk[0]['write_bytes'] / 1e9:.3f} GB write: MPX + |x|^2 as floats)" if fk else "n/a")
         + (f"; three-kernel front end {three / 1e9:.3f} GB = {three / alg:.2f} ×" if three else ""),
     "CPU oracle (`cpu_baseline`, kind \"port\"), same stream":
         (f"{cb.get('value', 0):.1f} MS/s on 1 core; {((cb.get('all_cores') or {}).get('value') or 0):.0f} MS/s with one oracle process per core ({(cb.get('all_cores') or {}).get('cores', '?')} cores)" if cb else "n/a"),
