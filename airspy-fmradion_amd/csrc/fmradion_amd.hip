@@ -246,6 +246,7 @@ struct fmr_chain {
   int c_pll = 64;                      // PLL chunk length (>= C_PLL_MIN; 32: 0.40 ms, 48: 0.345, 64: 0.33, 96 / 128: 0.47 per 2^27-sample call)
   int H_b = 0;                         // halo of the pre-de-emphasis buffers (>= warm-up)
   size_t max_ck = 0, max_agc_nc = 0, max_dc_nc = 0;
+  DevBuf<double> d_pll_wfirst;          // start node of every integration wave's first chunk (the fused down-sweep reads it)
   DevBuf<double> d_base_de, d_raw_de, d_pll_nodes, d_pll_G, d_pll_M, d_pll_PQ, d_pll_dstart, d_pll_PQ2, d_pll_dstart2, d_pll_gres,
       d_blk_level, d_agc_M,
       d_dc_G, d_dc_start;
@@ -261,6 +262,10 @@ struct fmr_chain {
   // asynchronous calls never overwrite a table that is still being copied
   static constexpr int kTabSlots = 8;
   static constexpr int kMaxFusedWg = 1024;
+#ifndef FMR_FE_SPARE_CUS
+#define FMR_FE_SPARE_CUS 8
+#endif
+  static constexpr int kFeSpareCus = FMR_FE_SPARE_CUS;      // CUs the pipelined chain's front end leaves to the kernels beside it
   int *h_tab_all = nullptr;  // pinned, kTabSlots * tab_ints
   size_t tab_ints = 0;       // 5*max_blocks block table + 3*max_ck chunk table + (max_blocks+1) first-chunk table
   unsigned long long call_seq = 0;      // calls issued
@@ -310,7 +315,7 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_pll_wgr.release(); d_pll_pre.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     d_af_nodes.release(); d_af_G.release(); d_af_M.release(); d_af_out.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
@@ -890,6 +895,7 @@ int fmr_chain::init(const fmr_config *c) {
       if ((rc = d_pll_PQ2.alloc((size_t)S * max_grp2 * 56))) return rc;
       if ((rc = d_pll_dstart2.alloc((size_t)S * max_grp2 * 7))) return rc;
       if ((rc = d_pll_pre.alloc((size_t)S * max_grp * 56))) return rc;
+      if ((rc = d_pll_wfirst.alloc((size_t)S * (max_ck / 64 + 2) * 7))) return rc;
       if ((rc = d_pll_sync.alloc((size_t)S))) return rc;               // zeroed here; the kernels leave it zeroed
       if ((rc = d_pll_tick2.alloc((size_t)S * max_grp2))) return rc;
       pll_tick2_per_stream = (int)max_grp2;
@@ -1355,7 +1361,7 @@ int fmr_chain::run_tables(CallCtx &k) {
     // maps to, and the kernels that run beside the front end -- lock logic (32 KB of LDS), the DC block's node pass (213
     // VGPRs), the spare PLL rounds -- do not fit beside a 152 KB workgroup: on an XCD the front end fills they wait for
     // it to end (measured: the lock logic 250 instead of 55 us, and the next PLL pass behind it).
-    const int fe_dflt = pipelined ? std::max(8, n_cu - 8) : n_cu;
+    const int fe_dflt = pipelined ? std::max(8, n_cu - kFeSpareCus) : n_cu;
     const int fe_cus = (pipelined && env.fe_cus > 0) ? std::min(env.fe_cus, n_cu) : fe_dflt;
     const int wg_per_stream = std::max(1, std::min(kMaxFusedWg, fe_cus / S));
     fused_tiles_per_wg = (fused_n_tiles + wg_per_stream - 1) / wg_per_stream;
@@ -1683,12 +1689,22 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
         // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
         // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
         PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
+        // The pass that integrates the Jacobians composes them in its own tail (the node pass's up-sweep: k_pll_up's work
+        // without its launch and without reading 31 MB of Jacobians back), see k_pll_shoot
+        const bool up_in_shoot = sy != nullptr && it < pll_jac_rounds && it + 1 < pll_iters;
+        const PllUpArgs upa = up_in_shoot ? PllUpArgs{d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp, ngrp2, d_pll_dstart2.p, d_pll_sync.p, d_pll_tick2.p}
+                                          : PllUpArgs{};
+        // ... and every later pass runs the down-sweep of the node pass before it in its own head (k_pll_down's work without
+        // its launch): a round is two launches, integration + up-sweep kernel (the first round: one)
+        const bool down_in_shoot = sy != nullptr && it > 0;
+        const PllDownArgs dna = down_in_shoot ? PllDownArgs{d_pll_pre.p, d_pll_dstart2.p, ngrp, ngrp2, pllc.minfreq, pllc.maxfreq, d_pll_wfirst.p}
+                                              : PllDownArgs{};
         auto shoot = [&](auto kern) {
           sub(ps, it == 0 ? "pll_shoot_jac" : "pll_shoot", [&] {
           hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, ps, k.base, base_stride, H_b, ct,
                              k.raw, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
                              d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
-                             pll_rtol, (int)(it > 0));
+                             pll_rtol, (int)(it > 0), upa, dna, sy ? d_pll_wfirst.p : (double *)nullptr);
           });
         };
         // the first round writes no L-R samples unless it can be the accepted one (a call of one or two chunks)
@@ -1719,15 +1735,11 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
 #endif
         if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
         if (!env.pll_v1) {
+          if (!up_in_shoot)
           sub(ps, "pll_up", [&] {
           hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, ps, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
                              d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p, d_flags.p, d_pll_sync.p,
                              d_pll_tick2.p);
-          });
-          sub(ps, "pll_down", [&] {
-          hipLaunchKernelGGL(k_pll_down, dim3(ngrp, S), dim3(64), 0, ps, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
-                             d_pll_pre.p, d_pll_dstart2.p, ngrp2, d_flags.p, pllc.minfreq, pllc.maxfreq,
-                             d_pll_sync.p);
           });
           continue;
         }

@@ -2120,7 +2120,7 @@ __global__ __launch_bounds__(BLOCK) void k_fe_post(float2 *__restrict__ in_halo,
 // values are summed here from the fused front end's pieces (index order: deterministic) instead of read from the
 // per-block arrays k_disc writes -- mean / rms of the discriminator output (Utility.h:135-152) and the IF RMS
 // (Utility.h:118-132, FmDecode.cpp:95).
-#define FMR_STATS_THREADS 512
+#define FMR_STATS_THREADS 384
 __global__ __launch_bounds__(FMR_STATS_THREADS) void k_stats(BlockTab bt, const float *__restrict__ if_rms_blk,
                                               const float *__restrict__ bb_mean_blk,
                                               const float *__restrict__ bb_rms_blk, StreamState *st, int n_streams,
@@ -2129,7 +2129,7 @@ __global__ __launch_bounds__(FMR_STATS_THREADS) void k_stats(BlockTab bt, const 
   // One workgroup per stream.  Phase 1, all waves: a lane per block fetches (or, behind the fused front end, sums from the
   // partial sums, index order: deterministic) the block's three values -- every load of up to 512 blocks in flight at
   // once; with one wave doing 64 blocks at a time this was 0.15-0.2 ms of memory latency.  Phase 2, wave 0: the EMA
-  // chain over the blocks in order, from LDS (8 KB: the kernel fits beside the front end's workgroup).
+  // chain over the blocks in order, from LDS (6 KB: the kernel fits beside the front end's workgroup).
   constexpr int NT = FMR_STATS_THREADS;
   __shared__ float s_r[NT], s_m[NT], s_l[NT];
   __shared__ int s_n[NT];

@@ -958,6 +958,19 @@ __device__ __forceinline__ void pll_round_check(IterFlags &F, PllSync &Y, double
   else F.pll_resid = have_d ? m : mr;
 }
 
+#define FMR_NODE_GRP 32    // chunks per level-1 group of the node pass (below)
+#define FMR_NODE_GRP2 32   // level-1 groups per level-2 group
+// The up-sweep of the node pass from a group's Jacobians and mismatches in LDS (defined with the node pass below): the
+// integration pass that has just computed them runs it in its own tail (round 5), k_pll_up stages them from HBM first.
+struct PllUpArgs { double *PQ, *PRE, *PQ2; int ngrp, ngrp2; double *dstart2; PllSync *sync; unsigned int *tick2; };
+// ... and the down-sweep of the node pass in the HEAD of the pass that integrates from its result (pll_down_group).
+struct PllDownArgs { const double *PRE, *dstart2; int ngrp, ngrp2; double minfreq, maxfreq; const double *wave_first; };
+__device__ __forceinline__ void pll_down_group(const PllDownArgs &dn, double *nodes_s, const double *g, const double *m, int nck, int s, int grp,
+                                               PllSync *sync, double *sm, double *sr, double *so, double *first, int lane);
+__device__ __forceinline__ void pll_up_from_lds(const PllUpArgs &u, int s, int grp, int n, double *sm, double *sh, int lane);
+__device__ __forceinline__ void pll_stage_group(const double *__restrict__ m, const double *__restrict__ g, const double *__restrict__ nd,
+                                                int c0, int n, int lane, double *sm, double *sr, double *so, int rs = 8);
+
 // WOUT: store the demodulated L-R samples and the wrap masks.  The first round's trajectory is never the accepted one
 // (its start nodes are the nominal ramp), so it skips the 8 bytes per sample.
 //
@@ -975,7 +988,10 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const fm_mpx_t *__restrict__ b
                             const double *__restrict__ nodes, double *__restrict__ G, double *__restrict__ M,
                             int *__restrict__ ck_wraps, unsigned long long *__restrict__ ck_mask, int mask_words,
                             IterFlags *__restrict__ fl, double *__restrict__ wg_r,
-                            PllSync *__restrict__ sync, double tol, double rtol, int have_d) {
+                            PllSync *__restrict__ sync, double tol, double rtol, int have_d,
+                            PllUpArgs up = PllUpArgs{} /* JAC pass, PQ != null: the node pass's up-sweep runs in this launch's tail */,
+                            PllDownArgs dn = PllDownArgs{} /* PRE != null: ... and its down-sweep in this launch's head (nodes is then written) */,
+                            double *__restrict__ wave_first = nullptr /* [S][workgroups][7]: the start node of every wave's first chunk, for the next down-sweep */) {
   constexpr int T = 32, TP = T + 1;          // tile: 64 rows of T samples, one pad word pair per row
 #ifdef FMR_PLL_TRACE   // diagnostic build: where and when every workgroup ran (tools/pll_trace.py reads the dump)
   const unsigned long long trace_t0 = __builtin_readcyclecounter(), trace_w0 = wall_clock64();
@@ -984,6 +1000,7 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const fm_mpx_t *__restrict__ b
   __shared__ double xs[64 * TP];
   __shared__ int s_off[64], s_len[64];
   static_assert(64 * TP >= 64 * 25, "the tile also carries the Jacobians out, 25 elements per lane at a time");
+  static_assert(64 * TP >= FMR_NODE_GRP2 * 56 + 64, "... and stages the up-sweep of the node pass");
   for (int i = threadIdx.x; i < 257; i += blockDim.x) tab[i] = atan_tab[i];
   const int lane = threadIdx.x;
   const int c = blockIdx.x * blockDim.x + lane;
@@ -1002,8 +1019,52 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const fm_mpx_t *__restrict__ b
   double rmax = 0.0;
   PllRegs S;
   const double *nd = nodes + ((long long)s * (ct.nck + 1) + cc) * 7;
+  double nxt[7];                             // start node of the NEXT chunk (the boundary mismatch at the end)
+  if (!JAC && dn.PRE) {
+    // ---- the node pass's down-sweep for this wave's two groups of 32 chunks, here: k_pll_down was a launch of its own
+    // (26 us + a launch gap) whose every workgroup did 32 dependent 7 x 7 steps and went away.  A wave needs the new start
+    // nodes of ITS chunks only: those of chunks c0 + 1 .. from its own two sweeps, that of its first chunk from the group's
+    // prefix composite (pll_down_group) -- nothing another wave of this launch writes.
+    double *sm = xs, *sr = xs + FMR_NODE_GRP * 49, *so = sr + FMR_NODE_GRP * 7, *first = so + FMR_NODE_GRP * 7;
+    static_assert(64 * TP >= FMR_NODE_GRP * (49 + 7 + 7) + 8, "down-sweep staging");
+    double *nds = const_cast<double *>(nodes) + (long long)s * (ct.nck + 1) * 7;
+    const double *gb = G + (long long)s * ct.nck * 9;
+    const double *mb2 = M + (long long)s * ct.nck * 49;
 #pragma unroll
-  for (int k = 0; k < 7; k++) S.v[k] = nd[k];
+    for (int k = 0; k < 7; k++) { S.v[k] = 0.0; nxt[k] = 0.0; }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const int grp = 2 * blockIdx.x + h, c0 = grp * FMR_NODE_GRP;
+      if (c0 >= ct.nck) break;
+      __syncthreads();
+      pll_down_group(dn, nds, gb, mb2, ct.nck, s, grp, sync, sm, sr, so, first, lane);
+      __syncthreads();
+      // lane l of this half starts chunk c0 + t (t = l & 31): t = 0 from `first` (h = 0) / the other half's last node
+      // (h = 1, kept in `carry`), t >= 1 from so[t - 1]; its next node is so[t]
+      const int t = lane & 31;
+      if ((lane >> 5) == h) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          if (t > 0) S.v[k] = so[(t - 1) * 7 + k];
+          else if (h == 0) S.v[k] = first[k];
+          nxt[k] = so[t * 7 + k];
+        }
+      }
+      if (h == 0) {      // chunk c0 + 32's start node = the last node of this sweep: lane 32 takes it
+#pragma unroll
+        for (int k = 0; k < 7; k++) if (lane == 32) S.v[k] = so[31 * 7 + k];
+      }
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int k = 0; k < 7; k++) { S.v[k] = nd[k]; nxt[k] = 0.0; }
+  }
+  const bool nxt_in_regs = !JAC && dn.PRE != nullptr;       // (else the next chunk's start node is read where it is needed)
+  if (wave_first && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 7; k++) wave_first[((long long)s * gridDim.x + blockIdx.x) * 7 + k] = S.v[k];
+  }
   S.li = 0.0; S.lq = 0.0; S.freq_err = 0.0;
   pll_sincos(S.v[0], S.sn, S.cs);
   const PllRot rot = pll_rot_make(pc);
@@ -1075,11 +1136,12 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const fm_mpx_t *__restrict__ b
     // the call's end node has no consumer
     if (c + 1 < ct.nck) {
       const double wsc = 1.0 / (1e-7 * (fabs(S.v[3]) + fabs(S.v[5]) + 1.0));
-      rmax = fabs(wrap_pm_pi(S.v[0] - nd[7])) * 1e7;
-      rmax = fmax(rmax, fabs(S.v[1] - nd[8]) * 1e9);
-      rmax = fmax(rmax, fabs(S.v[2] - nd[9]) * 1e5);
+      auto nx = [&](int k) { return nxt_in_regs ? nxt[k] : nd[7 + k]; };
+      rmax = fabs(wrap_pm_pi(S.v[0] - nx(0))) * 1e7;
+      rmax = fmax(rmax, fabs(S.v[1] - nx(1)) * 1e9);
+      rmax = fmax(rmax, fabs(S.v[2] - nx(2)) * 1e5);
 #pragma unroll
-      for (int k = 3; k < 7; k++) rmax = fmax(rmax, fabs(S.v[k] - nd[7 + k]) * wsc);
+      for (int k = 3; k < 7; k++) rmax = fmax(rmax, fabs(S.v[k] - nx(k)) * wsc);
     }
   }
   if (JAC) {   // JAC == false: frozen-Jacobian round, the stored M of the last JAC round stands
@@ -1101,6 +1163,28 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const fm_mpx_t *__restrict__ b
     };
     part(std::integral_constant<int, 0>{}, std::integral_constant<int, 25>{});
     part(std::integral_constant<int, 25>{}, std::integral_constant<int, 24>{});
+  }
+  // ---- the node pass's up-sweep, here: k_pll_up would start behind a launch boundary, with every workgroup of this pass
+  // gone, and read the 31 MB of Jacobians of a 2^27-sample call back from HBM -- 49 us of the step for 2 x 32 dependent
+  // 7 x 8 compositions per wave.  This wave's two groups of 32 chunks are composed as soon as it has stored them (read
+  // back through L2, 12.5 KB each, by the same staging code: held in registers across the sweep they cost the pass its
+  // second wave per SIMD).  Same arithmetic, same order: pll_up_from_lds is k_pll_up's body.
+  if (JAC && up.PQ) {
+    double *sm = xs, *sh = xs + FMR_NODE_GRP2 * 56, *sr = sm + FMR_NODE_GRP * 49;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's G and M stores are in L2
+    const double *ndb = nodes + (long long)s * (ct.nck + 1) * 7;
+    const double *gb = G + (long long)s * ct.nck * 9;
+    const double *mb2 = M + (long long)s * ct.nck * 49;
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const int grp = 2 * blockIdx.x + h, c0 = grp * FMR_NODE_GRP;
+      if (c0 >= ct.nck) break;
+      const int ng = min(FMR_NODE_GRP, ct.nck - c0);
+      __syncthreads();
+      pll_stage_group(mb2, gb, ndb, c0, ng, lane, sm, sr, nullptr, 7);
+      __syncthreads();
+      pll_up_from_lds(up, s, grp, ng, sm, sh, lane);
+    }
   }
 #ifdef FMR_PLL_TRACE
   if (threadIdx.x == 0 && (JAC || WOUT)) {
@@ -1139,8 +1223,6 @@ __global__ __launch_bounds__(64) void k_pll_shoot(const fm_mpx_t *__restrict__ b
 // ~1e-9 in lock), i.e. ~7e-11 in freq per flip; scales sit above that floor:
 // phase 1e-7 rad, freq 1e-9, phase error 1e-5, biquad delays 1e-7 of the (I,Q) pair.
 // ---------------------------------------------------------------------------
-#define FMR_NODE_GRP 32    // chunks per level-1 group
-#define FMR_NODE_GRP2 32   // level-1 groups per level-2 group
 // mismatch r[c][i] = G[c][i] - old[c+1][i]
 __device__ __forceinline__ double pll_mismatch(const double *g, const double *nd, int c, int i) {
   double v = g[(long long)c * 9 + i] - nd[(long long)(c + 1) * 7 + i];
@@ -1154,7 +1236,7 @@ __device__ __forceinline__ double pll_mismatch(const double *g, const double *nd
 // chunks ahead: 288 eight-byte gather instructions per group and one memory latency per batch -- 59 us per pass.)
 __device__ __forceinline__ void pll_stage_group(const double *__restrict__ m, const double *__restrict__ g,
                                                 const double *__restrict__ nd, int c0, int n, int lane,
-                                                double *sm, double *sr, double *so, int rs = 8 /* row stride of sr / so */) {
+                                                double *sm, double *sr, double *so, int rs /* row stride of sr / so */) {
   constexpr int NL = (FMR_NODE_GRP * 49 + 63) / 64;
   const double *mb = m + (long long)c0 * 49;
   double tmp[NL];
@@ -1466,31 +1548,17 @@ __global__ __launch_bounds__(1024) void k_pll_check(IterFlags *fl, int n_streams
 //   k_pll_down:    start delta of a group = its prefix composite applied to the set's start delta (replaces C2's
 //                  32-step chain by one 7x8 product), then phase C; residual maxima through 64 x 8 atomicMax slots
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes, const double *__restrict__ G,
-                                               const double *__restrict__ M, int nck, double *PQ,
-                                               double *__restrict__ PRE, double *PQ2, int ngrp2,
-                                               double *__restrict__ dstart2, const IterFlags *__restrict__ fl,
-                                               PllSync *__restrict__ sync, unsigned int *__restrict__ tick2) {
-  // 14.8 KB of LDS in all: ten workgroups per CU, i.e. the ~2500 groups of a 2^27-sample call in ONE round (with the
-  // mismatches in an array of their own it was 16.9 KB, nine per CU, and a tenth of the groups ran behind the others)
-  __shared__ double sm[FMR_NODE_GRP2 * 56];      // phase A: FMR_NODE_GRP * 49 Jacobian entries, then the mismatches (stride 7)
-  __shared__ double sh[64];
-  static_assert(FMR_NODE_GRP2 * 56 >= FMR_NODE_GRP * (49 + 7), "shared staging buffer");
+__device__ __forceinline__ void pll_up_from_lds(const PllUpArgs &u, int s, int grp, int n, double *sm, double *sh, int lane) {
+  // sm: the group's n Jacobians (49 doubles each), then its mismatches at sm + FMR_NODE_GRP * 49 (stride 7); at least
+  // FMR_NODE_GRP2 * 56 doubles long (level 2 stages a set's maps there); sh: 64 doubles
   double *const sr = sm + FMR_NODE_GRP * 49;
-  const int s = blockIdx.y, grp = blockIdx.x, ngrp = gridDim.x;
-  if (fl[s].pll_converged) return;
-  const int lane = threadIdx.x, i = lane >> 3, k = lane & 7;
+  const int ngrp = u.ngrp, ngrp2 = u.ngrp2;
+  const int i = lane >> 3, k = lane & 7;
   const bool act = i < 7;
   const int ii = act ? i : 0;
   {
-    const double *nd = nodes + (long long)s * (nck + 1) * 7;
-    const double *g = G + (long long)s * nck * 9;
-    const double *m = M + (long long)s * nck * 49;
-    const int c0 = grp * FMR_NODE_GRP, c1 = min(c0 + FMR_NODE_GRP, nck);
-    pll_stage_group(m, g, nd, c0, c1 - c0, lane, sm, sr, nullptr, 7);
-    __syncthreads();
     double val = (act && i == k) ? 1.0 : 0.0;   // P = I, q = 0
-    for (int t = 0; t < c1 - c0; t++) {
+    for (int t = 0; t < n; t++) {
       sh[lane] = val;
       __syncthreads();                      // one wave per block: just orders the LDS write
       double acc = (k == 7) ? sr[t * 7 + ii] : 0.0;
@@ -1500,15 +1568,15 @@ __global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes,
       __syncthreads();
       val = acc;
     }
-    if (act) st_agent(&PQ[(((long long)s * ngrp + grp) * 7 + i) * 8 + k], val);
+    if (act) st_agent(&u.PQ[(((long long)s * ngrp + grp) * 7 + i) * 8 + k], val);
   }
   // ---- level 2: the last group of the set composes the set
   const int set = grp / FMR_NODE_GRP2;
   const int g0 = set * FMR_NODE_GRP2, g1 = min(g0 + FMR_NODE_GRP2, ngrp);
-  if (!pll_last_arrival(tick2 + (long long)s * ngrp2 + set, (unsigned int)(g1 - g0))) return;
+  if (!pll_last_arrival(u.tick2 + (long long)s * ngrp2 + set, (unsigned int)(g1 - g0))) return;
   {
-    const double *pq = PQ + (long long)s * ngrp * 56;
-    double *pre = PRE + (long long)s * ngrp * 56;
+    const double *pq = u.PQ + (long long)s * ngrp * 56;
+    double *pre = u.PRE + (long long)s * ngrp * 56;
     pll_stage_pq<true>(pq, g0, g1 - g0, lane, sm);
     __syncthreads();
     double val = (act && i == k) ? 1.0 : 0.0;
@@ -1523,13 +1591,13 @@ __global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes,
       __syncthreads();
       val = acc;
     }
-    if (act) st_agent(&PQ2[(((long long)s * ngrp2 + set) * 7 + i) * 8 + k], val);
+    if (act) st_agent(&u.PQ2[(((long long)s * ngrp2 + set) * 7 + i) * 8 + k], val);
   }
   // ---- level 3: the last set walks the level-2 maps (lane i = component i)
-  if (!pll_last_arrival(&sync[s].tick_up, (unsigned int)ngrp2)) return;
+  if (!pll_last_arrival(&u.sync[s].tick_up, (unsigned int)ngrp2)) return;
   {
-    const double *pq2 = PQ2 + (long long)s * ngrp2 * 56;
-    double *ds = dstart2 + (long long)s * ngrp2 * 7;
+    const double *pq2 = u.PQ2 + (long long)s * ngrp2 * 56;
+    double *ds = u.dstart2 + (long long)s * ngrp2 * 7;
     const bool a7 = lane < 7;
     const int l7 = a7 ? lane : 0;
     double d = 0.0;
@@ -1537,20 +1605,20 @@ __global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes,
     constexpr int NLQ = (FMR_NODE_GRP2 * 56 + 63) / 64;
     double nxt[NLQ];
     auto fetch = [&](int q0) {
-      const int n = min(FMR_NODE_GRP2, ngrp2 - q0);
+      const int nq = min(FMR_NODE_GRP2, ngrp2 - q0);
       const double *pb = pq2 + (long long)q0 * 56;
 #pragma unroll
-      for (int u = 0; u < NLQ; u++) { const int idx = lane + 64 * u; nxt[u] = (idx < n * 56) ? ld_agent(pb + idx) : 0.0; }
+      for (int v = 0; v < NLQ; v++) { const int idx = lane + 64 * v; nxt[v] = (idx < nq * 56) ? ld_agent(pb + idx) : 0.0; }
     };
     fetch(0);
     for (int q0 = 0; q0 < ngrp2; q0 += FMR_NODE_GRP2) {
-      const int n = min(FMR_NODE_GRP2, ngrp2 - q0);
+      const int nq = min(FMR_NODE_GRP2, ngrp2 - q0);
       __syncthreads();
 #pragma unroll
-      for (int u = 0; u < NLQ; u++) { const int idx = lane + 64 * u; if (idx < FMR_NODE_GRP2 * 56) sm[idx] = nxt[u]; }
+      for (int v = 0; v < NLQ; v++) { const int idx = lane + 64 * v; if (idx < FMR_NODE_GRP2 * 56) sm[idx] = nxt[v]; }
       __syncthreads();
       if (q0 + FMR_NODE_GRP2 < ngrp2) fetch(q0 + FMR_NODE_GRP2);
-      for (int t = 0; t < n; t++) {
+      for (int t = 0; t < nq; t++) {
         if (a7) ds[(long long)(q0 + t) * 7 + lane] = d;
         const double *row = sm + (t * 7 + l7) * 8;
         const double d0 = readlane_d(d, 0), d1 = readlane_d(d, 1), d2 = readlane_d(d, 2), d3 = readlane_d(d, 3),
@@ -1564,27 +1632,43 @@ __global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes,
   }
 }
 
-__global__ __launch_bounds__(64) void k_pll_down(double *__restrict__ nodes, const double *__restrict__ G,
-                                                 const double *__restrict__ M, int nck,
-                                                 const double *__restrict__ PRE, const double *__restrict__ dstart2,
-                                                 int ngrp2, const IterFlags *__restrict__ fl, double minfreq,
-                                                 double maxfreq, PllSync *__restrict__ sync) {
-  __shared__ double sm[FMR_NODE_GRP * 49];       // (15.8 KB in all: ten workgroups per CU, see k_pll_up)
-  __shared__ double sr[FMR_NODE_GRP * 7];
-  __shared__ double so[FMR_NODE_GRP * 7];
+__global__ __launch_bounds__(64) void k_pll_up(const double *__restrict__ nodes, const double *__restrict__ G,
+                                               const double *__restrict__ M, int nck, double *PQ,
+                                               double *__restrict__ PRE, double *PQ2, int ngrp2,
+                                               double *__restrict__ dstart2, const IterFlags *__restrict__ fl,
+                                               PllSync *__restrict__ sync, unsigned int *__restrict__ tick2) {
+  // 14.8 KB of LDS in all: ten workgroups per CU, i.e. the ~2500 groups of a 2^27-sample call in ONE round (with the
+  // mismatches in an array of their own it was 16.9 KB, nine per CU, and a tenth of the groups ran behind the others)
+  __shared__ double sm[FMR_NODE_GRP2 * 56];      // phase A: FMR_NODE_GRP * 49 Jacobian entries, then the mismatches (stride 7)
+  __shared__ double sh[64];
+  static_assert(FMR_NODE_GRP2 * 56 >= FMR_NODE_GRP * (49 + 7), "shared staging buffer");
+  double *const sr = sm + FMR_NODE_GRP * 49;
   const int s = blockIdx.y, grp = blockIdx.x, ngrp = gridDim.x;
   if (fl[s].pll_converged) return;
-  const int i = threadIdx.x;
-  const bool act = i < 7;
-  const int ii = act ? i : 0;
-  double *nd = nodes + (long long)s * (nck + 1) * 7;
+  const int lane = threadIdx.x;
+  const double *nd = nodes + (long long)s * (nck + 1) * 7;
   const double *g = G + (long long)s * nck * 9;
   const double *m = M + (long long)s * nck * 49;
+  const int c0 = grp * FMR_NODE_GRP, c1 = min(c0 + FMR_NODE_GRP, nck);
+  pll_stage_group(m, g, nd, c0, c1 - c0, lane, sm, sr, nullptr, 7);
+  __syncthreads();
+  pll_up_from_lds(PllUpArgs{PQ, PRE, PQ2, ngrp, ngrp2, dstart2, sync, tick2}, s, grp, c1 - c0, sm, sh, lane);
+}
+
+// The down-sweep of one group of FMR_NODE_GRP chunks (k_pll_down's body, rounds 1-4): start delta of the group = its prefix
+// composite applied to the set's start delta, then the deltas propagate chunk by chunk; the new start nodes of chunks
+// c0 + 1 .. c0 + n are left in `so` (stride 7) AND stored, the new start node of chunk c0 itself -- which the group before
+// this one stores, from its own propagation: the same number up to rounding -- in first[0..6].  Residual maxima through the
+// 64 x 8 atomicMax slots.  sm / sr / so: FMR_NODE_GRP x 49 / 7 / 7 doubles of LDS.
+__device__ __forceinline__ void pll_down_group(const PllDownArgs &dn, double *nd, const double *g, const double *m, int nck, int s, int grp,
+                                               PllSync *sync, double *sm, double *sr, double *so, double *first, int lane) {
+  const int i = lane;
+  const bool act = i < 7;
+  const int ii = act ? i : 0;
   const double two_pi = 2.0 * 3.14159265358979323846, inv_two_pi = 1.0 / two_pi;
   const int c0 = grp * FMR_NODE_GRP, c1 = min(c0 + FMR_NODE_GRP, nck);
-  // start delta of the group: (P | q) of the groups before it in its set, applied to the set's start delta
-  const double *pre = PRE + (((long long)s * ngrp + grp) * 7 + ii) * 8;
-  const double *d2 = dstart2 + ((long long)s * ngrp2 + grp / FMR_NODE_GRP2) * 7;
+  const double *pre = dn.PRE + (((long long)s * dn.ngrp + grp) * 7 + ii) * 8;
+  const double *d2 = dn.dstart2 + ((long long)s * dn.ngrp2 + grp / FMR_NODE_GRP2) * 7;
   double pr[8], dv[7];
 #pragma unroll
   for (int q = 0; q < 8; q++) pr[q] = pre[q];
@@ -1594,10 +1678,22 @@ __global__ __launch_bounds__(64) void k_pll_down(double *__restrict__ nodes, con
   const double wm = fabs(g[(long long)c0 * 9 + 3]) + fabs(g[(long long)c0 * 9 + 5]);
   double inv_scale = 1.0 / (1e-7 * (wm + 1.0));
   if (i == 0) inv_scale = 1e7; else if (i == 1) inv_scale = 1e9; else if (i == 2) inv_scale = 1e5;
+  // the node this group's first chunk was integrated from: NOT read from `nd` -- the group before this one overwrites it in
+  // this very launch -- but from the copy the last integration pass left (one per wave: only even groups are asked)
+  const double old0 = dn.wave_first[((long long)s * ((nck + 63) / 64) + (grp >> 1)) * 7 + ii];
   pll_stage_group(m, g, nd, c0, c1 - c0, i, sm, sr, so, 7);
   __syncthreads();
   double d = fma(pr[0], dv[0], fma(pr[1], dv[1], pr[7])) + (fma(pr[2], dv[2], pr[3] * dv[3]) +
              fma(pr[4], dv[4], fma(pr[5], dv[5], pr[6] * dv[6])));
+  auto fix = [&](double nv) {
+    if (i == 0) {                             // keep the phase inside (0, 2 pi] like the reference
+      nv -= two_pi * floor(nv * inv_two_pi);
+      if (nv <= 0.0) nv += two_pi;
+    }
+    if (i == 1) nv = fmax(dn.minfreq, fmin(dn.maxfreq, nv));   // the true freq never leaves the clamp range
+    return nv;
+  };
+  if (act) first[i] = (grp == 0) ? old0 : fix(old0 + d);      // (chunk 0 starts from the carried state: fixed)
   double resid = 0.0;
   for (int t = 0; t < c1 - c0; t++) {
     const double *row = sm + t * 49 + ii * 7;
@@ -1607,12 +1703,7 @@ __global__ __launch_bounds__(64) void k_pll_down(double *__restrict__ nodes, con
     const double p1 = fma(row[2], d2v, row[3] * d3);
     const double p2 = fma(row[4], d4, fma(row[5], d5, row[6] * d6));
     d = p0 + (p1 + p2);                       // delta of node c+1
-    double nv = so[t * 7 + ii] + d;
-    if (i == 0) {                             // keep the phase inside (0, 2 pi] like the reference
-      nv -= two_pi * floor(nv * inv_two_pi);
-      if (nv <= 0.0) nv += two_pi;
-    }
-    if (i == 1) nv = fmax(minfreq, fmin(maxfreq, nv));   // the true freq never leaves the clamp range
+    const double nv = fix(so[t * 7 + ii] + d);
     if (act) {
       so[t * 7 + i] = nv;                     // (each lane reads and writes only its own column)
       resid = fmax(resid, fabs(d) * inv_scale);
@@ -1687,9 +1778,9 @@ __global__ __launch_bounds__(64) void k_pll_finish(
   const int s = blockIdx.x;
   const int lane = threadIdx.x;
   if (!fl[s].pll_converged || fl[s].pll_fallback) return;
-  // 8 KB of LDS in all: in the pipelined chain this kernel runs beside the next call's front end, whose workgroup leaves
-  // 11 KB of a CU's LDS free (with 32 KB it waited for the front end to end, and the next PLL pass behind it)
-  constexpr int kFlagBuf = 1024;
+  // 6 KB of LDS in all: in the pipelined chain this kernel runs beside the next call's front end, whose workgroup leaves
+  // 7.5 KB of a CU's LDS free (with 32 KB it waited for the front end to end, and the next PLL pass behind it)
+  constexpr int kFlagBuf = 512;
   __shared__ int sflag[kFlagBuf];
   StreamState &S = st[s];
   int lock_cnt = S.lock_cnt, pilot_periods = S.pilot_periods;

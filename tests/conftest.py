@@ -16,6 +16,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: bring torch's HIP context up before any test loads the A/B partner build of the library
+    (libfmradion_amd_ab.so, the same kernels a second time): torch.cuda initialised AFTER both libraries are loaded has been
+    seen to report "No HIP GPUs are available" on the GPU box (the tests that allocate through torch then fail for a
+    reason that has nothing to do with them)."""
+    if not any("gpu" in it.keywords for it in items):
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 GOLD = os.path.join(HERE, "golden")
 
 
