@@ -251,6 +251,7 @@ struct fmr_chain {
       d_blk_level, d_agc_M,
       d_dc_G, d_dc_start;
   DevBuf<float> d_agc_nodes, d_agc_G;
+  DevBuf<unsigned int> d_agc_tick;      // k_agc_round's last-arrival ticket, one per stream (left at zero by its users)
   DevBuf<double> d_af_nodes, d_af_G, d_af_M, d_af_out;   // AmDecoder audio tail, time-parallel form
   DcCoef am_dk{};
   DevBuf<int> d_ck_wraps, d_blk_wraps;
@@ -301,7 +302,7 @@ struct fmr_chain {
 #endif
     // a tail stage that was never enqueued (an asynchronous last call nobody synchronised) is dropped, not launched: its
     // output mux would write into the caller's audio buffer, which the caller may have freed by now
-    tail_pending = false;
+    tail_pending = false; agc_pending = false; agc_job = nullptr;
     for (hipStream_t st : {stream, side, side2, tail}) if (st) (void)hipStreamSynchronize(st);
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     for (auto &k : trace) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
@@ -315,7 +316,7 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     d_af_nodes.release(); d_af_G.release(); d_af_M.release(); d_af_out.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
@@ -461,7 +462,8 @@ struct fmr_chain {
     const float *disc_gain = nullptr;
     bool agc_on_side{};
     bool agc_deferred{};
-    std::function<int(hipEvent_t)> enqueue_agc{};
+    std::function<int(hipEvent_t, bool)> enqueue_agc{};
+    bool agc_late{};
     bool done = false;                 // the front end found nothing to decode
     hipEvent_t ev_mpx = nullptr;       // recorded where this call's MPX (discriminator output) is complete
     std::function<void()> fe_post{};   // pipelined chain: the front-end stage's end-of-call kernel, when it is still to be launched
@@ -496,6 +498,13 @@ struct fmr_chain {
   static constexpr int kDeBlock = 256;
   TailCtx tail_job{};
   bool tail_pending = false;
+  // Pipelined chain: the IF AGC of call N is enqueued a call late -- on the side stream behind the tables of call N+1,
+  // beside that call's front end -- or by whatever drains the chain (flush_agc).  Enqueued in its own call it sits in
+  // front of the lock logic and the next call's tables on that stream, and two or three Newton rounds of it (a noisy
+  // input, the IF filter's wider band) then hold the next call's PLL back by 0.1 ms.
+  bool agc_pending = false;
+  std::function<int(hipEvent_t, bool)> agc_job{};
+  int flush_agc();
   void tail_channels(const TailCtx &t, hipStream_t st, int ch_base, int nch_l);
   int tail_stage(const TailCtx &t, hipStream_t ts);
   int flush_tail(hipEvent_t gate);
@@ -787,6 +796,7 @@ int fmr_chain::init(const fmr_config *c) {
   max_agc_nc = max_if / C_AGC + 2;
   if (has_dec) {
     if ((rc = d_agc_nodes.alloc((size_t)S * (max_agc_nc + 1)))) return rc;
+    if ((rc = d_agc_tick.alloc((size_t)S))) return rc;
     if ((rc = d_agc_G.alloc((size_t)S * max_agc_nc))) return rc;
     if ((rc = d_agc_M.alloc((size_t)S * max_agc_nc))) return rc;
   }
@@ -1405,8 +1415,10 @@ int fmr_chain::run_tables(CallCtx &k) {
   if (iter_on_side) {
     if (ev_agc_live) HIPCHK(hipStreamWaitEvent(side, ev_agc, 0));
     const int nc = (int)((N_if + C_AGC - 1) / C_AGC);
+    k.agc_late = pipelined;         // (the AGC's own part of the reset goes with the late AGC, run_if_stage)
     hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, side, d_flags.p, d_agc_nodes.p, nc, d_state.p, S,
-                       (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p, pll_tick2_per_stream);
+                       (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p, pll_tick2_per_stream,
+                       k.agc_late ? 1 : 3);
   }
   if (pipelined && ring_prev >= 0 && ring_prev != k.par) {
     // halos of this call's ring slot = the tail of the previous call's slot (its writers -- front end, discriminator, PLL
@@ -1421,10 +1433,9 @@ int fmr_chain::run_tables(CallCtx &k) {
   }
   // the decoder waits for the tables.  In the pipelined chain the front end shares its stream and must not: the wait is
   // enqueued behind the front end's launch (below)
-  if (!pipelined) {
-    HIPCHK(hipEventRecord(ev_tab, side));
-    HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
-  }
+  HIPCHK(hipEventRecord(ev_tab, side));
+  if (!pipelined) HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
+  else if (int rc = flush_agc()) return rc;     // the previous call's IF AGC: behind these tables, beside this front end
   bt = BlockTab{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
               d_tab_slot + 4 * max_blocks, nb};
   if_stride = H_if + (long long)max_if;
@@ -1499,10 +1510,7 @@ int fmr_chain::run_tables(CallCtx &k) {
       if (int rc = flush_tail(ev_fe[k.par])) return rc;
     }
   }
-  if (pipelined) {
-    HIPCHK(hipEventRecord(ev_tab, side));
-    HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
-  }
+  if (pipelined) HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
   return FMR_OK;
 }
 
@@ -1621,8 +1629,12 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     agc_deferred = agc_aside && stereo;
     const float *const nrm_in = (agc_aside && !fir_enable) ? k.nrm : nullptr;     // (non-null: the front end stored |x|^2, not the IF samples)
     const long long nrm_in_stride = k.nrm_stride;
-    enqueue_agc = [=](hipEvent_t gate) -> int {
-    if (agc_aside) {
+    const bool agc_late = k.agc_late && agc_aside;
+    enqueue_agc = [=](hipEvent_t gate, bool in_order) -> int {
+    if (in_order) {          // (late: everything it reads is ordered before this point of its stream already)
+      hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, as, d_flags.p, d_agc_nodes.p, agc_nc, d_state.p, S,
+                         (unsigned long long *)nullptr, 0, (unsigned int *)nullptr, 0, 2);
+    } else if (agc_aside) {
       if (gate) {
         HIPCHK(hipStreamWaitEvent(side2, gate, 0));
       } else {
@@ -1630,22 +1642,24 @@ int fmr_chain::run_if_stage(CallCtx &k) {
         HIPCHK(hipStreamWaitEvent(side2, ev_if, 0));
       }
     }
-    const int agc_nw = std::max(1, std::min(16, (agc_nc + 64 * FMR_AGC_PER_LANE - 1) / (64 * FMR_AGC_PER_LANE)));
     // FM without the equaliser: the discriminator does not see the gains (atan2 is invariant to them) -- the recurrence is
     // solved for its state only, and its 4 bytes per IF sample stay out of HBM unless the debug tap asks for them
     float *const gain_out = (agc_aside && !debug_taps) ? (float *)nullptr : d_gain.p;
     timed_on(as, "if_agc", [&] {
+      const int ginv = (mode == FMR_MODE_FM || mode == FMR_MODE_NBFM) ? (gain_out ? 1 : 2) : 0;
+      // (four waves, one per SIMD: a workgroup of sixteen finds no compute unit with room for all of them while the PLL's
+      // first pass -- one 260-register wave per SIMD, 1258 workgroups queueing -- holds the chip)
+      constexpr int kAgcWg = 256;
+      const dim3 rgrid((agc_nc + kAgcWg - 1) / kAgcWg, S);
       for (int it = 0; it < agc_iters; it++) {
         if (nrm_in)
-          hipLaunchKernelGGL((k_agc_shoot<C_AGC, float>), dim3((agc_nc + 63) / 64, S), dim3(64), 0, as, nrm_in, nrm_in_stride, 0,
-                             (int)N_if, gain_out, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
-                             agc_init, agc_max, agc_rate, d_flags.p);
+          hipLaunchKernelGGL((k_agc_round<C_AGC, float>), rgrid, dim3(kAgcWg), 0, as, nrm_in, nrm_in_stride, 0, (int)N_if,
+                             gain_out, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc, agc_init, agc_max,
+                             agc_rate, d_state.p, d_flags.p, ginv, d_agc_tick.p);
         else
-        hipLaunchKernelGGL((k_agc_shoot<C_AGC, float2>), dim3((agc_nc + 63) / 64, S), dim3(64), 0, as, xin, x_stride, x_off,
-                           (int)N_if, gain_out, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
-                           agc_init, agc_max, agc_rate, d_flags.p);
-        hipLaunchKernelGGL(k_agc_nodes, dim3(S), dim3(64 * agc_nw), 0, as, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc,
-                           d_state.p, d_flags.p, (mode == FMR_MODE_FM || mode == FMR_MODE_NBFM) ? (gain_out ? 1 : 2) : 0);
+          hipLaunchKernelGGL((k_agc_round<C_AGC, float2>), rgrid, dim3(kAgcWg), 0, as, xin, x_stride, x_off, (int)N_if,
+                             gain_out, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc, agc_init, agc_max,
+                             agc_rate, d_state.p, d_flags.p, ginv, d_agc_tick.p);
       }
       if (nrm_in)
         hipLaunchKernelGGL(k_if_agc_fallback<float>, dim3((S + 63) / 64), dim3(64), 0, as, nrm_in, nrm_in_stride, 0, (int)N_if,
@@ -1659,7 +1673,8 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     };
     if (agc_aside) { disc_gain = nullptr; agc_on_side = true; }
     gain_valid = !(agc_aside && !debug_taps);
-    if (!agc_deferred) { if (int rca = enqueue_agc(nullptr)) return rca; }
+    if (agc_late) { agc_deferred = false; agc_job = enqueue_agc; agc_pending = true; }
+    else if (!agc_deferred) { if (int rca = enqueue_agc(nullptr, false)) return rca; }
   }
   return FMR_OK;
 }
@@ -1725,7 +1740,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
             (void)hipEventRecord(ev_mono, side2);
             mono_enqueued = true;
           };
-          if ((rc_agc = enqueue_agc(gate))) return;
+          if ((rc_agc = enqueue_agc(gate, false))) return;
           if (split_mono) mono_aside();
         }
 #ifdef FMR_AB_PARTNERS
@@ -1777,7 +1792,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
     });
     // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
     // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
-    if (agc_on_side && !agc_deferred) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
+    if (agc_on_side && !agc_deferred && !k.agc_late) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
     HIPCHK(hipEventRecord(ev_fin, side));
     fin_on_side = true;
   }
@@ -1878,7 +1893,7 @@ int fmr_chain::run_fm(CallCtx &k) {
     auto tail_fn = [&](hipStream_t st, int ch_base, int nch_l) { tail_channels(t, st, ch_base, nch_l); };
     if (int rcp = run_fm_pll(k, base_stride_, split_mono, tail_fn, mono_enqueued, fin_on_side, fin_covers_all)) return rcp;
   }
-  if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr)) return rca; }   // PLL path not taken
+  if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr, false)) return rca; }   // PLL path not taken
   if (k.fe_post) { k.fe_post(); k.fe_post = nullptr; }
   t.fin_on_side = fin_on_side; t.fin_covers_all = fin_covers_all; t.agc_on_side = agc_on_side; t.mono_enqueued = mono_enqueued;
 
@@ -2026,7 +2041,16 @@ int fmr_chain::tail_stage(const TailCtx &t, hipStream_t ts) {
 
 // Pipelined chain: enqueue the tail stage of the last decoded call on the tail stream, behind `gate` (the front end of
 // the call that follows it; null: nothing to wait for but the call's own PLL stage).
+int fmr_chain::flush_agc() {
+  if (!agc_pending) return FMR_OK;
+  agc_pending = false;
+  const int rc = agc_job(nullptr, true);
+  agc_job = nullptr;
+  return rc;
+}
 int fmr_chain::flush_tail(hipEvent_t gate) {
+  const int rc_agc = flush_agc();       // (the tail waits for its call's AGC: enqueued first, or the wait finds an older record)
+  if (rc_agc != FMR_OK && !tail_pending) return rc_agc;
   if (!tail_pending) return FMR_OK;
   tail_pending = false;
   const int rc = enqueue_tail(gate);

@@ -2157,11 +2157,19 @@ __global__ __launch_bounds__(FMR_STATS_THREADS) void k_stats(BlockTab bt, const 
       if (my_n) {
         const int lo = bt.if_off[b], hi = lo + my_n - 1, ng = 3 * n_tiles;
         const int g0 = (lo - kb_ref) / 128, g1 = min((hi - kb_ref) / 128, ng - 1);   // thirds that hold samples of the block
-        for (int g = g0; g <= g1; g++) {
-          const FusedPart pt = part[(long long)s * ng + g];
+        // (eight entries in flight per lane: a block spans ~20 thirds, and one at a time that was 20 memory round trips
+        // in a row -- 0.13 ms on average beside the PLL's first pass.  Summed in the same index order.)
+        for (int g = g0; g <= g1; g += 8) {
+          FusedPart pt[8];
 #pragma unroll
-          for (int h = 0; h < 2; h++)
-            if (pt.blk[h] == b) { sd += pt.sum[h][0]; sq += pt.sum[h][1]; se += pt.sum[h][2]; }
+          for (int u = 0; u < 8; u++) pt[u] = part[(long long)s * ng + min(g + u, g1)];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            if (g + u > g1) break;
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+              if (pt[u].blk[h] == b) { sd += pt[u].sum[h][0]; sq += pt[u].sum[h][1]; se += pt[u].sum[h][2]; }
+          }
         }
       }
       const float fn = (float)(unsigned)(my_n ? my_n : 1);

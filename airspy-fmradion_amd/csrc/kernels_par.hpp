@@ -397,70 +397,55 @@ __global__ void k_dc_pass2_mux(const double *__restrict__ p0, const double *__re
 // squared magnitude, 1e-11 of the gain's factor z -- far inside the dead zone the reference's own gain wanders in.
 __device__ __forceinline__ float agc_nrm(float2 v, float g) { const float xr = v.x * g, xi = v.y * g; return xr * xr + xi * xi; }
 __device__ __forceinline__ float agc_nrm(float e, float g) { return (g * g) * e; }
-template <int C, class XT>
-__global__ void k_agc_shoot(const XT *__restrict__ x, long long x_stride, int x_off, int n,
-                            float *__restrict__ gain, long long g_stride, const float *__restrict__ nodes,
-                            float *__restrict__ G, double *__restrict__ M, int nc, float initial_gain, float max_gain,
-                            float rate, const IterFlags *__restrict__ fl) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const int s = blockIdx.y;
-  if (c >= nc || fl[s].agc_converged) return;
-  const XT *xs = x + (long long)s * x_stride + x_off;
-  float *gs = gain ? gain + (long long)s * g_stride : nullptr;   // null: nobody reads the per-sample gains (FM without the
-  const int i0 = c * C, i1 = min(i0 + C, n);                      // equaliser: atan2 does not see them) -- only the state carries
-  float g = nodes[(long long)s * (nc + 1) + c];
-  double dg = 1.0;
-  const double r = (double)rate;
-  serial_prefetch<8>(xs, i0, i1, [&](int i, XT v) {
-    if (gs) gs[i] = g;
-    const float nrm = agc_nrm(v, g);
-    const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
-    const float gn = g * z;
-    // d(g z)/dg = z + g dz/dg = z - 2 r nrm   (nrm ~ g^2)
-    dg *= ((double)z - 2.0 * r * (double)nrm);
-    g = gn;
-    if (!isfinite(g)) { g = initial_gain; dg = 0.0; }
-    else if (g > max_gain) { g = max_gain; dg = 0.0; }
-  });
-  G[(long long)s * nc + c] = g;
-  M[(long long)s * nc + c] = dg;
-}
-
 // node pass: v[c+1] = G[c] + M[c] (v[c] - old[c]); affine scan: every lane composes 8
 // consecutive chunk maps serially, one wave scan covers 512 chunks, then every lane
 // replays its 8 maps from its scanned start value.
 #define FMR_AGC_PER_LANE 8
-__global__ __launch_bounds__(1024) void k_agc_nodes(float *__restrict__ nodes, const float *__restrict__ G,
-                                                    const double *__restrict__ M, int nc, StreamState *st,
-                                                    IterFlags *fl, int gain_invariant) {
+// (G and M are read with agent-scope loads: in k_agc_round they were stored by other workgroups of the same launch)
+__device__ __forceinline__ void agc_node_pass(const int s, float *__restrict__ nodes, const float *G, const double *M,
+                                              int nc, StreamState *st, IterFlags *fl, int gain_invariant) {
   // blockDim.x = 64 * NW: the NW waves take consecutive 64*K-chunk segments of a pass, scan their maps with an
   // identity carry in parallel, chain the NW segment maps and replay with the true carries (as k_dc_nodes).
   __shared__ double segA[16], segB[16];
   __shared__ double pass_end;
   __shared__ float wmax[16];
-  const int s = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
-  if (fl[s].agc_converged) return;
   float *nd = nodes + (long long)s * (nc + 1);
   const float *g = G + (long long)s * nc;
   const double *m = M + (long long)s * nc;
   constexpr int K = FMR_AGC_PER_LANE;
   double carry = (double)nd[0];   // v[0] is the carried state, fixed
   float maxrel = 0.f;
-  for (int c0 = 0; c0 < nc; c0 += 64 * K * NW) {
+  __shared__ float old_next;      // the node a tile's last lane overwrites is the OLD start of the next tile's first chunk
+  // the next tile's maps are fetched while this tile is scanned (the pass was ten memory round trips in a row)
+  double a_n[K];
+  float g_n[K], o_n[K + 1];
+  auto fetch = [&](int c0) {
     const int cb = c0 + (wv * 64 + lane) * K;
-    double a[K], b[K];
-    float oldn[K];
-    // maps of this lane: v' = a v + b with b = G - a*old (old read before any write of this tile)
 #pragma unroll
     for (int j = 0; j < K; j++) {
       const int c = cb + j;
       if (c < nc) {
-        a[j] = m[c];
-        b[j] = (double)g[c] - a[j] * (double)nd[c];
-        oldn[j] = nd[c + 1];
-      } else { a[j] = 1.0; b[j] = 0.0; oldn[j] = 0.f; }
+        a_n[j] = __longlong_as_double(__hip_atomic_load((const long long *)&m[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        g_n[j] = __hip_atomic_load(&g[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else { a_n[j] = 1.0; g_n[j] = 0.f; }
     }
+#pragma unroll
+    for (int j = 0; j <= K; j++) o_n[j] = nd[min(cb + j, nc)];
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < nc; c0 += 64 * K * NW) {
+    const int cb = c0 + (wv * 64 + lane) * K;
+    double a[K], b[K];
+    float oldn[K];
+    // maps of this lane: v' = a v + b with b = G - a*old
+    if (c0 > 0 && threadIdx.x == 0) o_n[0] = old_next;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      if (cb + j < nc) { a[j] = a_n[j]; b[j] = (double)g_n[j] - a[j] * (double)o_n[j]; oldn[j] = o_n[j + 1]; }
+      else { a[j] = 1.0; b[j] = 0.0; oldn[j] = 0.f; }
+    }
+    if (c0 + 64 * K * NW < nc) fetch(c0 + 64 * K * NW);
     double ca = 1.0, cbv = 0.0;               // composition of the lane's K maps
 #pragma unroll
     for (int j = 0; j < K; j++) { cbv = a[j] * cbv + b[j]; ca = a[j] * ca; }
@@ -489,7 +474,7 @@ __global__ __launch_bounds__(1024) void k_agc_nodes(float *__restrict__ nodes, c
         maxrel = fmaxf(maxrel, fabsf(vf - oldn[j]) / fmaxf(fabsf(vf), 1e-30f));
       }
     }
-    if (wv == NW - 1 && lane == 63) pass_end = (double)(float)(sa * cw + sb);
+    if (wv == NW - 1 && lane == 63) { pass_end = (double)(float)(sa * cw + sb); old_next = oldn[K - 1]; }
     __syncthreads();
     carry = pass_end;
     __syncthreads();
@@ -528,24 +513,86 @@ __global__ __launch_bounds__(1024) void k_agc_nodes(float *__restrict__ nodes, c
     }
   }
 }
+// One Newton round in one launch: the integration pass, a chunk per lane; the workgroup of a stream that finishes last runs
+// the node pass (last-arrival ticket, as the PLL's rounds: nobody waits for anybody).  Launched with FOUR waves per
+// workgroup: the node pass of the two-launch form was one workgroup of sixteen, which finds no compute unit with room for
+// all its waves while the PLL's first pass holds the chip (0.1 ms of waiting per round, measured: 1024 threads 0.125 ms per
+// round, 256 threads 0.087, 64 threads -- a one-wave node pass -- 0.166).
+template <int C, class XT>
+__global__ __launch_bounds__(1024) void k_agc_round(const XT *__restrict__ x, long long x_stride, int x_off, int n,
+                                                    float *__restrict__ gain, long long g_stride, float *__restrict__ nodes,
+                                                    float *G, double *M, int nc, float initial_gain, float max_gain,
+                                                    float rate, StreamState *st, IterFlags *fl, int gain_invariant,
+                                                    unsigned int *__restrict__ ticket) {
+  __shared__ int s_last;
+  const int s = blockIdx.y;
+  // (stable for the whole launch: the node pass that sets it runs after every workgroup of the stream has passed here)
+  if (fl[s].agc_converged) return;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nc) {
+    const XT *xs = x + (long long)s * x_stride + x_off;
+    float *gs = gain ? gain + (long long)s * g_stride : nullptr;
+    const int i0 = c * C, i1 = min(i0 + C, n);
+    float g = nodes[(long long)s * (nc + 1) + c];
+    double dg = 1.0;
+    const double r = (double)rate;
+    serial_prefetch<8>(xs, i0, i1, [&](int i, XT v) {
+      if (gs) gs[i] = g;
+      const float nrm = agc_nrm(v, g);
+      const float z = (float)(1.0 + (r * (1.0 - (double)nrm)));
+      const float gn = g * z;
+      // d(g z)/dg = z + g dz/dg = z - 2 r nrm   (nrm ~ g^2)
+      dg *= ((double)z - 2.0 * r * (double)nrm);
+      g = gn;
+      if (!isfinite(g)) { g = initial_gain; dg = 0.0; }
+      else if (g > max_gain) { g = max_gain; dg = 0.0; }
+    });
+    __hip_atomic_store(&G[(long long)s * nc + c], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((long long *)&M[(long long)s * nc + c], __double_as_longlong(dg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this wave's stores are acknowledged by the L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(&ticket[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1);
+    if (s_last) __hip_atomic_store(&ticket[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  agc_node_pass(s, nodes, G, M, nc, st, fl, gain_invariant);
+}
 
 __global__ void k_iter_begin(IterFlags *fl, float *__restrict__ agc_nodes, int agc_nc, const StreamState *st,
                              int n_streams, unsigned long long *__restrict__ pll_sync, int sync_words,
-                             unsigned int *__restrict__ pll_tick2, int n_tick2) {
+                             unsigned int *__restrict__ pll_tick2, int n_tick2, int part = 3) {
+  // part: 1 = what the PLL rounds (and the audio AGC) read, 2 = what the IF AGC's rounds read, 3 = both.  The pipelined
+  // chain resets the two apart: its IF AGC of call N is enqueued a call late, behind the tables of call N+1.
   const int s = blockIdx.x;
   if (s >= n_streams) return;
   if (threadIdx.x == 0) {
-    fl[s] = IterFlags{};
-    if (agc_nodes) agc_nodes[(long long)s * (agc_nc + 1)] = st[s].agc_gain;
+    if (part == 3) fl[s] = IterFlags{};
+    else if (part == 1) {
+      IterFlags z{};
+      const IterFlags &o = fl[s];
+      z.agc_converged = o.agc_converged; z.agc_iters = o.agc_iters; z.agc_fallback = o.agc_fallback;
+      z.agc_resid = o.agc_resid;
+      for (int i = 0; i < 16; i++) z.agc_hist[i] = o.agc_hist[i];
+      fl[s] = z;
+    } else {
+      IterFlags &o = fl[s];
+      o.agc_converged = 0; o.agc_iters = 0; o.agc_fallback = 0; o.agc_resid = 0.f;
+      for (int i = 0; i < 16; i++) o.agc_hist[i] = 0.f;
+    }
+    if (agc_nodes && (part & 2)) agc_nodes[(long long)s * (agc_nc + 1)] = st[s].agc_gain;
   }
   // the PLL rounds' tickets and maximum slots (PllSync) are left at zero by the kernels that use them; a call that
   // starts from anything else (an aborted call before it) would mistake its last arrivals, so they are zeroed anyway
-  if (pll_sync) {
+  if (pll_sync && (part & 1)) {
     for (int i = threadIdx.x; i < sync_words; i += blockDim.x) pll_sync[(long long)s * sync_words + i] = 0ull;
     for (int i = threadIdx.x; i < n_tick2; i += blockDim.x) pll_tick2[(long long)s * n_tick2 + i] = 0u;
   }
   // initial guess: the carried gain everywhere
-  if (agc_nodes) {
+  if (agc_nodes && (part & 2)) {
     const float g0 = st[s].agc_gain;
     for (int c = 1 + threadIdx.x; c <= agc_nc; c += blockDim.x) agc_nodes[(long long)s * (agc_nc + 1) + c] = g0;
   }

@@ -27,13 +27,14 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--r8b", action="store_true", help="the R8B resampler class (three-kernel front end, fp16 stage B)")
     ap.add_argument("--if-filter", action="store_true", help="the IF filter (-f medium) behind the fused front end")
+    ap.add_argument("--sigma", type=float, default=1e-3, help="noise per I / Q component (bench.py --sigma)")
     args = ap.parse_args()
     import torch
     fmr = importlib.import_module("airspy-fmradion_amd")
     dev = torch.device("cuda", 0)
     B, blk = args.blocks, bench.BLK
     n = B * blk
-    iq = torch.stack([bench.synth_fm_stereo_torch(n, bench.FS, 0, dev)])
+    iq = torch.stack([bench.synth_fm_stereo_torch(n, bench.FS, 0, dev, sigma=args.sigma)])
     audio = torch.zeros((1, 2 * (int(n * 0.0048) + 64)), dtype=torch.float64, device=dev)
     kw = {}
     if args.r8b:
