@@ -186,6 +186,7 @@ struct fmr_chain {
     return FMR_OK;
   }
   hipStream_t side = nullptr, side2 = nullptr;   // side2: the IF AGC when it is off the critical path
+  hipEvent_t ev_pll1 = nullptr;      // pipelined chain: the PLL's second pass is done (the passes after it may run on the side stream)
   hipEvent_t ev_disc = nullptr, ev_pll = nullptr, ev_stats = nullptr, ev_fin = nullptr, ev_if = nullptr, ev_agc = nullptr,
              ev_tab = nullptr, ev_mono = nullptr;
   int pll_tick2_per_stream = 0;
@@ -266,6 +267,15 @@ struct fmr_chain {
 #ifndef FMR_FE_SPARE_CUS
 #define FMR_FE_SPARE_CUS 8
 #endif
+  // Pipelined chain with many short streams: the front end takes whole workgroups per stream and leaves more than its 8
+  // spare compute units (32 streams: 7 x 32 = 224 of 256).  The small kernels beside it then ask for 8 KB of LDS they never
+  // touch: a front-end workgroup leaves 7.7 KB of its unit's LDS free, so they can only go to the units it leaves alone
+  // instead of sharing one with eight front-end waves (config5: 0.523 -> 0.502 ms per step, the front end 0.273 -> 0.252).
+  // With only the 8 spare units (one long stream) the same ballast costs 4% -- the side stream's kernels queue on them.
+  static constexpr int kBallastBytes = 8192, kBallastMinSpare = 24;
+  static constexpr int kSpareAsideMaxBlocks = 512;   // (run_fm_pll)
+  int fe_spare_cus = 0;           // compute units the last front-end launch left alone
+  size_t side_ballast() const { return (pipelined && fe_spare_cus >= kBallastMinSpare) ? (size_t)kBallastBytes : 0; }
   static constexpr int kFeSpareCus = FMR_FE_SPARE_CUS;      // CUs the pipelined chain's front end leaves to the kernels beside it
   int *h_tab_all = nullptr;  // pinned, kTabSlots * tab_ints
   size_t tab_ints = 0;       // 5*max_blocks block table + 3*max_ck chunk table + (max_blocks+1) first-chunk table
@@ -302,7 +312,7 @@ struct fmr_chain {
 #endif
     // a tail stage that was never enqueued (an asynchronous last call nobody synchronised) is dropped, not launched: its
     // output mux would write into the caller's audio buffer, which the caller may have freed by now
-    tail_pending = false; agc_pending = false; agc_job = nullptr;
+    tail_pending = false;
     for (hipStream_t st : {stream, side, side2, tail}) if (st) (void)hipStreamSynchronize(st);
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     for (auto &k : trace) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
@@ -336,6 +346,7 @@ struct fmr_chain {
     for (auto &b : d_part_pp) b.release();
     for (auto &b : d_stereo_pp) b.release();
     if (ev_agc) (void)hipEventDestroy(ev_agc);
+    if (ev_pll1) (void)hipEventDestroy(ev_pll1);
     if (ev_tab) (void)hipEventDestroy(ev_tab);
     if (ev_mono) (void)hipEventDestroy(ev_mono);
     if (stream) (void)hipStreamDestroy(stream);
@@ -462,8 +473,7 @@ struct fmr_chain {
     const float *disc_gain = nullptr;
     bool agc_on_side{};
     bool agc_deferred{};
-    std::function<int(hipEvent_t, bool)> enqueue_agc{};
-    bool agc_late{};
+    std::function<int(hipEvent_t)> enqueue_agc{};
     bool done = false;                 // the front end found nothing to decode
     hipEvent_t ev_mpx = nullptr;       // recorded where this call's MPX (discriminator output) is complete
     std::function<void()> fe_post{};   // pipelined chain: the front-end stage's end-of-call kernel, when it is still to be launched
@@ -498,13 +508,6 @@ struct fmr_chain {
   static constexpr int kDeBlock = 256;
   TailCtx tail_job{};
   bool tail_pending = false;
-  // Pipelined chain: the IF AGC of call N is enqueued a call late -- on the side stream behind the tables of call N+1,
-  // beside that call's front end -- or by whatever drains the chain (flush_agc).  Enqueued in its own call it sits in
-  // front of the lock logic and the next call's tables on that stream, and two or three Newton rounds of it (a noisy
-  // input, the IF filter's wider band) then hold the next call's PLL back by 0.1 ms.
-  bool agc_pending = false;
-  std::function<int(hipEvent_t, bool)> agc_job{};
-  int flush_agc();
   void tail_channels(const TailCtx &t, hipStream_t st, int ch_base, int nch_l);
   int tail_stage(const TailCtx &t, hipStream_t ts);
   int flush_tail(hipEvent_t gate);
@@ -567,6 +570,7 @@ int fmr_chain::init(const fmr_config *c) {
     HIPCHK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
   }
   HIPCHK(hipEventCreateWithFlags(&ev_agc, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ev_pll1, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ev_tab, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ev_mono, hipEventDisableTiming));
   for (hipEvent_t *e : {&ev_disc, &ev_pll, &ev_stats, &ev_fin, &ev_if}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -1109,6 +1113,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
   long long count_mid_call = 0;
   N_if = 0;
   use_fused = false;
+  fe_spare_cus = 0;
   k.fused_disc = false;
   fused_geom = FusedGeom{};
   hipStream_t fes = stream;      // (pipelined chain too: the front end alternates with the PLL stage on the decoder stream)
@@ -1376,6 +1381,7 @@ int fmr_chain::run_tables(CallCtx &k) {
     const int wg_per_stream = std::max(1, std::min(kMaxFusedWg, fe_cus / S));
     fused_tiles_per_wg = (fused_n_tiles + wg_per_stream - 1) / wg_per_stream;
     fused_grid = (fused_n_tiles + fused_tiles_per_wg - 1) / fused_tiles_per_wg;
+    fe_spare_cus = std::max(0, n_cu - fused_grid * S);
     int *t_wg = h_tab + (tab_ints - kMaxFusedWg);
     const long long kb_ref = 384 * fused_T_first - fused_geom.kB_prev;
     int b = 0;
@@ -1415,10 +1421,8 @@ int fmr_chain::run_tables(CallCtx &k) {
   if (iter_on_side) {
     if (ev_agc_live) HIPCHK(hipStreamWaitEvent(side, ev_agc, 0));
     const int nc = (int)((N_if + C_AGC - 1) / C_AGC);
-    k.agc_late = pipelined;         // (the AGC's own part of the reset goes with the late AGC, run_if_stage)
     hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, side, d_flags.p, d_agc_nodes.p, nc, d_state.p, S,
-                       (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p, pll_tick2_per_stream,
-                       k.agc_late ? 1 : 3);
+                       (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p, pll_tick2_per_stream);
   }
   if (pipelined && ring_prev >= 0 && ring_prev != k.par) {
     // halos of this call's ring slot = the tail of the previous call's slot (its writers -- front end, discriminator, PLL
@@ -1435,7 +1439,6 @@ int fmr_chain::run_tables(CallCtx &k) {
   // enqueued behind the front end's launch (below)
   HIPCHK(hipEventRecord(ev_tab, side));
   if (!pipelined) HIPCHK(hipStreamWaitEvent(stream, ev_tab, 0));
-  else if (int rc = flush_agc()) return rc;     // the previous call's IF AGC: behind these tables, beside this front end
   bt = BlockTab{d_tab_slot, d_tab_slot + max_blocks, d_tab_slot + 2 * max_blocks, d_tab_slot + 3 * max_blocks,
               d_tab_slot + 4 * max_blocks, nb};
   if_stride = H_if + (long long)max_if;
@@ -1629,12 +1632,8 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     agc_deferred = agc_aside && stereo;
     const float *const nrm_in = (agc_aside && !fir_enable) ? k.nrm : nullptr;     // (non-null: the front end stored |x|^2, not the IF samples)
     const long long nrm_in_stride = k.nrm_stride;
-    const bool agc_late = k.agc_late && agc_aside;
-    enqueue_agc = [=](hipEvent_t gate, bool in_order) -> int {
-    if (in_order) {          // (late: everything it reads is ordered before this point of its stream already)
-      hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, as, d_flags.p, d_agc_nodes.p, agc_nc, d_state.p, S,
-                         (unsigned long long *)nullptr, 0, (unsigned int *)nullptr, 0, 2);
-    } else if (agc_aside) {
+    enqueue_agc = [=](hipEvent_t gate) -> int {
+    if (agc_aside) {
       if (gate) {
         HIPCHK(hipStreamWaitEvent(side2, gate, 0));
       } else {
@@ -1650,14 +1649,15 @@ int fmr_chain::run_if_stage(CallCtx &k) {
       // (four waves, one per SIMD: a workgroup of sixteen finds no compute unit with room for all of them while the PLL's
       // first pass -- one 260-register wave per SIMD, 1258 workgroups queueing -- holds the chip)
       constexpr int kAgcWg = 256;
+      const size_t agc_ballast = agc_aside ? side_ballast() : 0;
       const dim3 rgrid((agc_nc + kAgcWg - 1) / kAgcWg, S);
       for (int it = 0; it < agc_iters; it++) {
         if (nrm_in)
-          hipLaunchKernelGGL((k_agc_round<C_AGC, float>), rgrid, dim3(kAgcWg), 0, as, nrm_in, nrm_in_stride, 0, (int)N_if,
+          hipLaunchKernelGGL((k_agc_round<C_AGC, float>), rgrid, dim3(kAgcWg), agc_ballast, as, nrm_in, nrm_in_stride, 0, (int)N_if,
                              gain_out, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc, agc_init, agc_max,
                              agc_rate, d_state.p, d_flags.p, ginv, d_agc_tick.p);
         else
-          hipLaunchKernelGGL((k_agc_round<C_AGC, float2>), rgrid, dim3(kAgcWg), 0, as, xin, x_stride, x_off, (int)N_if,
+          hipLaunchKernelGGL((k_agc_round<C_AGC, float2>), rgrid, dim3(kAgcWg), agc_ballast, as, xin, x_stride, x_off, (int)N_if,
                              gain_out, (long long)max_if, d_agc_nodes.p, d_agc_G.p, d_agc_M.p, agc_nc, agc_init, agc_max,
                              agc_rate, d_state.p, d_flags.p, ginv, d_agc_tick.p);
       }
@@ -1673,8 +1673,7 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     };
     if (agc_aside) { disc_gain = nullptr; agc_on_side = true; }
     gain_valid = !(agc_aside && !debug_taps);
-    if (agc_late) { agc_deferred = false; agc_job = enqueue_agc; agc_pending = true; }
-    else if (!agc_deferred) { if (int rca = enqueue_agc(nullptr, false)) return rca; }
+    if (!agc_deferred) { if (int rca = enqueue_agc(nullptr)) return rca; }
   }
   return FMR_OK;
 }
@@ -1693,6 +1692,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
   } else {
     // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
     int rc_agc = FMR_OK;          // a failure inside the lambda must leave run_fm_pll, not only the lambda
+    bool spare_moved = false;     // the passes after the second went to the side stream
     // (trace mode: every kernel of the group carries its own event pair)
     auto sub = [&](hipStream_t st, const char *name, auto &&launch) { if (timing == 3) timed_on(st, name, launch); else launch(); };
     timed("pll", [&] {
@@ -1700,7 +1700,17 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
       const int ngrp2 = (ngrp + FMR_NODE_GRP2 - 1) / FMR_NODE_GRP2;
       const int pll_iters = (N_if <= kSmallCall) ? 3 : K_PLL_ITERS;       // (short calls: see the AGC above)
       hipStream_t ps = stream;
+      // Pipelined chain, streams of few blocks: the passes after the second -- which a call in lock does not need, and which
+      // then cost five launches of workgroups that read a flag and leave, ~25 us between this call's accepted pass and the
+      // next call's front end on this stream -- go to the side stream, in front of the lock logic that waits for them anyway
+      // (32 streams x 64 blocks: 0.503 -> 0.478 ms per step).  When they are needed (rounds 3+, the serial fallback) they
+      // run beside the next front end; nothing of that call reads what they write before its tables, which are behind the
+      // lock logic on the same stream.  Not with one long stream: there the side stream -- lock logic over 2048 blocks in
+      // one wave, the AGC's rounds -- is as long as the step already, and five more launches on it hold the next call's
+      // tables back (0.517 -> 0.539).
+      const bool spare_aside = pipelined && !env.pll_v1 && nb <= kSpareAsideMaxBlocks;
       for (int it = 0; it < pll_iters; it++) {
+        if (spare_aside && it == 2 && !spare_moved) { (void)hipEventRecord(ev_pll1, stream); (void)hipStreamWaitEvent(side, ev_pll1, 0); spare_moved = true; ps = side; }
         // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
         // contraction 5e-4 per round in lock, so the round count is the same as with fresh Jacobians)
         PllSync *const sy = env.pll_v1 ? nullptr : d_pll_sync.p;      // null: seven-kernel round (k_pll_check etc.)
@@ -1740,7 +1750,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
             (void)hipEventRecord(ev_mono, side2);
             mono_enqueued = true;
           };
-          if ((rc_agc = enqueue_agc(gate, false))) return;
+          if ((rc_agc = enqueue_agc(gate))) return;
           if (split_mono) mono_aside();
         }
 #ifdef FMR_AB_PARTNERS
@@ -1750,12 +1760,14 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
 #endif
         if (it == pll_iters - 1) break;        // nothing integrates the nodes a last update would give
         if (!env.pll_v1) {
-          if (!up_in_shoot)
+          if (!up_in_shoot) {
+          if (spare_aside && it == 1) { (void)hipEventRecord(ev_pll1, stream); (void)hipStreamWaitEvent(side, ev_pll1, 0); spare_moved = true; ps = side; }
           sub(ps, "pll_up", [&] {
           hipLaunchKernelGGL(k_pll_up, dim3(ngrp, S), dim3(64), 0, ps, d_pll_nodes.p, d_pll_G.p, d_pll_M.p, nck,
                              d_pll_PQ.p, d_pll_pre.p, d_pll_PQ2.p, ngrp2, d_pll_dstart2.p, d_flags.p, d_pll_sync.p,
                              d_pll_tick2.p);
           });
+          }
           continue;
         }
 #ifdef FMR_AB_PARTNERS
@@ -1781,18 +1793,22 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
     if (rc_agc) return rc_agc;
     HIPCHK(hipGetLastError());    // a launch of the rounds above that could not be enqueued
     // lock logic / PPS / state commit beside the audio chain (needed again only by fm_out)
-    HIPCHK(hipEventRecord(ev_pll, stream));
-    HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
+    if (spare_moved) HIPCHK(hipEventRecord(ev_pll, side));
+    else {
+      HIPCHK(hipEventRecord(ev_pll, stream));
+      HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
+    }
+    const size_t fin_ballast = side_ballast();
     timed_on(side, "pll_finish", [&] {
-      hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), 0, side, bt, ct, d_pll_G.p,
+      hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), fin_ballast, side, bt, ct, d_pll_G.p,
                          d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
-      hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), 0, side, k.base, base_stride, H_b, bt, ct, d_atan.p,
+      hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), fin_ballast, side, k.base, base_stride, H_b, bt, ct, d_atan.p,
                          pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
                          d_blk_wraps.p, d_blk_level.p, k.stereo_blk, d_state.p, d_flags.p);
     });
     // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
     // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
-    if (agc_on_side && !agc_deferred && !k.agc_late) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
+    if (agc_on_side && !agc_deferred) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
     HIPCHK(hipEventRecord(ev_fin, side));
     fin_on_side = true;
   }
@@ -1854,8 +1870,9 @@ int fmr_chain::run_fm(CallCtx &k) {
     timed_on(side, "in_halo", [&] {   // front end waits for this stream's table kernels anyway)
       hipLaunchKernelGGL((k_update_in_halo<256, 0>), dim3(1, S), dim3(256), 0, side, d_in_halo.p, H_in, d_iq, (long long)stride, N_in);
     });
+  const size_t stats_ballast = side_ballast();
   timed_on(side, "stats", [&] {     // (fused front end: the block values are summed from its partial sums on the fly)
-    hipLaunchKernelGGL(k_stats, dim3(S), dim3(FMR_STATS_THREADS), 0, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
+    hipLaunchKernelGGL(k_stats, dim3(S), dim3(FMR_STATS_THREADS), stats_ballast, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
                        d_bb_rms_blk.p, d_state.p, S, (int)!(pipelined && k.fused_disc),   // (the front-end stage commits its own phase)
                        k.fused_disc ? k.part : (const FusedPart *)nullptr, fused_n_tiles, fused_kb_ref);
   });
@@ -1893,7 +1910,7 @@ int fmr_chain::run_fm(CallCtx &k) {
     auto tail_fn = [&](hipStream_t st, int ch_base, int nch_l) { tail_channels(t, st, ch_base, nch_l); };
     if (int rcp = run_fm_pll(k, base_stride_, split_mono, tail_fn, mono_enqueued, fin_on_side, fin_covers_all)) return rcp;
   }
-  if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr, false)) return rca; }   // PLL path not taken
+  if (agc_deferred) { agc_deferred = false; if (int rca = enqueue_agc(nullptr)) return rca; }   // PLL path not taken
   if (k.fe_post) { k.fe_post(); k.fe_post = nullptr; }
   t.fin_on_side = fin_on_side; t.fin_covers_all = fin_covers_all; t.agc_on_side = agc_on_side; t.mono_enqueued = mono_enqueued;
 
@@ -2041,16 +2058,7 @@ int fmr_chain::tail_stage(const TailCtx &t, hipStream_t ts) {
 
 // Pipelined chain: enqueue the tail stage of the last decoded call on the tail stream, behind `gate` (the front end of
 // the call that follows it; null: nothing to wait for but the call's own PLL stage).
-int fmr_chain::flush_agc() {
-  if (!agc_pending) return FMR_OK;
-  agc_pending = false;
-  const int rc = agc_job(nullptr, true);
-  agc_job = nullptr;
-  return rc;
-}
 int fmr_chain::flush_tail(hipEvent_t gate) {
-  const int rc_agc = flush_agc();       // (the tail waits for its call's AGC: enqueued first, or the wait finds an older record)
-  if (rc_agc != FMR_OK && !tail_pending) return rc_agc;
   if (!tail_pending) return FMR_OK;
   tail_pending = false;
   const int rc = enqueue_tail(gate);

@@ -564,35 +564,21 @@ __global__ __launch_bounds__(1024) void k_agc_round(const XT *__restrict__ x, lo
 
 __global__ void k_iter_begin(IterFlags *fl, float *__restrict__ agc_nodes, int agc_nc, const StreamState *st,
                              int n_streams, unsigned long long *__restrict__ pll_sync, int sync_words,
-                             unsigned int *__restrict__ pll_tick2, int n_tick2, int part = 3) {
-  // part: 1 = what the PLL rounds (and the audio AGC) read, 2 = what the IF AGC's rounds read, 3 = both.  The pipelined
-  // chain resets the two apart: its IF AGC of call N is enqueued a call late, behind the tables of call N+1.
+                             unsigned int *__restrict__ pll_tick2, int n_tick2) {
   const int s = blockIdx.x;
   if (s >= n_streams) return;
   if (threadIdx.x == 0) {
-    if (part == 3) fl[s] = IterFlags{};
-    else if (part == 1) {
-      IterFlags z{};
-      const IterFlags &o = fl[s];
-      z.agc_converged = o.agc_converged; z.agc_iters = o.agc_iters; z.agc_fallback = o.agc_fallback;
-      z.agc_resid = o.agc_resid;
-      for (int i = 0; i < 16; i++) z.agc_hist[i] = o.agc_hist[i];
-      fl[s] = z;
-    } else {
-      IterFlags &o = fl[s];
-      o.agc_converged = 0; o.agc_iters = 0; o.agc_fallback = 0; o.agc_resid = 0.f;
-      for (int i = 0; i < 16; i++) o.agc_hist[i] = 0.f;
-    }
-    if (agc_nodes && (part & 2)) agc_nodes[(long long)s * (agc_nc + 1)] = st[s].agc_gain;
+    fl[s] = IterFlags{};
+    if (agc_nodes) agc_nodes[(long long)s * (agc_nc + 1)] = st[s].agc_gain;
   }
   // the PLL rounds' tickets and maximum slots (PllSync) are left at zero by the kernels that use them; a call that
   // starts from anything else (an aborted call before it) would mistake its last arrivals, so they are zeroed anyway
-  if (pll_sync && (part & 1)) {
+  if (pll_sync) {
     for (int i = threadIdx.x; i < sync_words; i += blockDim.x) pll_sync[(long long)s * sync_words + i] = 0ull;
     for (int i = threadIdx.x; i < n_tick2; i += blockDim.x) pll_tick2[(long long)s * n_tick2 + i] = 0u;
   }
   // initial guess: the carried gain everywhere
-  if (agc_nodes && (part & 2)) {
+  if (agc_nodes) {
     const float g0 = st[s].agc_gain;
     for (int c = 1 + threadIdx.x; c <= agc_nc; c += blockDim.x) agc_nodes[(long long)s * (agc_nc + 1) + c] = g0;
   }

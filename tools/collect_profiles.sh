@@ -34,11 +34,14 @@ timeout 300 python bench.py --resampler-class r8b --steps 20 --warmup 3 > gpurun
 timeout 300 python bench.py --if-filter --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_if_filter.json 2>/dev/null < /dev/null
 for sg in 1e-2 3e-2; do timeout 200 python bench.py --sigma $sg --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_sigma_${sg}.json 2>/dev/null < /dev/null; done
 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_driver_form.json 2>/dev/null < /dev/null
+# the drop-in call: one block per fmr_process() through host buffers (latency percentiles)
+timeout 200 python bench.py --api-mode block --steps 300 --blocks 400 --no-cpu-baseline > gpurun_out/${tag}_bench_block1.json 2>/dev/null < /dev/null
 timeout 120 tools/bench_fused.bin > gpurun_out/${tag}_fused_harness.log 2>&1 < /dev/null
 # the chain's own schedule trace, the equaliser's cycle account and rates, the PLL's mismatch history
 timeout 120 python tools/step_timeline.py --show 2 --out gpurun_out/${tag}_step_timeline.txt > /dev/null 2>&1
 timeout 120 python tools/step_timeline.py --show 1 --r8b --out gpurun_out/${tag}_step_timeline_r8b.txt > /dev/null 2>&1
 timeout 120 python tools/step_timeline.py --show 1 --if-filter --out gpurun_out/${tag}_step_timeline_if_filter.txt > /dev/null 2>&1
+timeout 120 python tools/step_timeline.py --show 1 --sigma 1e-2 --out gpurun_out/${tag}_step_timeline_sigma_1e-2.txt > /dev/null 2>&1 < /dev/null
 { timeout 120 python tools/mpf_rate.py < /dev/null; } 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_mpf_account.txt
 timeout 120 python tools/pll_mismatch.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_pll_mismatch.txt
 tail -3 gpurun_out/${tag}_pytest_gpu.log

@@ -52,7 +52,7 @@ for p in sorted(glob.glob(g(f"{tag}_bench_*.json"))):
     name = os.path.basename(p)
     json.dump(b, open(prof(name), "w"), indent=1)
     others[name[len(tag) + 7:-5]] = {"value": b["value"], "unit": b["unit"], "ms_per_step": b["ms_per_step"],
-                                     "stage_ms": b["roofline"].get("stage", {}).get("ms") if isinstance(b["roofline"].get("stage"), dict) else None}
+                                     "stage_ms": (b.get("roofline") or {}).get("stage", {}).get("ms") if isinstance((b.get("roofline") or {}).get("stage"), dict) else None}
 
 # the dominant kernel in the rocprofv3 --stats run of the same command
 rows = list(csv.DictReader(open(stats)))
