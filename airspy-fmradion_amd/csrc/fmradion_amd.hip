@@ -255,7 +255,8 @@ struct fmr_chain {
   DevBuf<unsigned int> d_agc_tick;      // k_agc_round's last-arrival ticket, one per stream (left at zero by its users)
   DevBuf<double> d_af_nodes, d_af_G, d_af_M, d_af_out;   // AmDecoder audio tail, time-parallel form
   DcCoef am_dk{};
-  DevBuf<int> d_ck_wraps, d_blk_wraps;
+  DevBuf<int> d_ck_wraps, d_blk_wraps, d_walk_go;
+  size_t ck_copy = 0;             // elements of one copy of d_ck_wraps
   DevBuf<unsigned long long> d_ck_mask;
   int mask_words = 2;
   DevBuf<IterFlags> d_flags;
@@ -312,7 +313,7 @@ struct fmr_chain {
 #endif
     // a tail stage that was never enqueued (an asynchronous last call nobody synchronised) is dropped, not launched: its
     // output mux would write into the caller's audio buffer, which the caller may have freed by now
-    tail_pending = false;
+    tail_pending = false; walk_pending = false; walk_job = nullptr;
     for (hipStream_t st : {stream, side, side2, tail}) if (st) (void)hipStreamSynchronize(st);
     for (auto &k : ktimes) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
     for (auto &k : trace) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
@@ -326,7 +327,7 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_walk_go.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     d_af_nodes.release(); d_af_G.release(); d_af_M.release(); d_af_out.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
@@ -508,6 +509,14 @@ struct fmr_chain {
   static constexpr int kDeBlock = 256;
   TailCtx tail_job{};
   bool tail_pending = false;
+  // Pipelined chain: the lock logic's walk over the blocks of call N (k_pll_finish) is enqueued a call late -- on the side
+  // stream behind the tables of call N+1, with the tail of call N whose output mux waits for it (flush_tail), beside the
+  // front end of call N+1 -- or by whatever drains the chain.  What the next PLL needs of it, k_pll_commit has committed
+  // in call N (kernels_par.hpp): the next call's tables no longer wait for a one-wave walk over 2048 blocks.
+  bool walk_pending = false;
+  std::function<int()> walk_job{};
+  int flush_walk();
+  int walk_par = 0;               // which copy of the PLL's wrap counts / wrap masks / verdict the next call writes
   void tail_channels(const TailCtx &t, hipStream_t st, int ch_base, int nch_l);
   int tail_stage(const TailCtx &t, hipStream_t ts);
   int flush_tail(hipEvent_t gate);
@@ -898,7 +907,9 @@ int fmr_chain::init(const fmr_config *c) {
     if ((rc = d_pll_nodes.alloc((size_t)S * (max_ck + 1) * 7))) return rc;
     if ((rc = d_pll_G.alloc((size_t)S * max_ck * 9))) return rc;
     if ((rc = d_pll_M.alloc((size_t)S * max_ck * 49))) return rc;
-    if ((rc = d_ck_wraps.alloc((size_t)S * max_ck))) return rc;
+    if ((rc = d_ck_wraps.alloc((size_t)S * max_ck * (pipelined ? 2 : 1)))) return rc;      // (pipelined chain: two copies, see walk_par)
+    ck_copy = (size_t)S * max_ck;
+    if ((rc = d_walk_go.alloc((size_t)S * 2))) return rc;
     {
       const size_t max_grp = max_ck / FMR_NODE_GRP + 2;
       if ((rc = d_pll_PQ.alloc((size_t)S * max_grp * 56))) return rc;
@@ -915,7 +926,7 @@ int fmr_chain::init(const fmr_config *c) {
       pll_tick2_per_stream = (int)max_grp2;
     }
     mask_words = (std::max(c_pll, 128) + 63) / 64;   // wrap bit masks: one word per 64 samples of a chunk
-    if ((rc = d_ck_mask.alloc((size_t)S * max_ck * mask_words))) return rc;
+    if ((rc = d_ck_mask.alloc((size_t)S * max_ck * mask_words * (pipelined ? 2 : 1)))) return rc;
     if ((rc = d_blk_wraps.alloc((size_t)S * max_blocks))) return rc;
     if ((rc = d_blk_level.alloc((size_t)S * max_blocks))) return rc;
     max_dc_nc = max_au / C_DC + 2;
@@ -1693,6 +1704,13 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
     // ---- pilot PLL: Newton multiple shooting over chunks of C_PLL samples
     int rc_agc = FMR_OK;          // a failure inside the lambda must leave run_fm_pll, not only the lambda
     bool spare_moved = false;     // the passes after the second went to the side stream
+    // the wrap counts and masks the lock logic's walk reads: two copies in the pipelined chain, where the walk of this call
+    // runs beside the next call's front end and is not ordered before that call's PLL passes, which write them again
+    const bool walk_late = pipelined && !env.pll_v1 && !serial_mode;
+    const int wpar = walk_late ? walk_par : 0;
+    if (walk_late) walk_par ^= 1;
+    int *const ck_wraps_now = d_ck_wraps.p + (size_t)wpar * ck_copy;
+    unsigned long long *const ck_mask_now = d_ck_mask.p + (size_t)wpar * ck_copy * mask_words;
     // (trace mode: every kernel of the group carries its own event pair)
     auto sub = [&](hipStream_t st, const char *name, auto &&launch) { if (timing == 3) timed_on(st, name, launch); else launch(); };
     timed("pll", [&] {
@@ -1728,7 +1746,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
           sub(ps, it == 0 ? "pll_shoot_jac" : "pll_shoot", [&] {
           hipLaunchKernelGGL(kern, dim3((nck + 63) / 64, S), dim3(64), 0, ps, k.base, base_stride, H_b, ct,
                              k.raw, base_stride, H_b, d_atan.p, pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p,
-                             d_pll_M.p, d_ck_wraps.p, d_ck_mask.p, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
+                             d_pll_M.p, ck_wraps_now, ck_mask_now, mask_words, d_flags.p, d_pll_wgr.p, sy, 1.0,
                              pll_rtol, (int)(it > 0), upa, dna, sy ? d_pll_wfirst.p : (double *)nullptr);
           });
         };
@@ -1783,6 +1801,9 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
                            nck, d_pll_dstart.p, d_flags.p, pllc.minfreq, pllc.maxfreq, d_pll_gres.p);
 #endif
       }
+      // the serial fallback (a kernel that reads a flag and leaves unless the rounds gave up) goes with the lock logic in the
+      // pipelined chain: it carries the lock counters on, as the late walk of the call before does on that stream
+      if (walk_late && !spare_moved) { (void)hipEventRecord(ev_pll1, stream); (void)hipStreamWaitEvent(side, ev_pll1, 0); spare_moved = true; ps = side; }
       if (pilot_shift)
         hipLaunchKernelGGL(k_pll_fallback<true>, dim3(S), dim3(64), 0, ps, k.base, base_stride, H_b, bt,
                            k.raw, base_stride, H_b, d_atan.p, pllc, k.stereo_blk, d_state.p, S, d_flags.p);
@@ -1799,13 +1820,33 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
       HIPCHK(hipStreamWaitEvent(side, ev_pll, 0));
     }
     const size_t fin_ballast = side_ballast();
-    timed_on(side, "pll_finish", [&] {
-      hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 63) / 64, S), dim3(64), fin_ballast, side, bt, ct, d_pll_G.p,
-                         d_ck_wraps.p, d_blk_wraps.p, d_blk_level.p, d_flags.p);
-      hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), fin_ballast, side, k.base, base_stride, H_b, bt, ct, d_atan.p,
-                         pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, d_ck_wraps.p, d_ck_mask.p, mask_words,
-                         d_blk_wraps.p, d_blk_level.p, k.stereo_blk, d_state.p, d_flags.p);
+    int *const walk_go = d_walk_go.p + (size_t)wpar * S;
+    const fm_mpx_t *const base_l = k.base; int *const stereo_blk_l = k.stereo_blk;
+    const BlockTab bt_l = bt; const ChunkTab ct_l = ct;
+    auto walk = [=]() -> int {
+      timed_on(side, "pll_finish", [&] {
+        hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), fin_ballast, side, base_l, base_stride, H_b, bt_l, ct_l, d_atan.p,
+                           pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, ck_wraps_now, ck_mask_now, mask_words,
+                           d_blk_wraps.p, d_blk_level.p, stereo_blk_l, d_state.p, d_flags.p,
+                           walk_late ? walk_go : (const int *)nullptr);
+      });
+      if (walk_late) HIPCHK(hipEventRecord(ev_fin, side));
+      return FMR_OK;
+    };
+    timed_on(side, walk_late ? "pll_commit" : "pll_blocks", [&] {
+      hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 3) / 4, S), dim3(256), fin_ballast, side, bt, ct, d_pll_G.p,
+                         ck_wraps_now, d_blk_wraps.p, d_blk_level.p, d_flags.p);
+      if (walk_late)
+        hipLaunchKernelGGL(k_pll_commit, dim3(S), dim3(FMR_COMMIT_THREADS), fin_ballast, side, bt, ct, pllc, d_pll_G.p, d_blk_wraps.p,
+                           d_blk_level.p, d_state.p, d_flags.p, walk_go);
     });
+    if (walk_late) {
+      // (the tail waits for this stream's statistics and AGC itself: ev_fin, recorded behind the late walk, covers neither)
+      walk_job = walk; walk_pending = true;
+      fin_on_side = true;
+      return FMR_OK;
+    }
+    if (int rcw = walk()) return rcw;
     // one event for everything beside the main stream: this stream's own work (statistics, lock logic) and the
     // AGC stream's -- the main stream then waits once, before the output mux, instead of four times
     if (agc_on_side && !agc_deferred) { HIPCHK(hipStreamWaitEvent(side, ev_agc, 0)); fin_covers_all = true; }
@@ -2058,7 +2099,16 @@ int fmr_chain::tail_stage(const TailCtx &t, hipStream_t ts) {
 
 // Pipelined chain: enqueue the tail stage of the last decoded call on the tail stream, behind `gate` (the front end of
 // the call that follows it; null: nothing to wait for but the call's own PLL stage).
+int fmr_chain::flush_walk() {
+  if (!walk_pending) return FMR_OK;
+  walk_pending = false;
+  const int rc = walk_job();
+  walk_job = nullptr;
+  return rc;
+}
 int fmr_chain::flush_tail(hipEvent_t gate) {
+  const int rc_walk = flush_walk();       // (the tail's output mux waits for its call's walk: enqueued first, or the wait finds an older record)
+  if (rc_walk != FMR_OK && !tail_pending) return rc_walk;
   if (!tail_pending) return FMR_OK;
   tail_pending = false;
   const int rc = enqueue_tail(gate);

@@ -505,8 +505,15 @@ __device__ __forceinline__ void agc_node_pass(const int s, float *__restrict__ n
     // gain_invariant == 2: nobody reads the per-sample gains of this call either (FM without the equaliser, no debug tap)
     // -- the call is solved for the carried state only, and the node pass has just computed that state from the first
     // integration pass: a second pass would only rewrite gains that are never read.  Round 1 is accepted at the same 5e-5.
+    // ... and when only the state is wanted, round 1 is accepted up to a movement of 2e-3 as well: the node pass has just
+    // applied the first-order correction to every node, what it leaves is second order -- 1.3 x movement^2 in a float64
+    // model of this recurrence over noise levels 1e-3 ... 1e-1 (tools/agc_round_model.py: movement 1.0e-3 -> error 8.5e-7,
+    // 5.3e-3 -> 3.2e-5, 1.1e-2 -> 1.6e-4), so <= 5e-6 here, a tenth of what the later rounds are accepted at and below the
+    // 3e-5 they stagnate at.  A second round could only measure that: it was 0.08-0.1 ms of the side stream for every call
+    // of a noisy input (sigma 1e-2: movement 2.8e-4) or behind the IF filter (5.8e-5).
     const float tight = gain_invariant ? 1.0e-6f : 1.5e-7f;
     if (maxrel <= tight || (gain_invariant && (fl[s].agc_iters >= 2 || gain_invariant == 2) && maxrel <= 5.0e-5f) ||
+        (gain_invariant == 2 && fl[s].agc_iters == 1 && maxrel <= 2.0e-3f) ||
         (!gain_invariant && fl[s].agc_iters >= 3 && maxrel <= 1.0e-6f)) {   // gains of the last shoot pass stand
       fl[s].agc_converged = 1;
       st[s].agc_gain = nd[nc];
@@ -1792,14 +1799,23 @@ __device__ __forceinline__ int wave_scan_dpp(int v) {
 __global__ void k_pll_blocks(BlockTab bt, ChunkTab ct, const double *__restrict__ G,
                              const int *__restrict__ ck_wraps, int *__restrict__ blk_wraps,
                              double *__restrict__ blk_level, const IterFlags *__restrict__ fl) {
+  // a WAVE per block, a lane per chunk (a block of the benchmark holds ~40 chunks): one load per lane and a wave sum, not a
+  // thread per block adding its chunks one load behind the other -- this kernel runs beside the next call's front end,
+  // where every memory round trip is microseconds
   const int s = blockIdx.y;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= bt.nb || !fl[s].pll_converged || fl[s].pll_fallback) return;
+  const int c0 = ct.first[b], c1 = ct.first[b + 1];
+  const double level = (c1 > c0 && lane == 0) ? G[((long long)s * ct.nck + (c1 - 1)) * 9 + 7] : 0.0;
   int w = 0;
-  for (int c = ct.first[b]; c < ct.first[b + 1]; c++) w += ck_wraps[(long long)s * ct.nck + c];
-  blk_wraps[(long long)s * bt.nb + b] = w;
-  blk_level[(long long)s * bt.nb + b] =
-      (ct.first[b + 1] > ct.first[b]) ? G[((long long)s * ct.nck + (ct.first[b + 1] - 1)) * 9 + 7] : 0.0;
+  for (int c = c0 + lane; c < c1; c += 64) w += ck_wraps[(long long)s * ct.nck + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+  if (lane == 0) {
+    blk_wraps[(long long)s * bt.nb + b] = w;
+    blk_level[(long long)s * bt.nb + b] = level;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_pll_finish(
@@ -1807,10 +1823,13 @@ __global__ __launch_bounds__(64) void k_pll_finish(
     const float *__restrict__ atan_tab, PllConst pc, int pilot_shift, const double *__restrict__ nodes,
     const double *__restrict__ G, const int *__restrict__ ck_wraps, const unsigned long long *__restrict__ ck_mask,
     int mask_words, const int *__restrict__ blk_wraps, const double *__restrict__ blk_level,
-    int *__restrict__ stereo_blk, StreamState *st, const IterFlags *__restrict__ fl) {
+    int *__restrict__ stereo_blk, StreamState *st, const IterFlags *__restrict__ fl,
+    const int *__restrict__ walk_go = nullptr) {
+  // walk_go != nullptr: the loop state has been committed by k_pll_commit, which also left the call's verdict here -- in
+  // the pipelined chain this walk runs behind the NEXT call's tables, whose reset has cleared the round flags by then
   const int s = blockIdx.x;
   const int lane = threadIdx.x;
-  if (!fl[s].pll_converged || fl[s].pll_fallback) return;
+  if (walk_go ? !walk_go[s] : (!fl[s].pll_converged || fl[s].pll_fallback)) return;
   // 6 KB of LDS in all: in the pipelined chain this kernel runs beside the next call's front end, whose workgroup leaves
   // 7.5 KB of a CU's LDS free (with 32 KB it waited for the front end to end, and the next PLL pass behind it)
   constexpr int kFlagBuf = 512;
@@ -1946,7 +1965,7 @@ __global__ __launch_bounds__(64) void k_pll_finish(
     }
   }
   if (lane != 0) return;
-  if (ct.nck > 0) {
+  if (ct.nck > 0 && !walk_go) {
     const double *g = G + ((long long)s * ct.nck + (ct.nck - 1)) * 9;
     if (ns >= 65536) {
       S.pll_favg = ((double)wr * 2.0 * 3.14159265358979323846 + (g[0] - S.pll_phase)) / (double)ns;
@@ -1959,6 +1978,97 @@ __global__ __launch_bounds__(64) void k_pll_finish(
   S.lock_cnt = lock_cnt; S.pilot_periods = pilot_periods; S.pps_cnt = pps_cnt; S.sample_cnt = sample_cnt;
   S.n_pps = n_pps < FMR_MAX_PPS ? n_pps : FMR_MAX_PPS;
   S.stereo_detected = (lock_cnt >= pc.lock_delay);
+}
+
+// Pipelined chain: the part of k_pll_finish the NEXT call's PLL needs -- the loop state at the end of the call and the
+// mean phase increment its start nodes are ramped with -- without the walk over the blocks.  The walk's two inputs to it
+// are sums (wraps, samples) and whether the call ends in lock: the lock counter restarts at every block below the
+// signal threshold and counts samples until it reaches the delay, so it ends at or above the delay exactly when the
+// samples behind the last such block (with the carried count when there is none) reach it.  One wave per stream, two
+// passes over the block values with every load of a pass in flight.  The walk then runs a call late, behind the next
+// call's tables: on the side stream it was between this call's PLL and those tables -- 0.06 ms alone, 0.19 ms when it
+// shares a compute unit with the next front end, which is that front end's whole duration -- and the next call's first
+// PLL pass waited for it.
+// Beside the next call's front end a memory round trip takes microseconds (the front end keeps HBM at 60% of its peak):
+// a lane per block with its loads one behind the other was 64 round trips, 0.19 ms.  Here a thread holds eight blocks and
+// has all their loads in flight at once: three round trips for up to 2048 blocks.
+#define FMR_COMMIT_THREADS 256
+__global__ __launch_bounds__(FMR_COMMIT_THREADS) void k_pll_commit(BlockTab bt, ChunkTab ct, PllConst pc,
+                                                                   const double *__restrict__ G,
+                                                                   const int *__restrict__ blk_wraps,
+                                                                   const double *__restrict__ blk_level, StreamState *st,
+                                                                   const IterFlags *__restrict__ fl,
+                                                                   int *__restrict__ walk_go) {
+  constexpr int NT = FMR_COMMIT_THREADS, K = 8;
+  __shared__ int s_low[NT / 64];
+  __shared__ long long s_sum[NT / 64][3];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool go = fl[s].pll_converged && !fl[s].pll_fallback;
+  if (tid == 0) walk_go[s] = go ? 1 : 0;
+  if (!go || ct.nck <= 0) return;
+  StreamState &S = st[s];
+  const int lock0 = S.lock_cnt;
+  const double ph0 = S.pll_phase;
+  double gl[9];
+  if (tid == 0) {
+    const double *g = G + ((long long)s * ct.nck + (ct.nck - 1)) * 9;
+#pragma unroll
+    for (int q = 0; q < 9; q++) gl[q] = g[q];
+  }
+  // pass 1: the last block below the signal threshold
+  int last_low = -1;
+  for (int b0 = 0; b0 < bt.nb; b0 += NT * K) {
+    int n[K]; double lv[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const int b = min(b0 + j * NT + tid, bt.nb - 1);
+      n[j] = bt.if_len[b]; lv[j] = blk_level[(long long)s * bt.nb + b];
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const int b = b0 + j * NT + tid;
+      if (b < bt.nb && n[j] != 0 && !(2 * lv[j] > pc.minsignal)) last_low = max(last_low, b);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last_low = max(last_low, __shfl_xor(last_low, o, 64));
+  if (lane == 0) s_low[wv] = last_low;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NT / 64; u++) last_low = max(last_low, s_low[u]);
+  // pass 2: wraps, samples, samples behind that block
+  long long wr = 0, ns = 0, ns_after = 0;
+  for (int b0 = 0; b0 < bt.nb; b0 += NT * K) {
+    int n[K], w[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const int b = min(b0 + j * NT + tid, bt.nb - 1);
+      n[j] = bt.if_len[b]; w[j] = blk_wraps[(long long)s * bt.nb + b];
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const int b = b0 + j * NT + tid;
+      if (b < bt.nb && n[j] != 0) { wr += w[j]; ns += n[j]; if (b > last_low) ns_after += n[j]; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    wr += __shfl_xor(wr, o, 64); ns += __shfl_xor(ns, o, 64); ns_after += __shfl_xor(ns_after, o, 64);
+  }
+  if (lane == 0) { s_sum[wv][0] = wr; s_sum[wv][1] = ns; s_sum[wv][2] = ns_after; }
+  __syncthreads();
+  if (tid != 0) return;
+  wr = ns = ns_after = 0;
+#pragma unroll
+  for (int u = 0; u < NT / 64; u++) { wr += s_sum[u][0]; ns += s_sum[u][1]; ns_after += s_sum[u][2]; }
+  const long long cnt_end = (last_low < 0 ? (long long)lock0 : 0ll) + ns_after;
+  if (ns >= 65536) {
+    S.pll_favg = ((double)wr * 2.0 * 3.14159265358979323846 + (gl[0] - ph0)) / (double)ns;
+    S.pll_favg_valid = (cnt_end >= (long long)pc.lock_delay) ? 1 : 0;
+  }
+  S.pll_phase = gl[0]; S.pll_freq = gl[1]; S.lf_x1 = gl[2];
+  S.bq_i_x1 = gl[3]; S.bq_i_x2 = gl[4]; S.bq_q_x1 = gl[5]; S.bq_q_x2 = gl[6];
+  S.pll_level = gl[7]; S.pll_freq_err = gl[8];
 }
 
 // Serial fallback: the plain loop when the shooting iteration did not converge (unlocked: without a pilot the loop's

@@ -564,6 +564,11 @@ def test_fm_stereo_hard_signals(pilot, sigma, amp, pilotcut):
     assert all(r <= 3 for r, _, _, _ in its[1:]), its
     if sigma <= 1e-3 and pilot >= 0.10:
         assert all(r == 2 for r, _, _, _ in its[1:]), its
+    # the IF AGC, solved for its carried state only: one Newton round once the chain runs (the round-1 acceptance of
+    # k_agc_round / agc_node_pass: the first-order correction is in, what is left is second order), no serial fallback,
+    # and the state the reference carries
+    assert all(a == 1 and f == 0 for _, _, a, f in its[1:]), its
+    assert st.if_agc_gain == pytest.approx(fm.get_if_agc_gain(), rel=2e-4)
 
 
 def test_randomised_block_partition(pilotcut):
