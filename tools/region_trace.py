@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--out", default="")
+    ap.add_argument("--dump", default="", help="steps (1-based, comma separated) whose kernels are listed one by one")
     args = ap.parse_args()
     import torch
     fmr = importlib.import_module("airspy-fmradion_amd")
@@ -65,6 +66,17 @@ def main():
     last = max(r[3] for r in tr)
     lines.append("# last kernel of the region ends %.3f ms after the first front end started; last PLL stage ended at %.3f"
                  % (last - t0, pll[-1][3] - t0))
+    names = ["dec ", "side", "agc ", "fe  ", "tail"]
+    cols = {0: 0, 1: 1, 2: 2, 3: 3, 4: 3}
+    for d in [int(v) for v in args.dump.split(",") if v]:
+        if d < 1 or d >= len(fe):
+            continue
+        w0, w1 = fe[d - 1][2], fe[d][2]
+        lines.append("# step %d: start us, duration us, stream, kernel" % d)
+        for name, st, a, b in tr:
+            if b < w0 or a > w1:
+                continue
+            lines.append("%9.1f %8.1f  %s %s%s" % ((a - w0) * 1e3, (b - a) * 1e3, names[st], "      " * cols[st], name))
     txt = "\n".join(lines)
     print(txt)
     if args.out:
