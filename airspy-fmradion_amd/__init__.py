@@ -18,9 +18,9 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "libfmradion_amd.so")
 # The same sources with -DFMR_AB_PARTNERS: the product plus the slower forms two GPU tests compare it with (the PLL's
 # seven-launch Newton round, FMR_PLL_V1) and a test hook (FMR_TEST_AGC_LATE).  Loaded only by chains that are created while
-# one of those switches is set; the product library does not carry them.
+# Chain(..., ab=True) -- the two tests that need them say so; the switches themselves are read from the environment by that
+# library only.  The product library does not carry them, and a leftover variable in the environment selects nothing.
 LIB_PATH_AB = os.path.join(_DIR, "libfmradion_amd_ab.so")
-AB_SWITCHES = ("FMR_PLL_V1", "FMR_TEST_AGC_LATE")
 SRC = os.path.join(_DIR, "csrc", "fmradion_amd.hip")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -104,7 +104,8 @@ def lib(ab=False):
         return _libs[ab]
     path = LIB_PATH_AB if ab else LIB_PATH
     if not os.path.exists(path):
-        raise FmrError(f"{path} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+        raise FmrError(f"{path} is missing: run __graft_entry__.build() (there is no CPU fallback)" if not ab else
+                       f"{path} (the A/B partner build two GPU tests load) is missing: run __graft_entry__.build()")
     L = C.CDLL(path)
     vp, u32p, fp, dp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_double)
     L.fmr_create.restype = C.c_int
@@ -206,8 +207,8 @@ class Chain:
     def __init__(self, mode=MODE_FM, input_rate=384000.0, enable_resampler=False, fourth_down=False,
                  fmfilter_enable=False, filter_coeff=None, stereo=True, deemphasis_us=50.0, pilot_shift=False,
                  multipath_stages=0, max_block_len=65536, max_blocks=1, n_streams=1, device=0, nbfm_freq_dev=0.0, input_format=0,
-                 output_rate=0.0, resampler_class=RESAMPLER_FAST, in_order=False):
-        self._L = lib(ab=any(k in os.environ for k in AB_SWITCHES))
+                 output_rate=0.0, resampler_class=RESAMPLER_FAST, in_order=False, ab=False):
+        self._L = lib(ab=bool(ab))
         coeff = np.ascontiguousarray(DELAY_3TAPS if filter_coeff is None else filter_coeff, dtype=np.float32)
         self._coeff = coeff
         cfg = Config()

@@ -9,6 +9,7 @@
 // the whole call at once, the block structure travels as small offset tables
 // the host derives from the resampler's integer output-count law.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <functional>
 #include <thread>
@@ -113,6 +114,9 @@ struct EnvKnobs {
   static constexpr int test_agc_late = 0;
 #endif
   double pll_rtol = -1.0;       // FMR_PLL_RTOL       PLL acceptance threshold (< 0 = default)
+  bool fe_stamps = false;       // FMR_FE_STAMPS=1    diagnostics: every front-end workgroup leaves its start / end time and hardware id (fmr_debug_read 5)
+  bool evt_markers = false;     // FMR_EVT_MARKERS=1  diagnostics: time the fused front end between two event MARKERS on its stream (rounds 1-5) instead of
+                                //                    with the start / stop events of its own dispatch
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
   void load() {
@@ -120,6 +124,7 @@ struct EnvKnobs {
     auto num = [](const char *n, int dflt) { const char *e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
     pipeline = num("FMR_PIPELINE", -1); fe_cus = num("FMR_FE_CUS", 0);
     host_prof = on("FMR_HOST_PROF"); no_fused = on("FMR_NO_FUSED");
+    fe_stamps = on("FMR_FE_STAMPS"); evt_markers = on("FMR_EVT_MARKERS");
 #ifdef FMR_AB_PARTNERS
     test_agc_late = num("FMR_TEST_AGC_LATE", 0); pll_v1 = set("FMR_PLL_V1");
 #endif
@@ -137,6 +142,7 @@ struct fmr_chain {
   // side stream: per-block bookkeeping (statistics EMAs, PLL lock logic / PPS) runs beside the
   // audio chain instead of in front of it
   bool dec_valid = true;
+  bool if_valid = true;                 // the IF samples of the last call are in last_if (false: the fused front end's discriminator epilogue kept them on chip and stored |x|^2 there)
   bool gain_valid = true;               // the per-sample AGC gains of the last call are in d_gain (fmr_debug_read 4)
   bool debug_taps = false;               // FMR_DEBUG_TAPS=1: keep the de-emphasised 384 kHz signal readable (fmr_debug_read 2,3)
   DeScan de_scan{};
@@ -233,6 +239,14 @@ struct fmr_chain {
   DevBuf<unsigned short> d_fused_afragB;   // stage-B tap fragments (fp16 high / low terms) and the inverse of their scale
   float fused_hB_inv_scale = 1.f;
   DevBuf<FusedPart> d_fused_part;
+  DevBuf<float> d_fused_mid32;              // per front-end workgroup: fp32 copies of mid samples beyond fp16's range (FusedRing::at32)
+  DevBuf<unsigned long long> d_fe_stamps;   // FMR_FE_STAMPS=1: {start, end, hardware id} of every workgroup of the last fused launch
+  int fe_stamps_n = 0;                      //   ... and how many workgroups that launch had
+  // The dominant kernel is timed with the start / stop events of ITS OWN dispatch (hipExtLaunchKernelGGL): the time stamps
+  // the command processor takes when the kernel's first wave starts and its last wave has ended -- what rocprofv3's kernel
+  // trace reads -- and no marker packets on the decoder stream (two markers around a kernel cost 7-10 us of the step and
+  // put their own processing time, ~4 us, into the interval).  Set by timed_on for the launch it wraps.
+  hipEvent_t ext_a = nullptr, ext_b = nullptr;
   int n_cu = 256;
   DevBuf<float> d_hBp;                 // zero-padded tap rows for v3
   DevBuf<float> d_hpA;                 // stage-A taps in polyphase order [D][Q] (k_ifr_decim2)
@@ -325,7 +339,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_walk_go.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -362,13 +376,23 @@ struct fmr_chain {
                               std::strcmp(name, "blk_reduce") == 0 ||
                               (mode == FMR_MODE_FM && std::strcmp(name, "fm_block") == 0);   // FM with the IF FIR on
     // mode 4: the same on every fourth call only (two event markers on the decoder stream cost 7-10 us of a 0.56 ms step)
-    if ((timing == 2 || (timing == 4 && (call_seq & 3ull) == 0)) && stage_kernel) {
+    // mode 5: as mode 4, but the fused front end on EVERY call: it is timed with the events of its own dispatch, which put no
+    // markers on the stream
+    const bool own_events = !env.evt_markers && std::strcmp(name, "ifr_fused") == 0;
+    const bool sampled = timing == 2 || ((timing == 4 || timing == 5) && (call_seq & 3ull) == 0);
+    if (stage_kernel && (sampled || (timing == 5 && own_events))) {
       KernelTime kt{name, nullptr, nullptr};
       (void)hipEventCreate(&kt.a);
       (void)hipEventCreate(&kt.b);
-      (void)hipEventRecord(kt.a, st);
-      launch();
-      (void)hipEventRecord(kt.b, st);
+      if (own_events) {
+        ext_a = kt.a; ext_b = kt.b;
+        launch();
+        ext_a = ext_b = nullptr;
+      } else {
+        (void)hipEventRecord(kt.a, st);
+        launch();
+        (void)hipEventRecord(kt.b, st);
+      }
       dom_times.push_back(kt);
       return;
     }
@@ -820,6 +844,8 @@ int fmr_chain::init(const fmr_config *c) {
   if ((rc = d_gain.alloc((size_t)S * max_if))) return rc;
   if ((rc = d_dec.alloc((size_t)S * max_if))) return rc;
   if (fused_ok && (rc = d_fused_part.alloc((size_t)S * 3 * (max_if / 384 + 4)))) return rc;
+  if (fused_ok && (rc = d_fused_mid32.alloc((size_t)std::max(std::max(n_cu, S), 256) * 2 * FusedShape<kFusedD, kFusedNA>::MIDR))) return rc;
+  if (fused_ok && env.fe_stamps && (rc = d_fe_stamps.alloc(3 * (size_t)kMaxFusedWg * S + 2))) return rc;
   if ((rc = d_if_rms_blk.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_bb_mean_blk.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_bb_rms_blk.alloc((size_t)S * max_blocks))) return rc;
@@ -1164,6 +1190,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
     }
     k.fused_disc = use_fused && fused_disc_ok;
     dec_valid = !k.fused_disc || debug_taps;   // the float copy of the discriminator output is a debug tap of the fused kernel
+    if_valid = dec_valid;                      // ... and so are the IF samples behind its discriminator epilogue (the slot holds |x|^2 then)
     if (use_fused) {
       fused_geom = {mA_prev, kB_prev, n_prev, count_mid};
     } else if (count_mid > 0) {
@@ -1279,6 +1306,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
   } else {
     ifbuf = d_if.p;
     last_if = ifbuf;
+    if_valid = true;
     for (int b = 0; b < nb; b++) { t_if_off[b] = (int)N_if; t_if_len[b] = (int)block_len[b]; N_if += block_len[b]; }
     if (N_if > 0)
       HIPCHK(hipMemcpy2DAsync(ifbuf + H_if, sizeof(float2) * (H_if + max_if), d_iq, sizeof(float2) * stride,
@@ -1433,7 +1461,7 @@ int fmr_chain::run_tables(CallCtx &k) {
     if (ev_agc_live) HIPCHK(hipStreamWaitEvent(side, ev_agc, 0));
     const int nc = (int)((N_if + C_AGC - 1) / C_AGC);
     hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, side, d_flags.p, d_agc_nodes.p, nc, d_state.p, S,
-                       (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p, pll_tick2_per_stream);
+                       (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p, pll_tick2_per_stream, d_agc_tick.p);
   }
   if (pipelined && ring_prev >= 0 && ring_prev != k.par) {
     // halos of this call's ring slot = the tail of the previous call's slot (its writers -- front end, discriminator, PLL
@@ -1505,10 +1533,20 @@ int fmr_chain::run_tables(CallCtx &k) {
     // the discriminator's carried phase: when the previous call ran the discriminator in its decoder stage (a call too
     // short for the fused kernel), its phase is committed by that call's statistics kernel on the side stream
     if (pipelined && k.fused_disc && disc_commit_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
+    if (d_fe_stamps.p) { a.stamps = d_fe_stamps.p; fe_stamps_n = grid * S; }
+    if ((size_t)grid * S * 2 * FusedShape<D, NA>::MIDR > d_fused_mid32.n) { set_err("internal capacity exceeded (fused workgroups)"); return FMR_ERR_CAPACITY; }
+    a.mid32 = d_fused_mid32.p;
+    if (d_fe_stamps.p) hipLaunchKernelGGL(k_fused_stamp, dim3(1), dim3(1), 0, fes, d_fe_stamps.p + 3 * (size_t)kMaxFusedWg * S);
     timed_on(fes, "ifr_fused", [&] {
+      if (ext_a) {      // (timed with the events of its own dispatch)
+        if (par) hipExtLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, ext_a, ext_b, 0, a);
+        else hipExtLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, ext_a, ext_b, 0, a);
+        return;
+      }
       if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, a);
       else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, a);
     });
+    if (d_fe_stamps.p) hipLaunchKernelGGL(k_fused_stamp, dim3(1), dim3(1), 0, fes, d_fe_stamps.p + 3 * (size_t)kMaxFusedWg * S + 1);
     fused_kb_ref = a.kb_ref;
     if (pipelined) {
       // The PLL stage starts from here.  What the front-end stage carries into its next call -- the input history, the
@@ -1597,7 +1635,7 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     hipLaunchKernelGGL(k_iter_begin, dim3(S), dim3(256), 0, stream, d_flags.p,
                        (serial_mode || enable_mpf) ? (float *)nullptr : d_agc_nodes.p,
                        agc_nc, d_state.p, S, (unsigned long long *)d_pll_sync.p, (int)(sizeof(PllSync) / 8), d_pll_tick2.p,
-                       pll_tick2_per_stream);
+                       pll_tick2_per_stream, d_agc_tick.p);
   // With the equaliser on, the AGC'd amplitude feeds the constant-modulus error, and
   // the equaliser kernel is the serial bottleneck anyway: use the exact serial AGC.
   if (enable_mpf && !serial_mode && mode == FMR_MODE_FM) {
@@ -2114,7 +2152,7 @@ int fmr_chain::flush_tail(hipEvent_t gate) {
   const int rc = enqueue_tail(gate);
   if (rc != FMR_OK)      // the slot of the ring must still be released, or the calls that reuse it wait for a mark that never comes
     hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, tail, &h_marks[1], tail_job.seq);
-  return rc;
+  return rc != FMR_OK ? rc : rc_walk;     // (a walk that could not be enqueued leaves that call's lock flags and PPS events stale: an error of this call)
 }
 int fmr_chain::enqueue_tail(hipEvent_t gate) {
   TailCtx t = tail_job;
@@ -2130,7 +2168,9 @@ int fmr_chain::enqueue_tail(hipEvent_t gate) {
   }
   HIPCHK(hipStreamWaitEvent(tail, ev_pll, 0));
   if (gate) HIPCHK(hipStreamWaitEvent(tail, gate, 0));
+#ifndef FMR_DIAG_NO_TAIL      // (diagnostic builds under tools/: what the step costs without the tail's kernels beside the next front end)
   if (int rc = tail_stage(t, tail)) return rc;
+#endif
   if (t.ht.n) {
     timed_on(tail, "shift_halo", [&] { hipLaunchKernelGGL(k_shift_halo<256>, dim3(t.ht.n, S), dim3(256), 0, tail, t.ht); });
   }
@@ -2500,11 +2540,19 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
   if (!c || stream < 0 || stream >= c->S) return FMR_ERR_BAD_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
   if (int rc = c->sync_all()) return rc;
-  const long long n = c->last_n_if;
+  long long n = c->last_n_if;
   const void *src = nullptr;
   size_t esz = 0;
+  if (which == 5) {       // FMR_FE_STAMPS=1: {start, end [10 ns units of the constant clock], hardware id} per workgroup of the last fused launch
+    if (!c->d_fe_stamps.p || stream != 0) return FMR_ERR_BAD_ARG;
+    n = 3ll * c->fe_stamps_n;        // ... followed by the two stream stamps (one-thread kernels in front of and behind the launch)
+    if ((size_t)(n + 2) * 8 > cap_bytes) return FMR_ERR_CAPACITY;
+    if (n) HIPCHK(hipMemcpy(out, c->d_fe_stamps.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy((char *)out + (size_t)n * 8, c->d_fe_stamps.p + 3 * (size_t)c->kMaxFusedWg * c->S, 16, hipMemcpyDeviceToHost));
+    return n + 2;
+  }
   switch (which) {
-  case 0: src = c->last_if + (size_t)stream * (c->H_if + c->max_if) + c->H_if; esz = sizeof(float2); break;
+  case 0: src = (c->last_if && c->if_valid) ? c->last_if + (size_t)stream * (c->H_if + c->max_if) + c->H_if : nullptr; esz = sizeof(float2); break;
   case 1: src = (c->d_dec.p && c->dec_valid) ? c->d_dec.p + (size_t)stream * c->max_if : nullptr; esz = sizeof(float); break;
   case 2: src = c->d_raw_de.p ? c->d_raw_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
   case 3: src = c->d_base_de.p ? c->d_base_de.p + (size_t)stream * (c->H_a + c->max_if) + c->H_a : nullptr; esz = sizeof(double); break;
@@ -2595,7 +2643,7 @@ int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap) {
   if (!c) return FMR_ERR_BAD_ARG;
   if (int rc = c->sync_all()) return rc;
   int n = 0;
-  if (c->timing == 2 || c->timing == 4) {   // dominant kernel only: one entry per call since the last query
+  if (c->timing == 2 || c->timing == 4 || c->timing == 5) {   // dominant kernel only: one entry per call since the last query
     for (auto &k : c->dom_times) {
       float t = 0.f;
       (void)hipEventElapsedTime(&t, k.a, k.b);

@@ -58,6 +58,8 @@ struct FusedArgs {
   int part_from;                                              // partial sums are needed from this IF index on (k_stats walks the last ~400 blocks)
   const int *wg_blk0;                                         // [gridDim.x]: block that holds the first IF sample of each workgroup's run
   unsigned long long *dbg;                                    // tools/bench_fused.hip: per wave {busy, total} shader cycles of workgroup 0
+  float *mid32;                                               // [workgroup][2][3000]: fp32 copies of mid-ring samples fp16 cannot hold (FusedRing::at32), written and read on the repair paths only
+  unsigned long long *stamps;                                 // FMR_FE_STAMPS=1 (diagnostics): per workgroup {start, end} of the constant 100 MHz clock and the hardware id
 };
 
 #ifndef FUSED_DMA_AUX
@@ -70,10 +72,15 @@ struct FusedArgs {
 #endif
 // The epilogue's stores are plain (write-back through L2), not non-temporal: with 8 bytes per IF sample left, letting L2 gather
 // the lines costs the input stream less than streaming them out in 512-byte pieces (tools/bench_fused.hip: 223 against 231 us).
+// ... and GLOBAL stores, said so: behind the reinterpret_cast to an under-aligned vector type the compiler no longer knew the
+// address space and emitted FLAT stores (rounds 2-5).  A flat instruction counts in lgkmcnt as well as in vmcnt, so the
+// `s_waitcnt lgkmcnt(0)` in front of every epoch's barrier (fused_barrier) was also a wait for the epilogue's stores to pass
+// the address check of the memory pipeline -- where they queue behind the loader's DMA.
+#define FUSED_GPTR(T, p) ((__attribute__((address_space(1))) T *)(p))
 #ifdef FUSED_NT_STORES
-#define FUSED_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#define FUSED_STORE(T, v, p) __builtin_nontemporal_store((v), FUSED_GPTR(T, p))
 #else
-#define FUSED_STORE(v, p) (*(p) = (v))
+#define FUSED_STORE(T, v, p) (*FUSED_GPTR(T, p) = (v))
 #endif
 #ifndef FUSED_B_PRIO
 #define FUSED_B_PRIO 0       // s_setprio of the stage-B / epilogue waves
@@ -117,6 +124,17 @@ struct FusedShape {
   __host__ __device__ static constexpr int pos_of_piece(int p) { return p + p / PADP; }
 };
 
+// the constant 100 MHz clock (wall_clock64() of the HIP headers costs the kernel a private segment)
+__device__ __forceinline__ unsigned long long fused_realtime() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
+// FMR_FE_STAMPS=1: a one-thread kernel in front of and behind the fused launch on its stream: where on the constant clock the
+// stream reached them (the launch's own dispatch time stamps are not on that clock's epoch)
+__global__ void k_fused_stamp(unsigned long long *p) { *p = fused_realtime(); }
+
 // one barrier per epoch.  LDS traffic only: no wave waits here for its global stores, and the loader's DMA stays
 // in flight (a __syncthreads() would drain vmcnt)
 __device__ __forceinline__ void fused_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -132,6 +150,16 @@ struct FusedRing {
     const _Float16 *h = reinterpret_cast<const _Float16 *>(ring + c * SH::PLANE_BYTES), *l = reinterpret_cast<const _Float16 *>(ring + (2 + c) * SH::PLANE_BYTES);
     return (float)h[p] + (float)l[p] * (1.0f / 2048.0f);
   }
+  // ... on the repair paths: a mid sample beyond fp16's range (|y| > 65504: its high term is inf) was also stored as the float
+  // it is, in this workgroup's part of FusedArgs::mid32, by the stage-A wave that produced it (FusedMfmaA::run) -- an epoch
+  // or more ago, behind a vmcnt(0) wait and a barrier; read past the CU's vector cache, which may hold an older line.
+  __device__ __forceinline__ static float at32(const unsigned char *ring, const float *mid32, int c, int s) {
+    s %= SH::MIDR; if (s < 0) s += SH::MIDR;
+    const float v = at(ring, c, s);
+    if (__builtin_isfinite(v)) return v;
+    return __hip_atomic_load(mid32 + c * SH::MIDR + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ static float *mid32_of(const FusedArgs &a) { return a.mid32 + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * SH::MIDR); }
 };
 
 // ---- role: loader ---------------------------------------------------------------------------------------
@@ -314,6 +342,8 @@ struct FusedMfmaA {
     // discriminator's output), so a wave that finds a non-finite output -- rare, wave-uniform -- recomputes its unit with
     // plain fp32 FMAs over the NA taps of every output: outputs whose support holds the bad sample stay non-finite, the
     // others are what the quad form of rounds 2-4 produced (1e-7 from the matrix-core result).
+    // Samples beyond fp16's range (|x| > 65504: un-normalised FLOAT files, FileSource.cpp:514-528) take the same path: their
+    // high term is inf, the products NaN; the fp32 loop below is exact for them.
     if (!(ABL & 1) && __builtin_amdgcn_ballot_w64(!__builtin_isfinite(yo.x + yo.y + yo.z + yo.w)) != 0) {
 #pragma unroll 1
       for (int v = 0; v < 4; v++) {
@@ -324,7 +354,7 @@ struct FusedMfmaA {
           const int sm = sb + t;
           acc = fmaf(a.hA[t], *reinterpret_cast<const float *>(slot + 8 * sm + 16 * (sm / 160) + 4 * C), acc);
         }
-        yo[v] = acc;
+        yo.x = v == 0 ? acc : yo.x; yo.y = v == 1 ? acc : yo.y; yo.z = v == 2 ? acc : yo.z; yo.w = v == 3 ? acc : yo.w;
       }
     }
     if (jE < 0) {                    // (wave-uniform test first: only a call's first epochs reach back)
@@ -339,6 +369,15 @@ struct FusedMfmaA {
     }
     int pos = pos0 + jl0;            // a multiple of 4, like MIDR: the four samples wrap together
     if (pos >= SH::MIDR) pos -= SH::MIDR;
+    // A mid sample the ring's fp16 terms cannot hold (|y| > 65504, or not finite): the wave leaves fp32 copies of its whole
+    // unit for stage B's repair path (FusedRing::at32), which is what such a sample sends every tile that reads it to.  Rare
+    // and wave-uniform; the stores are acknowledged before the epoch's barrier.
+    if (!(ABL & 1) && a.mid32 && __builtin_amdgcn_ballot_w64(!(fmaxf(fmaxf(fabsf(yo.x), fabsf(yo.y)), fmaxf(fabsf(yo.z), fabsf(yo.w))) < 65000.f)) != 0) {
+      float *m32 = FusedRing::mid32_of(a) + C * SH::MIDR + pos;
+#pragma unroll
+      for (int v = 0; v < 4; v++) __hip_atomic_store(m32 + v, yo[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     {
       // into the ring as fp16 terms (high, 2048 x low): what stage B multiplies.  The four samples may straddle the end of a
       // period (125 is odd): four 2-byte stores per plane.
@@ -450,7 +489,8 @@ struct FusedB16 {
     float r = y[3];
     if ((n >> 1) == 0 && kq == 3 && !__builtin_isfinite(r)) {          // (the tile's own repair path, for this one sample)
       r = 0.f;
-      for (int j = 0; j < 210; j++) r = fmaf(a.hB_last[j], FusedRing::at(ring, n & 1, p - 3 + j), r);
+      const float *m32 = FusedRing::mid32_of(a);
+      for (int j = 0; j < 210; j++) r = fmaf(a.hB_last[j], FusedRing::at32(ring, m32, n & 1, p - 3 + j), r);
     }
     if ((n >> 1) == 0 && kq == 3) out[n & 1] = r;
   }
@@ -474,11 +514,11 @@ struct FusedB16 {
 #pragma unroll 1
         for (int v = 0; v < 4; v++) {
           const int pp = 16 * MT0 + 4 * kq + v, phi = (pp * 125) % 48, s0 = p + (n >> 1) * 125 + off(pp);
-          const float *hr = a.hB + phi * 210;
+          const float *hr = a.hB + phi * 210, *m32 = FusedRing::mid32_of(a);
           float r = 0.f;
 #pragma unroll 1
-          for (int j = 0; j < 210; j++) r = fmaf(hr[j], FusedRing::at(ring, n & 1, s0 + j), r);
-          y[v] = r;
+          for (int j = 0; j < 210; j++) r = fmaf(hr[j], FusedRing::at32(ring, m32, n & 1, s0 + j), r);
+          y.x = v == 0 ? r : y.x; y.y = v == 1 ? r : y.y; y.z = v == 2 ? r : y.z; y.w = v == 3 ? r : y.w;       // (y[v] with a run-time v went through scratch memory)
         }
       }
       float *sf = reinterpret_cast<float *>(stage);
@@ -598,16 +638,16 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
     if (va && vc) {
       // 8 bytes per IF sample in the product configuration (MPX + |x|^2): what the stores cost is their bytes -- every one
       // queues behind the loader's DMA (tools/bench_fused.hip: 16 B per sample 27 us of the launch, 8 B 10 us, 4 B 4 us)
-      if (ABL & 1024) __builtin_nontemporal_store((v4f){d0, d1, e0, e1}, reinterpret_cast<v4f_u *>(ns + 2 * ka));      // (harness: what ONE 16-byte store costs)
+      if (ABL & 1024) __builtin_nontemporal_store((v4f){d0, d1, e0, e1}, FUSED_GPTR(v4f_u, ns + 2 * ka));      // (harness: what ONE 16-byte store costs)
       else {
-      FUSED_STORE(((v2f){d0, d1}), reinterpret_cast<v2f_u *>(bs + ka));
-      if (ns && !(ABL & 512)) FUSED_STORE(((v2f){e0, e1}), reinterpret_cast<v2f_u *>(ns + ka));
+      FUSED_STORE(v2f_u, ((v2f){d0, d1}), bs + ka);
+      if (ns && !(ABL & 512)) FUSED_STORE(v2f_u, ((v2f){e0, e1}), ns + ka);
       }
-      if (os) __builtin_nontemporal_store(xx, reinterpret_cast<v4f_u *>(os + ka));
+      if (os) __builtin_nontemporal_store(xx, FUSED_GPTR(v4f_u, os + ka));
       if (a.dec) { float *pd = a.dec + (long long)s * a.dec_stride + ka; pd[0] = d0; pd[1] = d1; }
     } else {
-      if (va) { bs[ka] = d0; if (ns) ns[ka] = e0; if (os) os[ka] = x0; if (a.dec) a.dec[(long long)s * a.dec_stride + ka] = d0; }
-      if (vc) { bs[kc] = d1; if (ns) ns[kc] = e1; if (os) os[kc] = x1; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
+      if (va) { bs[ka] = d0; if (ns) ns[ka] = e0; if (os) *FUSED_GPTR(v2f, os + ka) = (v2f){x0.x, x0.y}; if (a.dec) a.dec[(long long)s * a.dec_stride + ka] = d0; }
+      if (vc) { bs[kc] = d1; if (ns) ns[kc] = e1; if (os) *FUSED_GPTR(v2f, os + kc) = (v2f){x1.x, x1.y}; if (a.dec) a.dec[(long long)s * a.dec_stride + kc] = d1; }
     }
   }
   if (ka == a.n_if - 1) { a.st[s].disc_save_next = ph0; a.st[s].disc_save_valid = 1; }
@@ -694,7 +734,9 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
         for (int t = 0; t < 2; t++) {
           const int idx = 128 * MT0 + t * 64 + lane;
           const int k = kb + idx;
-          if (k >= 0 && k < a.n_if) os[k] = stage[idx];
+          // (a plain vector type: float2's assignment operator takes a generic `this` and would bring the flat store back)
+          typedef float v2f_ __attribute__((ext_vector_type(2)));
+          if (k >= 0 && k < a.n_if) *FUSED_GPTR(v2f_, os + k) = *reinterpret_cast<const v2f_ *>(stage + idx);
         }
       }
       kb += 384; tile_g++;
@@ -759,6 +801,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a) {
   const float2 *xs = a.iq + (long long)s * a.iq_stride;
   const float2 *hs = a.in_halo + (long long)s * a.H_in;
 
+  if (a.stamps && threadIdx.x == 0) {
+    const size_t w = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.stamps[3 * w] = fused_realtime();
+    a.stamps[3 * w + 2] = ((unsigned long long)xcc << 32) | hw;
+  }
   if (wave == 0) {
     // ------------------------------------------------------------------ loader
     // cy[k]: DMA instructions of the batch issued k+1 epochs ago ... the batches younger than the one needed next
@@ -795,6 +845,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { a.dbg[0] = busy; a.dbg[1] = FUSED_CLK() - t_begin; }
+    if (a.stamps && lane == 0) a.stamps[3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = fused_realtime();
   } else if (wave == 1) {
     // ------------------------------------------------------------------ stage B (one row tile per wave) + a third of the epilogue
     fused_role_b<SH::EPT, 0, 0, (ABL & 2) != 0, (ABL & 32) != 0, ABL>(a, s, i0, t3, nt, NE, midr, stage, lane, wave);

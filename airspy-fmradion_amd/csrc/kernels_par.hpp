@@ -408,8 +408,9 @@ __device__ __forceinline__ void agc_node_pass(const int s, float *__restrict__ n
   // identity carry in parallel, chain the NW segment maps and replay with the true carries (as k_dc_nodes).
   __shared__ double segA[16], segB[16];
   __shared__ double pass_end;
-  __shared__ float wmax[16];
+  __shared__ float wmax[16], wcut[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  float cut = 0.f;
   float *nd = nodes + (long long)s * (nc + 1);
   const float *g = G + (long long)s * nc;
   const double *m = M + (long long)s * nc;
@@ -472,6 +473,7 @@ __device__ __forceinline__ void agc_node_pass(const int s, float *__restrict__ n
       if (c < nc) {
         nd[c + 1] = vf;
         maxrel = fmaxf(maxrel, fabsf(vf - oldn[j]) / fmaxf(fabsf(vf), 1e-30f));
+        if (a[j] == 0.0) cut = 1.f;          // the chunk ran into the gain clamp or the non-finite reset (k_agc_round: dg = 0)
       }
     }
     if (wv == NW - 1 && lane == 63) { pass_end = (double)(float)(sa * cw + sb); old_next = oldn[K - 1]; }
@@ -480,11 +482,11 @@ __device__ __forceinline__ void agc_node_pass(const int s, float *__restrict__ n
     __syncthreads();
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) maxrel = fmaxf(maxrel, __shfl_xor(maxrel, o, 64));
-  if (lane == 0) wmax[wv] = maxrel;
+  for (int o = 32; o > 0; o >>= 1) { maxrel = fmaxf(maxrel, __shfl_xor(maxrel, o, 64)); cut = fmaxf(cut, __shfl_xor(cut, o, 64)); }
+  if (lane == 0) { wmax[wv] = maxrel; wcut[wv] = cut; }
   __syncthreads();
   if (threadIdx.x == 0)
-    for (int u = 1; u < NW; u++) maxrel = fmaxf(maxrel, wmax[u]);
+    for (int u = 1; u < NW; u++) { maxrel = fmaxf(maxrel, wmax[u]); cut = fmaxf(cut, wcut[u]); }
   if (threadIdx.x != 0) return;
   {
     if (fl[s].agc_iters < 16) fl[s].agc_hist[fl[s].agc_iters] = maxrel;
@@ -510,10 +512,12 @@ __device__ __forceinline__ void agc_node_pass(const int s, float *__restrict__ n
     // model of this recurrence over noise levels 1e-3 ... 1e-1 (tools/agc_round_model.py: movement 1.0e-3 -> error 8.5e-7,
     // 5.3e-3 -> 3.2e-5, 1.1e-2 -> 1.6e-4), so <= 5e-6 here, a tenth of what the later rounds are accepted at and below the
     // 3e-5 they stagnate at.  A second round could only measure that: it was 0.08-0.1 ms of the side stream for every call
-    // of a noisy input (sigma 1e-2: movement 2.8e-4) or behind the IF filter (5.8e-5).
+    // of a noisy input (sigma 1e-2: movement 2.8e-4) or behind the IF filter (5.8e-5).  The model is of the smooth recurrence:
+    // a call in which some chunk ran into the gain clamp or the non-finite reset (the discontinuous branches, dg = 0) takes
+    // its second round.
     const float tight = gain_invariant ? 1.0e-6f : 1.5e-7f;
     if (maxrel <= tight || (gain_invariant && (fl[s].agc_iters >= 2 || gain_invariant == 2) && maxrel <= 5.0e-5f) ||
-        (gain_invariant == 2 && fl[s].agc_iters == 1 && maxrel <= 2.0e-3f) ||
+        (gain_invariant == 2 && fl[s].agc_iters == 1 && maxrel <= 2.0e-3f && cut == 0.f) ||
         (!gain_invariant && fl[s].agc_iters >= 3 && maxrel <= 1.0e-6f)) {   // gains of the last shoot pass stand
       fl[s].agc_converged = 1;
       st[s].agc_gain = nd[nc];
@@ -526,7 +530,7 @@ __device__ __forceinline__ void agc_node_pass(const int s, float *__restrict__ n
 // all its waves while the PLL's first pass holds the chip (0.1 ms of waiting per round, measured: 1024 threads 0.125 ms per
 // round, 256 threads 0.087, 64 threads -- a one-wave node pass -- 0.166).
 template <int C, class XT>
-__global__ __launch_bounds__(1024) void k_agc_round(const XT *__restrict__ x, long long x_stride, int x_off, int n,
+__global__ __launch_bounds__(256) void k_agc_round(const XT *__restrict__ x, long long x_stride, int x_off, int n,
                                                     float *__restrict__ gain, long long g_stride, float *__restrict__ nodes,
                                                     float *G, double *M, int nc, float initial_gain, float max_gain,
                                                     float rate, StreamState *st, IterFlags *fl, int gain_invariant,
@@ -571,11 +575,12 @@ __global__ __launch_bounds__(1024) void k_agc_round(const XT *__restrict__ x, lo
 
 __global__ void k_iter_begin(IterFlags *fl, float *__restrict__ agc_nodes, int agc_nc, const StreamState *st,
                              int n_streams, unsigned long long *__restrict__ pll_sync, int sync_words,
-                             unsigned int *__restrict__ pll_tick2, int n_tick2) {
+                             unsigned int *__restrict__ pll_tick2, int n_tick2, unsigned int *__restrict__ agc_tick) {
   const int s = blockIdx.x;
   if (s >= n_streams) return;
   if (threadIdx.x == 0) {
     fl[s] = IterFlags{};
+    if (agc_tick) agc_tick[s] = 0u;        // k_agc_round's last-arrival ticket: left at zero by a launch that completes, not by one that was aborted
     if (agc_nodes) agc_nodes[(long long)s * (agc_nc + 1)] = st[s].agc_gain;
   }
   // the PLL rounds' tickets and maximum slots (PllSync) are left at zero by the kernels that use them; a call that

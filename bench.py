@@ -425,7 +425,10 @@ def main():
     # stream); the host never synchronises inside the region, so launches run ahead of the GPU.
     # (from 8 steps on the events go on every fourth step: the two markers around a stage kernel cost 7-10 us on the decoder
     # stream -- measured with and without them, 0.5787 / 0.5792 / 0.5807 against 0.5685 / 0.5737 ms per step)
-    ev_mode = 0 if args.no_region_events else (4 if args.steps >= 8 else 2)
+    # round 6: the fused front end is timed on EVERY step with the start / stop events of its own dispatch (mode 5: no
+    # markers on the stream for it); the other stage kernels (the configurations without the fused discriminator) keep
+    # their marker pairs on every fourth step
+    ev_mode = 0 if args.no_region_events else (5 if args.steps >= 8 else 2)
     ch.enable_kernel_timing(ev_mode)
     if world > 1:
         dist.barrier()
@@ -446,10 +449,26 @@ def main():
         region.setdefault(name, []).append(ms)
     if ev_mode == 2:
         assert all(len(v) == args.steps for v in region.values()), {k: len(v) for k, v in region.items()}
-    elif ev_mode == 4:
-        assert region and all(args.steps // 4 <= len(v) <= args.steps // 4 + 1 for v in region.values()), {k: len(v) for k, v in region.items()}
+    elif ev_mode == 5:
+        assert region and all(args.steps // 4 <= len(v) <= args.steps // 4 + 1 or (k == "ifr_fused" and len(v) == args.steps)
+                              for k, v in region.items()), {k: len(v) for k, v in region.items()}
     if os.environ.get("FMR_BENCH_SERIES") and rank == 0:      # diagnostics: the stage kernels' launch-by-launch durations
         json.dump({k: [round(float(x), 5) for x in v] for k, v in region.items()}, open(os.environ["FMR_BENCH_SERIES"], "w"))
+    if os.environ.get("FMR_FE_STAMPS") and rank == 0:          # diagnostics: where the last timed front-end launch spent its time, workgroup by workgroup
+        raw = ch.debug_read(5)
+        before, after = int(raw[-2]), int(raw[-1])
+        stp = raw[:-2].reshape(-1, 3)
+        t_s, t_e = stp[:, 0].astype(np.int64), stp[:, 1].astype(np.int64)
+        rel_s, rel_e, dur = (t_s - t_s.min()) * 0.01, (t_e - t_s.min()) * 0.01, (t_e - t_s) * 0.01      # us (100 MHz clock)
+        xcc = (stp[:, 2] >> np.uint64(32)).astype(np.int64) & 0xf
+        pc = lambda v: [round(float(np.percentile(v, q)), 1) for q in (0, 10, 50, 90, 99, 100)]
+        print("[fe stamps] workgroups %d  start offset us (min p10 p50 p90 p99 max) %s  duration %s  end %s" %
+              (len(stp), pc(rel_s), pc(dur), pc(rel_e)), file=sys.stderr)
+        print("[fe stamps] stream stamp in front of the launch -> first workgroup %.1f us; last workgroup's end -> stream stamp behind the launch %.1f us" %
+              ((int(t_s.min()) - before) * 0.01, (after - int(t_e.max())) * 0.01), file=sys.stderr)
+        late = np.argsort(rel_e)[-8:]
+        print("[fe stamps] last to end: " + ", ".join("wg %d xcc %d start %.1f dur %.1f end %.1f" % (w, xcc[w], rel_s[w], dur[w], rel_e[w]) for w in late), file=sys.stderr)
+        print("[fe stamps] per XCC mean duration: " + ", ".join("%d: %.1f (n %d)" % (x, dur[xcc == x].mean(), int((xcc == x).sum())) for x in sorted(set(xcc.tolist()))), file=sys.stderr)
     st = ch.status(0)
     # The host's own cost per call.  Inside the timed loop the host runs ahead of the GPU until the chain's eight table
     # slots are taken and is then paced by the GPU: over a long loop t_enq / steps converges to ms_per_step whatever the
@@ -581,6 +600,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic[0], "traffic_source": pmc_traffic[1],
                          "avg_launch_ms": round(dec_ms, 5), "launches_timed": (len(region.get(dom_name, [])) or None),
+                         "timed_with": ("HIP events inside the timed region, on the stream the kernel runs on: " +
+                                        ("the start / stop events of the kernel's own dispatch (hipExtLaunchKernelGGL), every timed step"
+                                         if dom_name == "ifr_fused" and not os.environ.get("FMR_EVT_MARKERS") else
+                                         "an event marker before and after the launch")),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "box_streaming_read": None if box_read <= 0 else {"GB/s": round(box_read, 1), "frac_of_peak": round(box_read / HBM_PEAK_GBS, 4),
                                                 "kernel_vs_box": round(achieved / box_read, 4) if box_read > 0 else None,
@@ -653,7 +676,7 @@ def r8b_leg(fmr, iq, audio, n, blk, B, device, steps=10, warmup=3):
     for _ in range(warmup):
         step()
     ch.synchronize()
-    ch.enable_kernel_timing(4)
+    ch.enable_kernel_timing(5)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -233,7 +233,10 @@ int fmr_get_multipath_coefficients(fmr_chain *c, int stream, float *coeff, int c
  * most recent call to the host.  which: 0 = IF samples entering the decoder
  * (complex float, 2 floats each), 1 = discriminator output (float),
  * 2 = stereo difference after demod+de-emphasis (double), 3 = mono after
- * de-emphasis (double), 4 = AGC gain sequence (float).  Returns element count. */
+ * de-emphasis (double), 4 = AGC gain sequence (float).  Returns element count, or FMR_ERR_BAD_ARG for a
+ * tap the most recent call did not leave in memory: behind the fused front end's discriminator epilogue (FM at
+ * 10 MS/s without IF filter / equaliser) taps 0, 1 and 4 exist only in a chain created with FMR_DEBUG_TAPS=1 in the
+ * environment -- the product keeps those signals on chip. */
 long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t cap_bytes);
 
 /* Kernel timing with HIP events on the chain's own streams.  enable = 1: every kernel of
@@ -241,8 +244,11 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
  * kernels of the FIR + discriminator stage ("ifr_fused", or "ifr_decim" / "ifr_poly" / "disc", and the IF FIR
  * "fm_block" of an FM chain), one entry per launch accumulated until queried
  * (what bench.py uses inside its timed region); enable = 4: the same on every fourth call only (the two event
- * markers of a stage kernel cost 7-10 us on the decoder stream: bench.py samples).  Fills names/ms for up to cap
- * entries, returns the count. */
+ * markers of a stage kernel cost 7-10 us on the decoder stream: bench.py samples); enable = 5: as 4, and the fused front
+ * end ("ifr_fused") on EVERY call.  The fused front end is timed with the start / stop events of its own dispatch
+ * (hipExtLaunchKernelGGL: the command processor's time stamps of the kernel's begin and end, what rocprofv3's kernel
+ * trace reads; no marker packets on the stream), the other kernels between two event markers on their stream.
+ * Fills names/ms for up to cap entries, returns the count. */
 int fmr_get_kernel_times(fmr_chain *c, const char **names, float *ms, int cap);
 void fmr_enable_kernel_timing(fmr_chain *c, int enable);
 

@@ -133,7 +133,7 @@ def test_equaliser_waits_for_a_late_agc_kernel(pilotcut, monkeypatch, late_ms):
     fs, blk, nblk, batch = 384e3, 2517, 160, 8
     x = siggen.two_ray(siggen.fm_stereo_iq(nblk * blk, fs), 20)
     monkeypatch.setenv("FMR_TEST_AGC_LATE", str(late_ms))
-    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, stereo=True, multipath_stages=8, max_block_len=blk, max_blocks=batch)
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, stereo=True, multipath_stages=8, max_block_len=blk, max_blocks=batch, ab=True)
     fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 8, pilotcut)
     got, ref = [], []
     for i in range(0, nblk, batch):
@@ -155,7 +155,7 @@ def test_equaliser_reports_an_agc_kernel_that_never_runs(pilotcut, monkeypatch):
     fs, blk, batch = 384e3, 2517, 8
     x = siggen.two_ray(siggen.fm_stereo_iq(120 * blk, fs), 20)
     monkeypatch.setenv("FMR_TEST_AGC_LATE", "0")
-    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, stereo=True, multipath_stages=8, max_block_len=blk, max_blocks=batch)
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, stereo=True, multipath_stages=8, max_block_len=blk, max_blocks=batch, ab=True)
     fm = ora.FmDecoder(False, fmr.DELAY_3TAPS, True, 50.0, False, 8, pilotcut)
     # the equaliser starts after 100 warm-up blocks (FmDecode.cpp:107-110): 13 healthy calls first
     for i in range(0, 13 * batch, batch):
@@ -165,7 +165,7 @@ def test_equaliser_reports_an_agc_kernel_that_never_runs(pilotcut, monkeypatch):
             fm.process(b)
     ch.close()
     monkeypatch.setenv("FMR_TEST_AGC_LATE", "-1")
-    bad = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, stereo=True, multipath_stages=8, max_block_len=blk, max_blocks=batch)
+    bad = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, stereo=True, multipath_stages=8, max_block_len=blk, max_blocks=batch, ab=True)
     with pytest.raises(fmr.FmrError, match="gave up waiting for the AGC"):
         for i in range(0, 14 * batch, batch):
             bad.process_blocks(x[None, i * blk:(i + batch) * blk], [blk] * batch)
@@ -413,9 +413,9 @@ def test_launch_structure_switches_do_not_change_the_result(knobs, monkeypatch):
     x = siggen.fm_stereo_iq(n, 10e6, stream_id=3)[None, :]
     calls = [lens[0:3], lens[3:40], lens[40:41], lens[41:90], lens[90:140]]
 
-    def run():
+    def run(ab=False):
         ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, n_streams=1,
-                       max_block_len=65536, max_blocks=50)
+                       max_block_len=65536, max_blocks=50, ab=ab)
         out, alens, st, pos = [], [], [], 0
         for ll in calls:
             m = sum(ll)
@@ -430,7 +430,7 @@ def test_launch_structure_switches_do_not_change_the_result(knobs, monkeypatch):
     a, al_a, st_a = run()
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
-    b, al_b, st_b = run()
+    b, al_b, st_b = run(ab=True)           # (the switch is read by the A/B partner library only)
     assert st_a[-1][0] == 1 and st_a[-1][2] == 0 and st_b[-1][2] == 0        # locked, no serial fallback at the end
     assert al_a == al_b and st_a == st_b
     assert rms(a - b) < 1e-7

@@ -30,7 +30,7 @@ def _run(env_v1, xs, calls):
     try:
         S = xs.shape[0]
         ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=384e3, enable_resampler=False, stereo=True, n_streams=S,
-                       max_block_len=8192, max_blocks=64)
+                       max_block_len=8192, max_blocks=64, ab=bool(env_v1))
         audio, meta = [], []
         pos = 0
         for ll in calls:
