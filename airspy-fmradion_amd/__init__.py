@@ -34,7 +34,7 @@ EXPORTS = [
     "fmr_create", "fmr_destroy", "fmr_last_error", "fmr_version", "fmr_resampler_info", "fmr_process",
     "fmr_process_blocks", "fmr_process_blocks_device", "fmr_synchronize", "fmr_resample", "fmr_get_status",
     "fmr_get_pps_events", "fmr_get_multipath_coefficients", "fmr_debug_read", "fmr_get_kernel_times",
-    "fmr_probe_read_bandwidth", "fmr_get_kernel_trace",
+    "fmr_probe_read_bandwidth", "fmr_probe_shader_clock", "fmr_get_kernel_trace",
     "fmr_enable_kernel_timing", "fmr_filter_table", "fmr_fourth_convert", "fmr_design_taps", "fmr_design_taps_class",
     "fmr_host_alloc", "fmr_host_free", "fmr_create_sized", "fmr_get_status_sized",
 ]
@@ -184,6 +184,18 @@ def design_taps_class(in_rate, out_rate, resampler_class, stage):
     d = dict(zip(["D", "NA", "LB", "MB", "TB", "LT"], [int(v) for v in info]))
     rows = d["LT"] + 1 if d["LT"] else d["LB"]
     return (buf.reshape(rows, d["TB"]) if stage else buf), d
+
+
+def probe_shader_clock(device=0):
+    """The shader clock of the device right now [MHz] (a 20 us count on one wave)."""
+    out = C.c_double(0.0)
+    L = lib()
+    L.fmr_probe_shader_clock.restype = C.c_int
+    L.fmr_probe_shader_clock.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    rc = L.fmr_probe_shader_clock(int(device), C.byref(out))
+    if rc != 0:
+        raise FmrError(f"fmr_probe_shader_clock failed ({rc}): {L.fmr_last_error().decode()}")
+    return out.value
 
 
 def probe_read_bandwidth(device, dev_ptr, nbytes, reps=5):

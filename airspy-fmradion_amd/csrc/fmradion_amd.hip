@@ -117,6 +117,12 @@ struct EnvKnobs {
   bool fe_stamps = false;       // FMR_FE_STAMPS=1    diagnostics: every front-end workgroup leaves its start / end time and hardware id (fmr_debug_read 5)
   bool evt_markers = false;     // FMR_EVT_MARKERS=1  diagnostics: time the fused front end between two event MARKERS on its stream (rounds 1-5) instead of
                                 //                    with the start / stop events of its own dispatch
+#ifdef FMR_DIAG_KNOBS           // (diagnostic builds under tools/ only: what an A/B run varies without a rebuild)
+  int x_spare_aside = -1;       // FMR_X_SPARE_ASIDE=n  the PLL's spare rounds go to the side stream for calls of <= n blocks
+  int x_cpll = 0;               // FMR_X_CPLL=n         PLL chunk length
+#else
+  static constexpr int x_spare_aside = -1, x_cpll = 0;
+#endif
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
   void load() {
@@ -129,6 +135,9 @@ struct EnvKnobs {
     test_agc_late = num("FMR_TEST_AGC_LATE", 0); pll_v1 = set("FMR_PLL_V1");
 #endif
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
+#ifdef FMR_DIAG_KNOBS
+    x_spare_aside = num("FMR_X_SPARE_ASIDE", -1); x_cpll = num("FMR_X_CPLL", 0);
+#endif
   }
 };
 
@@ -368,8 +377,19 @@ struct fmr_chain {
   }
 
   // ---- kernel launch with optional HIP-event timing on the chain's stream ----
+  // FMR_FE_STAMPS=1: where on the constant clock a stream reached the end of one of its kernels, in a ring of eight calls
+  // (slot 16 (call_seq % kStampCalls) + id behind the workgroup stamps; id 0 / 1: in front of / behind the fused launch; a second
+  // ring of the same shape behind the first holds the shader clock [kHz] the stamp in front of the launch measured)
+  static constexpr int kStampCalls = 32;
+  unsigned long long *stamp_slot(int id) { return d_fe_stamps.p + 3 * (size_t)kMaxFusedWg * S + 16 * (size_t)(call_seq % kStampCalls) + id; }
+  void stamp_after(hipStream_t st, const char *name) {
+    static const char *const ids[] = {"", "", "deemph_decim", "aud_poly", "pilotcut", "dc_pass1", "fm_out", "pll", "stats", "if_agc", "pll_commit", "pll_finish", "pll_shoot_jac"};
+    for (int i = 2; i < 13; i++)
+      if (std::strcmp(name, ids[i]) == 0) { hipLaunchKernelGGL(k_fused_stamp, dim3(1), dim3(1), 0, st, stamp_slot(i), 0); return; }
+  }
   template <class F>
-  void timed_on(hipStream_t st, const char *name, F &&launch) {
+  void timed_on(hipStream_t st, const char *name, F &&launch_) {
+    auto launch = [&] { launch_(); if (d_fe_stamps.p) stamp_after(st, name); };
     // mode 2: only the kernels of the FIR+discriminator stage carry events (two per kernel per call)
     const bool stage_kernel = std::strcmp(name, "ifr_decim") == 0 || std::strcmp(name, "ifr_poly") == 0 ||
                               std::strcmp(name, "disc") == 0 || std::strcmp(name, "ifr_fused") == 0 ||
@@ -521,6 +541,7 @@ struct fmr_chain {
     int *stereo_blk = nullptr;
     long long N_if{}, N_au{}, a_top0{}, amA_prev{}, akB_prev{}, astride{};
     int nb{}, count_am{}, de_tout{}, dc_nc{}, nch{};
+    int au_max{};                // longest audio block of the call
     bool de_fused{}, fin_on_side{}, fin_covers_all{}, agc_on_side{}, mono_enqueued{};
     bool can_split{};            // the mono channel can be enqueued by itself (the shapes the per-channel tail kernels take)
     hipEvent_t ev_mpx = nullptr; // "the MPX of this call is there" (pipelined chain: what a drained tail's mono channel waits for)
@@ -569,6 +590,7 @@ static int upload(DevBuf<T> &b, const T *src, size_t n) {
 
 int fmr_chain::init(const fmr_config *c) {
   env.load();
+  if (env.x_cpll >= C_PLL_MIN) c_pll = env.x_cpll;
   cfg = *c;
   S = c->n_streams;
   mode = c->mode;
@@ -845,7 +867,7 @@ int fmr_chain::init(const fmr_config *c) {
   if ((rc = d_dec.alloc((size_t)S * max_if))) return rc;
   if (fused_ok && (rc = d_fused_part.alloc((size_t)S * 3 * (max_if / 384 + 4)))) return rc;
   if (fused_ok && (rc = d_fused_mid32.alloc((size_t)std::max(std::max(n_cu, S), 256) * 2 * FusedShape<kFusedD, kFusedNA>::MIDR))) return rc;
-  if (fused_ok && env.fe_stamps && (rc = d_fe_stamps.alloc(3 * (size_t)kMaxFusedWg * S + 2))) return rc;
+  if (fused_ok && env.fe_stamps && (rc = d_fe_stamps.alloc(3 * (size_t)kMaxFusedWg * S + 2 * kStampCalls * 16))) return rc;
   if ((rc = d_if_rms_blk.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_bb_mean_blk.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_bb_rms_blk.alloc((size_t)S * max_blocks))) return rc;
@@ -1418,6 +1440,9 @@ int fmr_chain::run_tables(CallCtx &k) {
     const int fe_dflt = pipelined ? std::max(8, n_cu - kFeSpareCus) : n_cu;
     const int fe_cus = (pipelined && env.fe_cus > 0) ? std::min(env.fe_cus, n_cu) : fe_dflt;
     const int wg_per_stream = std::max(1, std::min(kMaxFusedWg, fe_cus / S));
+    // (ceil(n / grid) macro tiles for all but the last workgroup.  Balanced runs -- n mod grid workgroups with one tile more --
+    // were measured in round 6: 248 instead of 245 workgroups at 2^27 samples, and the launch 5 us LONGER in the chain: the
+    // three compute units more that the uneven split leaves free serve the kernels beside it)
     fused_tiles_per_wg = (fused_n_tiles + wg_per_stream - 1) / wg_per_stream;
     fused_grid = (fused_n_tiles + fused_tiles_per_wg - 1) / fused_tiles_per_wg;
     fe_spare_cus = std::max(0, n_cu - fused_grid * S);
@@ -1536,7 +1561,7 @@ int fmr_chain::run_tables(CallCtx &k) {
     if (d_fe_stamps.p) { a.stamps = d_fe_stamps.p; fe_stamps_n = grid * S; }
     if ((size_t)grid * S * 2 * FusedShape<D, NA>::MIDR > d_fused_mid32.n) { set_err("internal capacity exceeded (fused workgroups)"); return FMR_ERR_CAPACITY; }
     a.mid32 = d_fused_mid32.p;
-    if (d_fe_stamps.p) hipLaunchKernelGGL(k_fused_stamp, dim3(1), dim3(1), 0, fes, d_fe_stamps.p + 3 * (size_t)kMaxFusedWg * S);
+    if (d_fe_stamps.p) hipLaunchKernelGGL(k_fused_stamp, dim3(1), dim3(1), 0, fes, stamp_slot(0), 16 * kStampCalls);
     timed_on(fes, "ifr_fused", [&] {
       if (ext_a) {      // (timed with the events of its own dispatch)
         if (par) hipExtLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, ext_a, ext_b, 0, a);
@@ -1546,7 +1571,7 @@ int fmr_chain::run_tables(CallCtx &k) {
       if (par) hipLaunchKernelGGL((k_ifr_fused<D, NA, 1, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, a);
       else hipLaunchKernelGGL((k_ifr_fused<D, NA, 0, 0>), dim3(grid, S), dim3(FUSED_THREADS), kLds, fes, a);
     });
-    if (d_fe_stamps.p) hipLaunchKernelGGL(k_fused_stamp, dim3(1), dim3(1), 0, fes, d_fe_stamps.p + 3 * (size_t)kMaxFusedWg * S + 1);
+    if (d_fe_stamps.p) hipLaunchKernelGGL(k_fused_stamp, dim3(1), dim3(1), 0, fes, stamp_slot(1), 0);
     fused_kb_ref = a.kb_ref;
     if (pipelined) {
       // The PLL stage starts from here.  What the front-end stage carries into its next call -- the input history, the
@@ -1764,7 +1789,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
       // lock logic on the same stream.  Not with one long stream: there the side stream -- lock logic over 2048 blocks in
       // one wave, the AGC's rounds -- is as long as the step already, and five more launches on it hold the next call's
       // tables back (0.517 -> 0.539).
-      const bool spare_aside = pipelined && !env.pll_v1 && nb <= kSpareAsideMaxBlocks;
+      const bool spare_aside = pipelined && !env.pll_v1 && nb <= (env.x_spare_aside >= 0 ? env.x_spare_aside : kSpareAsideMaxBlocks);
       for (int it = 0; it < pll_iters; it++) {
         if (spare_aside && it == 2 && !spare_moved) { (void)hipEventRecord(ev_pll1, stream); (void)hipStreamWaitEvent(side, ev_pll1, 0); spare_moved = true; ps = side; }
         // round 0 integrates the sensitivities too; later rounds reuse them (chord Newton: measured
@@ -1963,6 +1988,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   t.base = k.base; t.raw = k.raw; t.stereo_blk = k.stereo_blk; t.N_if = N_if; t.N_au = N_au; t.nb = nb; t.bt = bt;
   t.d_aud = d_aud; t.astride = (long long)astride; t.amA_prev = amA_prev; t.akB_prev = akB_prev;
   t.nch = stereo ? 2 : 1;
+  for (int b = 0; b < nb; b++) t.au_max = std::max(t.au_max, t_au_len[b]);
   t.count_am = (int)(arsc.mA - amA_prev);
   if ((size_t)t.count_am > max_amid || (size_t)N_au > max_au) { set_err("internal audio capacity exceeded"); return FMR_ERR_CAPACITY; }
   t.a_top0 = (long long)ars.D * amA_prev + ars.ca() - an_prev;
@@ -2034,7 +2060,7 @@ void fmr_chain::tail_channels(const TailCtx &t, hipStream_t st, int ch_base, int
     if (count_am > 0) {
       timed_on(st, "deemph_decim", [&] {
         const int tiles = (count_am + de_tout - 1) / de_tout;
-        const size_t lds = sizeof(double) * (size_t)(DE_SLOTS + DE_SLOTS / 16 + 1);
+        const size_t lds = sizeof(double) * (size_t)(DE_BLOCK * FMR_DE_RUN + 1);      // (an even run length carries a pad word: de_idx)
         auto go = [&](auto kern) {
           hipLaunchKernelGGL(kern, dim3(tiles, S, nch_l), dim3(DE_BLOCK), lds, st, t.base, t.raw, base_stride, H_b,
                              (int)N_if, deemph.b0, deemph.a1, de_scan, 1, (int)(stereo && !pilot_shift), d_ahA.p,
@@ -2083,7 +2109,12 @@ void fmr_chain::tail_channels(const TailCtx &t, hipStream_t st, int ch_base, int
       }
     });
     timed_on(st, "pilotcut", [&] {
-      if (n_pilotcut <= FMR_PCUT_MAXTAPS)
+      // (a 65536-sample block is 314 or 315 audio samples: the one-tile form takes 4.6 KB of LDS instead of 12.3, and thirteen
+      // instead of five of its workgroups fit beside a PLL pass on a compute unit)
+      if (n_pilotcut <= FMR_PCUT_MAXTAPS && t.au_max <= 320)
+        hipLaunchKernelGGL((k_pilotcut2<320, 320>), dim3(nb, S, nch_l), dim3(320), 0, st, d_a10.p, d_a11.p,
+                           a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au, 1.0, ch_base);
+      else if (n_pilotcut <= FMR_PCUT_MAXTAPS)
         hipLaunchKernelGGL((k_pilotcut2<320, 1280>), dim3(nb, S, nch_l), dim3(320), 0, st, d_a10.p, d_a11.p,
                            a1_stride, H_pc, bt, d_pilotcut.p, n_pilotcut, d_pc0.p, d_pc1.p, (long long)max_au, 1.0, ch_base);
       else
@@ -2545,11 +2576,13 @@ long long fmr_debug_read(fmr_chain *c, int stream, int which, void *out, size_t 
   size_t esz = 0;
   if (which == 5) {       // FMR_FE_STAMPS=1: {start, end [10 ns units of the constant clock], hardware id} per workgroup of the last fused launch
     if (!c->d_fe_stamps.p || stream != 0) return FMR_ERR_BAD_ARG;
-    n = 3ll * c->fe_stamps_n;        // ... followed by the two stream stamps (one-thread kernels in front of and behind the launch)
-    if ((size_t)(n + 2) * 8 > cap_bytes) return FMR_ERR_CAPACITY;
+    constexpr long long R = 2 * 16 * fmr_chain::kStampCalls;
+    n = 3ll * c->fe_stamps_n;        // ... followed by the two rings of stream stamps (32 calls x 16 ids: constant clock, shader cycles) and the sequence number of the last call
+    if ((size_t)(n + R + 1) * 8 > cap_bytes) return FMR_ERR_CAPACITY;
     if (n) HIPCHK(hipMemcpy(out, c->d_fe_stamps.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy((char *)out + (size_t)n * 8, c->d_fe_stamps.p + 3 * (size_t)c->kMaxFusedWg * c->S, 16, hipMemcpyDeviceToHost));
-    return n + 2;
+    HIPCHK(hipMemcpy((char *)out + (size_t)n * 8, c->d_fe_stamps.p + 3 * (size_t)c->kMaxFusedWg * c->S, R * 8, hipMemcpyDeviceToHost));
+    reinterpret_cast<unsigned long long *>(out)[n + R] = c->call_seq;
+    return n + R + 1;
   }
   switch (which) {
   case 0: src = (c->last_if && c->if_valid) ? c->last_if + (size_t)stream * (c->H_if + c->max_if) + c->H_if : nullptr; esz = sizeof(float2); break;
@@ -2617,6 +2650,29 @@ int fmr_probe_read_bandwidth(int device, const void *d_buf, size_t bytes, int re
     if (r > 0 && ms > 0.f) best = std::max(best, (double)(bytes / 16 * 16) / (ms * 1e-3) / 1e9);
   }
   *gbytes_per_s = best;
+  return FMR_OK;
+}
+
+int fmr_probe_shader_clock(int device, double *mhz) {
+  if (!mhz) return FMR_ERR_BAD_ARG;
+  struct Scope {
+    int prev_dev = -1;
+    unsigned long long *out = nullptr;
+    hipStream_t st = nullptr;
+    ~Scope() {
+      if (st) (void)hipStreamDestroy(st);
+      if (out) (void)hipHostFree(out);
+      if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    }
+  } sc;
+  HIPCHK(hipGetDevice(&sc.prev_dev));
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipHostMalloc((void **)&sc.out, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  HIPCHK(hipStreamCreateWithFlags(&sc.st, hipStreamNonBlocking));
+  hipLaunchKernelGGL(k_probe_clock, dim3(1), dim3(64), 0, sc.st, sc.out, 2000);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(sc.st));
+  *mhz = sc.out[1] ? (double)sc.out[0] / ((double)sc.out[1] * 0.01) : 0.0;     // cycles per microsecond
   return FMR_OK;
 }
 

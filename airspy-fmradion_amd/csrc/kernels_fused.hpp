@@ -133,7 +133,28 @@ __device__ __forceinline__ unsigned long long fused_realtime() {
 
 // FMR_FE_STAMPS=1: a one-thread kernel in front of and behind the fused launch on its stream: where on the constant clock the
 // stream reached them (the launch's own dispatch time stamps are not on that clock's epoch)
-__global__ void k_fused_stamp(unsigned long long *p) { *p = fused_realtime(); }
+__global__ void k_fused_stamp(unsigned long long *p, int cyc_off) {
+  // cyc_off != 0: the shader clock at this instant too -- cycles of this compute unit's counter over ~1 us of the constant
+  // clock (the counters of different XCDs are not comparable, so both reads are taken here), in kHz
+  const unsigned long long t = fused_realtime();
+  if (cyc_off) {
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    unsigned long long t1 = t;
+    while (t1 - t < 100) t1 = fused_realtime();
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    p[cyc_off] = (c1 - c0) * 100000ull / (t1 - t);
+  }
+  *p = t;
+}
+
+// fmr_probe_shader_clock: cycles of this compute unit's counter over `ticks` ticks of the constant 100 MHz clock
+__global__ void k_probe_clock(unsigned long long *out, int ticks) {
+  const unsigned long long t0 = fused_realtime(), c0 = __builtin_readcyclecounter();
+  unsigned long long t1 = t0;
+  while (t1 - t0 < (unsigned long long)ticks) t1 = fused_realtime();
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = t1 - t0; }
+}
 
 // one barrier per epoch.  LDS traffic only: no wave waits here for its global stores, and the loader's DMA stays
 // in flight (a __syncthreads() would drain vmcnt)

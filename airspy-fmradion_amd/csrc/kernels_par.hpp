@@ -90,12 +90,22 @@ __global__ void k_deemph_par(const fm_mpx_t *__restrict__ in0 /* MPX */, const d
 // decaying like A^n); the far end of the warm-up starts from 0 (A^768 = 4e-18).
 // FIR: acc += hA[k] * x[top-k], k ascending (same order as k_aud_decim / the oracle).
 // ---------------------------------------------------------------------------
-#define FMR_DE_LPL 16
+// 15, not 16: the workgroup's tile is then 256 x 15 doubles = 30.7 KB, and TWO of them fit beside the five one-wave
+// workgroups (18.4 KB each) a PLL integration pass keeps on every compute unit -- with 16 samples per lane (34.8 KB with the
+// pad word an even run needs) one did, and the tail stage's first kernel took 172 us beside the PLL's Jacobian pass (75 us
+// alone): the tail then ran 30 us into the next front end, whose workgroups -- a whole unit's LDS each -- cannot start while
+// a kernel that uses LDS still has workgroups to place (round 6, profiles/r06_fe_start.txt).
+#ifndef FMR_DE_LPL
+#define FMR_DE_LPL 15
+#endif
+// lane l's run starts FMR_DE_RUN doubles behind lane l-1's: the stride must be odd (a half-wave's 8-byte accesses then fall
+// on 32 different bank pairs), so an even run length takes a pad word and an odd one must NOT
+#define FMR_DE_RUN (FMR_DE_LPL | 1)
 struct DeScan {
   double pw[7];          // (A^LPL)^(2^j), j = 0..6
   const double *apow;    // (A^LPL)^k, k = 0..64
 };
-__device__ __forceinline__ int de_idx(int j) { return j + (j >> 4); }   // one pad word per lane run: 2-way at worst
+__device__ __forceinline__ int de_idx(int j) { return (FMR_DE_LPL & 1) ? j : j + j / FMR_DE_LPL; }
 
 // NA_T/D_T > 0: compile-time stage-A shape; every lane then owns 4 consecutive outputs and walks their
 // 4 accumulation chains over one shared run of NA + 3 D samples (17 LDS reads per output instead of NA).
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void k_deemph_decim(
   }
   __syncthreads();
   if (ch ? filt1 : filt0) {
-    double *mine = de_xs + tid * (FMR_DE_LPL + 1);
+    double *mine = de_xs + tid * FMR_DE_RUN;
     double v[FMR_DE_LPL];
 #pragma unroll
     for (int i = 0; i < FMR_DE_LPL; i++) v[i] = mine[i];

@@ -314,6 +314,11 @@ def main():
                     help="configs[3]: FM stereo with the MultipathFilter equaliser (-E N); 0 = configs[1], the headline")
     ap.add_argument("--input-format", choices=["cf32", "s16", "u8"], default="cf32",
                     help="source sample format the front-end kernel reads (the headline metric is cf32)")
+    ap.add_argument("--spinup-ms", type=float, default=60.0,
+                    help="ordinary steps run for this long BEFORE the W warm-up steps (0: none).  The GPU's shader clock ramps over "
+                         "tens of milliseconds of load after an idle gap (the oracle checks between set-up and warm-up are one), "
+                         "and a 5 + 20-step region ends before the ramp does; a stream that runs continuously never sees it.  The "
+                         "line reports the clock before the spin-up and on either side of the timed region (`clock`)")
     ap.add_argument("--no-region-events", action="store_true",
                     help="diagnostic: no HIP events inside the timed region (roofline from the instrumented step)")
     ap.add_argument("--api-mode", choices=["batch", "block"], default="batch",
@@ -418,9 +423,17 @@ def main():
     n_au_chk = int(alen0[:nchk].sum())
     audio_chk = audio[0, :n_au_chk].cpu().numpy().copy() if fmt == 0 else None      # every rank checks its own stream 0
     iq_chk = iq[0, :nchk * blk].cpu().numpy().view(np.complex64).reshape(-1).copy() if audio_chk is not None else None
+    # Spin-up (round 6): the same step, untimed, until the shader clock has ramped.  What the ramp costs a short region:
+    # profiles/r06_clock_ramp.txt (5 / 20 / 40 / 80 warm-up steps in front of 20 timed ones: 0.538 / 0.522 / 0.514 / 0.512 ms).
+    mhz = [fmr.probe_shader_clock(local_rank)]
+    spin_steps, t_sp = 0, time.perf_counter()
+    while (time.perf_counter() - t_sp) * 1e3 < args.spinup_ms:
+        step()
+        spin_steps += 1
     for _ in range(args.warmup):
         step()
     ch.synchronize()
+    mhz.append(fmr.probe_shader_clock(local_rank))
     # Timed region: only the stage kernels carry HIP events (two per kernel per step, on the chain's own
     # stream); the host never synchronises inside the region, so launches run ahead of the GPU.
     # (from 8 steps on the events go on every fourth step: the two markers around a stage kernel cost 7-10 us on the decoder
@@ -442,7 +455,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    blocks_done = (1 + args.warmup + args.steps) * B     # stream blocks decoded so far (set-up call + warm-up + timed steps)
+    mhz.append(fmr.probe_shader_clock(local_rank))
+    blocks_done = (1 + spin_steps + args.warmup + args.steps) * B     # stream blocks decoded so far (set-up call + spin-up + warm-up + timed steps)
     audio_last = audio[0, :int(alen.sum())].cpu().numpy().copy()      # stream 0 of this rank, the last TIMED step
     region = {}
     for name, ms in ch.kernel_times():
@@ -456,8 +470,21 @@ def main():
         json.dump({k: [round(float(x), 5) for x in v] for k, v in region.items()}, open(os.environ["FMR_BENCH_SERIES"], "w"))
     if os.environ.get("FMR_FE_STAMPS") and rank == 0:          # diagnostics: where the last timed front-end launch spent its time, workgroup by workgroup
         raw = ch.debug_read(5)
-        before, after = int(raw[-2]), int(raw[-1])
-        stp = raw[:-2].reshape(-1, 3)
+        seq = int(raw[-1])
+        NC = 32                                                 # calls in the ring of stream stamps (fmr_chain::kStampCalls)
+        ring = raw[-(2 * NC * 16 + 1):-(NC * 16 + 1)].astype(np.int64).reshape(NC, 16)      # constant 100 MHz clock
+        ring_khz = raw[-(NC * 16 + 1):-1].astype(np.int64).reshape(NC, 16)                   # shader clock [kHz] measured by the stamp in front of a front end
+        before, after = int(ring[seq % NC, 0]), int(ring[seq % NC, 1])
+        stp = raw[:-(2 * NC * 16 + 1)].reshape(-1, 3)
+        # the timed region step by step: front-end start to start, the stages, and the shader clock in front of the front end
+        ser = []
+        for c in range(seq - min(args.steps, NC - 2) + 1, seq + 1):
+            r0, r1 = ring[(c - 1) % NC], ring[c % NC]
+            if not (r0[0] and r1[0]):
+                continue
+            ser.append("%d: %.0f us (fe %.0f, pll stage %.0f) %.0f MHz" % (c - (seq - args.steps), (r1[0] - r0[0]) * 0.01, (r0[1] - r0[0]) * 0.01,
+                                                                           (r0[7] - r0[1]) * 0.01 if r0[7] else -1, ring_khz[(c - 1) % NC][0] * 1e-3))
+        print("[fe stamps] steps of the timed region, start to start of the front ends: " + "; ".join(ser), file=sys.stderr)
         t_s, t_e = stp[:, 0].astype(np.int64), stp[:, 1].astype(np.int64)
         rel_s, rel_e, dur = (t_s - t_s.min()) * 0.01, (t_e - t_s.min()) * 0.01, (t_e - t_s) * 0.01      # us (100 MHz clock)
         xcc = (stp[:, 2] >> np.uint64(32)).astype(np.int64) & 0xf
@@ -466,6 +493,12 @@ def main():
               (len(stp), pc(rel_s), pc(dur), pc(rel_e)), file=sys.stderr)
         print("[fe stamps] stream stamp in front of the launch -> first workgroup %.1f us; last workgroup's end -> stream stamp behind the launch %.1f us" %
               ((int(t_s.min()) - before) * 0.01, (after - int(t_e.max())) * 0.01), file=sys.stderr)
+        names = ["fe_before", "fe_after", "deemph_decim", "aud_poly", "pilotcut", "dc_pass1", "fm_out", "pll", "stats", "if_agc", "pll_commit", "pll_finish", "pll_shoot_jac"]
+        t0s = int(t_s.min())
+        for back in (1, 0):      # the stream stamps of the call before (whose tail runs into this front end) and of this call, relative to this front end's first workgroup
+            row = ring[(seq - back) % NC]
+            print("[fe stamps] call %d ends of kernels relative to the first workgroup of the last front end (us): " % (seq - back) +
+                  ", ".join("%s %.1f" % (nm, (int(row[i]) - t0s) * 0.01) for i, nm in enumerate(names) if row[i]), file=sys.stderr)
         late = np.argsort(rel_e)[-8:]
         print("[fe stamps] last to end: " + ", ".join("wg %d xcc %d start %.1f dur %.1f end %.1f" % (w, xcc[w], rel_s[w], dur[w], rel_e[w]) for w in late), file=sys.stderr)
         print("[fe stamps] per XCC mean duration: " + ", ".join("%d: %.1f (n %d)" % (x, dur[xcc == x].mean(), int((xcc == x).sum())) for x in sorted(set(xcc.tolist()))), file=sys.stderr)
@@ -622,6 +655,10 @@ def main():
                                  "timed loop the host is paced by the GPU once it is three calls ahead: " +
                                  "%.4f ms per step there" % (t_enq / args.steps * 1e3),
             "cold_first_call_ms": round(cold_ms, 2),
+            "clock": {"spinup_ms": args.spinup_ms, "spinup_steps": spin_steps,
+                      "shader_mhz": {"before_spinup": round(mhz[0]), "before_timed_region": round(mhz[1]), "after_timed_region": round(mhz[2])},
+                      "note": "untimed ordinary steps in front of the W warm-up steps: the shader clock ramps over tens of ms of load after "
+                              "an idle gap, the decoder's recurrence kernels follow it (--spinup-ms 0: the region as rounds 1-5 timed it)"},
             "audio_check": audio_check,
             "recurrences": {"agc_newton_rounds": st.agc_iterations, "pll_newton_rounds": st.pll_iterations,
                             "pll_residuals": [float("%.3g" % v) for v in st.pll_residual_history[:st.pll_iterations]],
@@ -634,7 +671,7 @@ def main():
     headline = (not am and fmt == 0 and S == 1 and not R8B and not IF_FILTER and not args.multipath_stages and not args.no_pilot
                 and args.sigma == 1e-3)
     if rank == 0 and world == 1 and headline and not args.no_r8b_leg:
-        out["r8b"] = r8b_leg(fmr, iq, audio, n, blk, B, local_rank)
+        out["r8b"] = r8b_leg(fmr, iq, audio, n, blk, B, local_rank, spinup_ms=args.spinup_ms)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -655,7 +692,7 @@ def main():
         run_other_configs(1)
 
 
-def r8b_leg(fmr, iq, audio, n, blk, B, device, steps=10, warmup=3):
+def r8b_leg(fmr, iq, audio, n, blk, B, device, steps=10, warmup=3, spinup_ms=60.0):
     """The same workload through the REFERENCE-EQUIVALENT resampler class (r8b::CDSPResampler24's default specification:
     0.98 x Nyquist, stop band from Nyquist, 180 dB -- IfResampler.cpp:25-29), timed in a second, short region of the same
     process and put into the headline line as `r8b`: the headline's FAST class is this project's own filter design, this is
@@ -673,6 +710,10 @@ def r8b_leg(fmr, iq, audio, n, blk, B, device, steps=10, warmup=3):
     ch.synchronize()
     nchk = min(B, 40)
     got = audio[0, :int(alen0[:nchk].sum())].cpu().numpy().copy()
+    spin_steps, t_sp = 0, time.perf_counter()        # (the shader clock's ramp after the idle gap of the headline's oracle checks: see main)
+    while (time.perf_counter() - t_sp) * 1e3 < spinup_ms:
+        step()
+        spin_steps += 1
     for _ in range(warmup):
         step()
     ch.synchronize()
@@ -704,7 +745,7 @@ def r8b_leg(fmr, iq, audio, n, blk, B, device, steps=10, warmup=3):
     assert err < 1e-5, f"R8B leg: audio RMS error {err} vs the r8brain-class oracle exceeds the north-star tolerance"
     bytes_per_launch = 8.0 * n
     return {"what": "the same step through the reference-equivalent resampler class (r8b::CDSPResampler24 defaults, IfResampler.cpp:25-29): "
-                    "second region of this process, %d steps after %d warm-up steps" % (steps, warmup),
+                    "second region of this process, %d steps after %d spin-up and %d warm-up steps" % (steps, spin_steps, warmup),
             "value": round(n * steps / dt / 1e6, 3), "unit": "MS/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
             "resampler": info,
             "stage": {"ms": round(stage_ms, 5), "frac": round(bytes_per_launch / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if stage_ms > 0 else None,

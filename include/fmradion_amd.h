@@ -264,6 +264,12 @@ int fmr_get_kernel_trace(fmr_chain *c, const char **names, int *streams, float *
  * the box the run landed on delivers to a kernel that does nothing but read. */
 int fmr_probe_read_bandwidth(int device, const void *d_buf, size_t bytes, int reps, double *gbytes_per_s);
 
+/* Measurement aid (no counterpart in the reference): the shader clock of `device` right now, in MHz -- one wave counts
+ * its compute unit's cycle counter over 20 us of the constant 100 MHz clock.  The clock ramps over tens of milliseconds
+ * of load after an idle gap and the recurrence kernels of the decoder follow it: bench.py reports it on either side of
+ * its timed region (what a 20-step region measures against a stream that runs continuously). */
+int fmr_probe_shader_clock(int device, double *mhz);
+
 /* Filter tables of FilterParameters (include/FilterParameters.h:31-49), by name
  * e.g. "jj1bdx_fm_384kHz_medium"; returns the length, *is_double tells the type. */
 int fmr_filter_table(const char *name, const void **data, int *is_double);

@@ -17,7 +17,7 @@ try:
 except Exception as e:
     print(v, 'FAILED', e); print(open(f'{O}/{v}.err').read()[-600:])
 PY
-    grep "fe stamps" $O/$v.err | head -2
+    grep "fe stamps" $O/$v.err | head -5
   done
 done
 cp /tmp/keep.so airspy-fmradion_amd/libfmradion_amd.so
