@@ -120,8 +120,10 @@ struct EnvKnobs {
 #ifdef FMR_DIAG_KNOBS           // (diagnostic builds under tools/ only: what an A/B run varies without a rebuild)
   int x_spare_aside = -1;       // FMR_X_SPARE_ASIDE=n  the PLL's spare rounds go to the side stream for calls of <= n blocks
   int x_cpll = 0;               // FMR_X_CPLL=n         PLL chunk length
+  int x_ballast = 0;            // FMR_X_BALLAST=mask   8 KB of LDS ballast (keeps a kernel off the front end's compute units): 1 lock walk, 2 commit
+  int x_sumw = -1;              // FMR_X_SUMW=n         weight of a macro tile with partial sums, in 1/1000 above 1 (default kFusedSumWeight)
 #else
-  static constexpr int x_spare_aside = -1, x_cpll = 0;
+  static constexpr int x_spare_aside = -1, x_cpll = 0, x_ballast = 0, x_sumw = -1;
 #endif
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
@@ -136,7 +138,7 @@ struct EnvKnobs {
 #endif
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
 #ifdef FMR_DIAG_KNOBS
-    x_spare_aside = num("FMR_X_SPARE_ASIDE", -1); x_cpll = num("FMR_X_CPLL", 0);
+    x_spare_aside = num("FMR_X_SPARE_ASIDE", -1); x_cpll = num("FMR_X_CPLL", 0); x_ballast = num("FMR_X_BALLAST", 0); x_sumw = num("FMR_X_SUMW", -1);
 #endif
   }
 };
@@ -249,6 +251,7 @@ struct fmr_chain {
   float fused_hB_inv_scale = 1.f;
   DevBuf<FusedPart> d_fused_part;
   DevBuf<float> d_fused_mid32;              // per front-end workgroup: fp32 copies of mid samples beyond fp16's range (FusedRing::at32)
+  DevBuf<float> d_zero16;                   // sixteen zero bytes (fused front end: the loader's source beyond the ends of a call)
   DevBuf<unsigned long long> d_fe_stamps;   // FMR_FE_STAMPS=1: {start, end, hardware id} of every workgroup of the last fused launch
   int fe_stamps_n = 0;                      //   ... and how many workgroups that launch had
   // The dominant kernel is timed with the start / stop events of ITS OWN dispatch (hipExtLaunchKernelGGL): the time stamps
@@ -288,6 +291,8 @@ struct fmr_chain {
   // asynchronous calls never overwrite a table that is still being copied
   static constexpr int kTabSlots = 8;
   static constexpr int kMaxFusedWg = 1024;
+  static constexpr int kFusedTile0Off = 512;             // the table's tail: [0, 512) first block of every run of the fused front end, [512, 1024) first macro tile of every run (+ the end)
+  static constexpr double kFusedSumWeight = 0.10;        // what a macro tile with per-block partial sums costs more than one without (run_tables)
 #ifndef FMR_FE_SPARE_CUS
 #define FMR_FE_SPARE_CUS 8
 #endif
@@ -348,7 +353,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_walk_go.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -867,6 +872,7 @@ int fmr_chain::init(const fmr_config *c) {
   if ((rc = d_dec.alloc((size_t)S * max_if))) return rc;
   if (fused_ok && (rc = d_fused_part.alloc((size_t)S * 3 * (max_if / 384 + 4)))) return rc;
   if (fused_ok && (rc = d_fused_mid32.alloc((size_t)std::max(std::max(n_cu, S), 256) * 2 * FusedShape<kFusedD, kFusedNA>::MIDR))) return rc;
+  if (fused_ok && (rc = d_zero16.alloc(4))) return rc;
   if (fused_ok && env.fe_stamps && (rc = d_fe_stamps.alloc(3 * (size_t)kMaxFusedWg * S + 2 * kStampCalls * 16))) return rc;
   if ((rc = d_if_rms_blk.alloc((size_t)S * max_blocks))) return rc;
   if ((rc = d_bb_mean_blk.alloc((size_t)S * max_blocks))) return rc;
@@ -1424,7 +1430,7 @@ int fmr_chain::run_tables(CallCtx &k) {
   // Table kernels and the PLL's initial node guess run on the side stream, beside the front end.
   hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((head_ints + 255) / 256)), dim3(256), 0, side,
                      (const int *)h_tab, d_tab_slot, (int)head_ints);
-  int fused_grid = 0, fused_tiles_per_wg = 0;
+  int fused_grid = 0, fused_tiles_per_wg = 0, fused_part_from = 0;
   fused_n_tiles = 0; fused_kb_ref = 0;
   long long fused_T_first = 0;
   if (use_fused) {
@@ -1439,7 +1445,7 @@ int fmr_chain::run_tables(CallCtx &k) {
     // it to end (measured: the lock logic 250 instead of 55 us, and the next PLL pass behind it).
     const int fe_dflt = pipelined ? std::max(8, n_cu - kFeSpareCus) : n_cu;
     const int fe_cus = (pipelined && env.fe_cus > 0) ? std::min(env.fe_cus, n_cu) : fe_dflt;
-    const int wg_per_stream = std::max(1, std::min(kMaxFusedWg, fe_cus / S));
+    const int wg_per_stream = std::max(1, std::min(kFusedTile0Off - 1, fe_cus / S));
     // (ceil(n / grid) macro tiles for all but the last workgroup.  Balanced runs -- n mod grid workgroups with one tile more --
     // were measured in round 6: 248 instead of 245 workgroups at 2^27 samples, and the launch 5 us LONGER in the chain: the
     // three compute units more that the uneven split leaves free serve the kernels beside it)
@@ -1448,9 +1454,38 @@ int fmr_chain::run_tables(CallCtx &k) {
     fe_spare_cus = std::max(0, n_cu - fused_grid * S);
     int *t_wg = h_tab + (tab_ints - kMaxFusedWg);
     const long long kb_ref = 384 * fused_T_first - fused_geom.kB_prev;
+    {   // the first block k_stats walks (kernels.hpp, same rule): earlier blocks need no partial sums
+      int seen = 0, b_first = 0;
+      for (int b0 = ((nb - 1) / 64) * 64; b0 > 0 && !b_first; b0 -= 64) {
+        for (int b = b0; b < std::min(b0 + 64, nb); b++) seen += t_if_len[b] != 0;
+        if (seen >= 400) b_first = b0;
+      }
+      fused_part_from = t_if_off[b_first];
+    }
+    // Where the runs start: a macro tile whose epilogue writes the per-block partial sums (the last ~400 blocks of a call:
+    // block walk, six wave reductions and a store per 128 samples) costs its workgroup kFusedSumWeight more than one that does
+    // not -- measured, round 6: the workgroups of the last fifth of a 2048-block call took 207-213 us against the others' 194-197
+    // and the launch ended with them (with weight 0.05 they still did, with 0.11 the last to end are spread over the chip).  Runs of equal WEIGHT instead of equal length; the table's tail carries the first tile of
+    // every run behind the first block of every run.
+    int *t_tile0 = t_wg + kFusedTile0Off;
+    {
+      const double eps = k.fused_disc ? (env.x_sumw >= 0 ? env.x_sumw * 1e-3 : kFusedSumWeight) : 0.0;
+      const long long tp = std::min<long long>(fused_n_tiles, std::max<long long>(0, (fused_part_from - kb_ref) / 384));   // first tile with sums
+      const double W = (double)tp + (double)(fused_n_tiles - tp) * (1.0 + eps);
+      t_tile0[0] = 0;
+      for (int w = 1; w < fused_grid; w++) {
+        const double cum = W * w / fused_grid;
+        const double tt = cum <= (double)tp ? cum : (double)tp + (cum - (double)tp) / (1.0 + eps);
+        int ti = (int)(tt + 0.5);
+        ti = std::max(ti, t_tile0[w - 1] + 1);                              // every run holds a tile
+        ti = std::min(ti, fused_n_tiles - (fused_grid - w));                // ... the later ones too
+        t_tile0[w] = ti;
+      }
+      t_tile0[fused_grid] = fused_n_tiles;
+    }
     int b = 0;
     for (int w = 0; w < fused_grid; w++) {
-      const long long kf = std::max<long long>(0, kb_ref + 384ll * w * fused_tiles_per_wg);
+      const long long kf = std::max<long long>(0, kb_ref + 384ll * t_tile0[w]);
       while (b < nb && (long long)t_if_off[b] + t_if_len[b] <= kf) b++;
       t_wg[w] = b;
     }
@@ -1458,12 +1493,12 @@ int fmr_chain::run_tables(CallCtx &k) {
     // the block table too (the side stream's copy of it sits behind the previous call's lock logic; both copies write
     // the same values)
     if (pipelined)
-      hipLaunchKernelGGL(k_copy_ints2, dim3((unsigned)((fused_grid + 2 * (size_t)max_blocks + 255) / 256)), dim3(256), 0, stream,
-                         (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), fused_grid, (const int *)h_tab, d_tab_slot,
+      hipLaunchKernelGGL(k_copy_ints2, dim3((unsigned)((kFusedTile0Off + fused_grid + 1 + 2 * (size_t)max_blocks + 255) / 256)), dim3(256), 0, stream,
+                         (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), kFusedTile0Off + fused_grid + 1, (const int *)h_tab, d_tab_slot,
                          2 * max_blocks);
     else
-      hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((fused_grid + 255) / 256)), dim3(256), 0, side,
-                         (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), fused_grid);
+      hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((kFusedTile0Off + fused_grid + 1 + 255) / 256)), dim3(256), 0, side,
+                         (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), kFusedTile0Off + fused_grid + 1);
   }
   int *d_first = d_tab_slot + 5 * (size_t)max_blocks;
   int *d_ck = d_tab_slot + head_ints;
@@ -1538,20 +1573,15 @@ int fmr_chain::run_tables(CallCtx &k) {
     a.tiles_per_wg = fused_tiles_per_wg;
     const int grid = fused_grid;
     a.wg_blk0 = d_tab_slot + (tab_ints - kMaxFusedWg);
+    a.wg_tile0 = a.wg_blk0 + kFusedTile0Off;
+    a.zero16 = reinterpret_cast<const float2 *>(d_zero16.p);
     a.base = k.fused_disc ? k.base : nullptr;        // null: IF samples only (an IF FIR or the equaliser comes first)
     a.base_stride = H_b + (long long)max_if; a.base_off = H_b;
     a.dec = debug_taps ? d_dec.p : nullptr; a.dec_stride = (long long)max_if;
     a.nf = disc_nf; a.bound = disc_bound;
     a.st = d_state.p; a.hB_last = d_hB_last.p; a.part = k.part;
     a.if_off = bt.if_off; a.if_len = bt.if_len; a.nb = nb;
-    {   // the first block k_stats walks (kernels.hpp, same rule): earlier blocks need no partial sums
-      int seen = 0, b_first = 0;
-      for (int b0 = ((nb - 1) / 64) * 64; b0 > 0 && !b_first; b0 -= 64) {
-        for (int b = b0; b < std::min(b0 + 64, nb); b++) seen += t_if_len[b] != 0;
-        if (seen >= 400) b_first = b0;
-      }
-      a.part_from = t_if_off[b_first];
-    }
+    a.part_from = fused_part_from;
     if ((size_t)a.n_tiles * 3 * S > d_fused_part.n) { set_err("internal capacity exceeded (fused tiles)"); return FMR_ERR_CAPACITY; }
     constexpr size_t kLds = FusedShape<D, NA>::LDS_BYTES;
     hipStream_t fes = stream;
@@ -1888,7 +1918,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
     const BlockTab bt_l = bt; const ChunkTab ct_l = ct;
     auto walk = [=]() -> int {
       timed_on(side, "pll_finish", [&] {
-        hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), fin_ballast, side, base_l, base_stride, H_b, bt_l, ct_l, d_atan.p,
+        hipLaunchKernelGGL(k_pll_finish, dim3(S), dim3(64), (env.x_ballast & 1) ? (size_t)kBallastBytes : fin_ballast, side, base_l, base_stride, H_b, bt_l, ct_l, d_atan.p,
                            pllc, (int)pilot_shift, d_pll_nodes.p, d_pll_G.p, ck_wraps_now, ck_mask_now, mask_words,
                            d_blk_wraps.p, d_blk_level.p, stereo_blk_l, d_state.p, d_flags.p,
                            walk_late ? walk_go : (const int *)nullptr);
@@ -1900,7 +1930,7 @@ int fmr_chain::run_fm_pll(CallCtx &k, long long base_stride, bool split_mono,
       hipLaunchKernelGGL(k_pll_blocks, dim3((nb + 3) / 4, S), dim3(256), fin_ballast, side, bt, ct, d_pll_G.p,
                          ck_wraps_now, d_blk_wraps.p, d_blk_level.p, d_flags.p);
       if (walk_late)
-        hipLaunchKernelGGL(k_pll_commit, dim3(S), dim3(FMR_COMMIT_THREADS), fin_ballast, side, bt, ct, pllc, d_pll_G.p, d_blk_wraps.p,
+        hipLaunchKernelGGL(k_pll_commit, dim3(S), dim3(FMR_COMMIT_THREADS), (env.x_ballast & 2) ? (size_t)kBallastBytes : fin_ballast, side, bt, ct, pllc, d_pll_G.p, d_blk_wraps.p,
                            d_blk_level.p, d_state.p, d_flags.p, walk_go);
     });
     if (walk_late) {

@@ -56,6 +56,8 @@ struct FusedArgs {
   FusedPart *part;                                            // [S][3 n_tiles] partial sums per 128-sample third of a macro tile
   const int *if_off; const int *if_len; int nb;               // block table (IF index space, this call)
   int part_from;                                              // partial sums are needed from this IF index on (k_stats walks the last ~400 blocks)
+  const float2 *zero16;                                       // sixteen zero bytes in device memory (the loader's source beyond the call's ends)
+  const int *wg_tile0;                                        // [gridDim.x + 1]: first macro tile of each workgroup's run (null: tiles_per_wg for all)
   const int *wg_blk0;                                         // [gridDim.x]: block that holds the first IF sample of each workgroup's run
   unsigned long long *dbg;                                    // tools/bench_fused.hip: per wave {busy, total} shader cycles of workgroup 0
   float *mid32;                                               // [workgroup][2][3000]: fp32 copies of mid-ring samples fp16 cannot hold (FusedRing::at32), written and read on the repair paths only
@@ -210,18 +212,51 @@ __device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, 
     }
     return issued;
   }
-  // edge region (start / end of the call): guarded element loads, previous call's tail from in_halo, zeros elsewhere
-  float4 *dst = reinterpret_cast<float4 *>(slot);
-  for (int p = lane; p < SH::NPIECE; p += 64) {
-    float2 v[2];
+  // edge region (start / end of the call): the previous call's tail from in_halo, zeros beyond the call.  The same DMA
+  // instructions with a per-lane source -- the call's samples, in_halo, or sixteen zero bytes in device memory -- as long
+  // as no 16-byte piece straddles one of the two borders (the region starts on an even sample: true when H_in and the call's
+  // length are even).  Round 6: as guarded element loads with a wait behind them (below), one such epoch took 7-20 us under
+  // the other workgroups' input streams, and the first and the last run of every call set the launch's end.
+  if (a.zero16 && !(a.H_in & 1) && !(a.n_valid & 1) && !(nb & 1)) {
+    int issued = 0;
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-      const long long n = nb + 2 * p + e;
-      v[e] = make_float2(0.f, 0.f);
-      if (n < 0) { if (n >= -(long long)a.H_in) v[e] = hs[a.H_in + n]; }
-      else if (n < a.n_valid) v[e] = xs[n];
+    for (int c = 0; c < SH::NDMA; c++) {
+      if (c == 0 && !whole) continue;
+      issued++;
+      const int pos = 64 * c + lane;
+      const int q = pos / (SH::PADP + 1), hole = (pos % (SH::PADP + 1)) == SH::PADP;
+      const int piece = pos - q - hole;
+      const long long n0 = nb + 2 * piece;
+      const float2 *gp = (n0 >= 0 && n0 + 2 <= a.n_valid) ? xs + n0 : (n0 < 0 && n0 >= -(long long)a.H_in) ? hs + (a.H_in + n0) : a.zero16;
+      if ((c < SH::NDMA - 1 || pos < SH::NPOS) && (c > 1 || whole || pos >= SH::PREPOS))
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                         (__attribute__((address_space(3))) void *)(slot + 1024 * c), 16, 0, FUSED_DMA_AUX);
     }
-    dst[SH::pos_of_piece(p)] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+    return issued;
+  }
+  // (odd lengths: element loads, eight pieces per lane in flight at a time, from clamped addresses)
+  float4 *dst = reinterpret_cast<float4 *>(slot);
+  constexpr int NIT = (SH::NPIECE + 63) / 64, UB = 8;
+#pragma unroll 1
+  for (int b0 = 0; b0 < NIT; b0 += UB) {
+    float2 v[UB][2];
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      const int p = lane + 64 * (b0 + u);
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const long long n = nb + 2 * p + e;
+        const bool in_h = n < 0 && n >= -(long long)a.H_in, in_x = n >= 0 && n < a.n_valid;
+        const float2 *src = in_h ? hs + (a.H_in + n) : xs + (in_x ? n : 0);
+        const float2 t = *src;
+        v[u][e] = (in_h || in_x) ? t : make_float2(0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      const int p = lane + 64 * (b0 + u);
+      if (p < SH::NPIECE) dst[SH::pos_of_piece(p)] = make_float4(v[u][0].x, v[u][0].y, v[u][1].x, v[u][1].y);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   return 0;
@@ -726,7 +761,7 @@ __device__ __forceinline__ void fused_role_b(const FusedArgs &a, int s, int i0, 
   float prev_tile = 0.f;                              // phase of the last sample of the previous tile (wave 1's first sample needs it)
   float save0 = 0.f;
   FusedBlkWin win{};
-  if (a.base) { save0 = a.st[s].disc_save; blk = a.wg_blk0[blockIdx.x]; win.load(a, blk, lane); }
+  if (a.base) { save0 = a.st[s].disc_save; blk = a.wg_blk0[(int)blockIdx.x]; win.load(a, blk, lane); }
   // (as in FusedB16::load: nothing loaded before the loop may still count as "in flight" inside it, or its first use in
   // every epoch waits for the epilogue's stores)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -810,8 +845,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_ifr_fused(FusedArgs a) {
   float2 *stage = reinterpret_cast<float2 *>(midr + 4 * SH::PLANE_BYTES);
   const int s = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int i0 = blockIdx.x * a.tiles_per_wg;
-  const int i1 = min(i0 + a.tiles_per_wg, a.n_tiles);
+  const int i0 = a.wg_tile0 ? a.wg_tile0[(int)blockIdx.x] : (int)blockIdx.x * a.tiles_per_wg;
+  const int i1 = a.wg_tile0 ? a.wg_tile0[(int)blockIdx.x + 1] : min(i0 + a.tiles_per_wg, a.n_tiles);
   if (i0 >= i1) return;
   // (the unused positions of the mid ring meet zero taps: they must hold finite numbers)
   for (int i = threadIdx.x; i < 4 * SH::PLANE_BYTES / 16; i += FUSED_THREADS) reinterpret_cast<uint4 *>(midr)[i] = make_uint4(0u, 0u, 0u, 0u);
