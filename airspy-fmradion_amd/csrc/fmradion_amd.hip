@@ -765,7 +765,7 @@ int fmr_chain::init(const fmr_config *c) {
                       ah[base + 64 * 8] = (_Float16)(t - (float)hi);
                     }
               const size_t x_len = (size_t)((((int)tl + 64 + 127) / 128) * 128 + 96);
-              const size_t lds5h = 8 * x_len + 2 * (size_t)KCH * 3 * 2 * 64 * 16 + 4 * 8 * 48 * sizeof(float2);
+              const size_t lds5h = 8 * x_len + 2 * (size_t)KCH * 3 * 2 * 64 * 16;      // (planes + two A chunks; the results are staged over the A buffers)
               if (lds5h <= 160 * 1024 - 64 && (size_t)63 * 125 + 32 * (size_t)nkb <= x_len && x_len <= 48 * 256) {
                 if ((rc = upload(d_afrag5h, ah.data(), ah.size()))) return rc;
                 poly5h = true; poly5h_nkb = nkb; poly5h_inv_scale = std::ldexp(1.0f, -ea); poly5h_lds = lds5h;
@@ -1280,7 +1280,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
       const int tiles = (int)((P_last - P_first) / 64 + 1);
       timed_on(fes, "ifr_poly", [&] {
         if (poly5h)
-          hipLaunchKernelGGL((k_ifr_poly5h<48, 125>), dim3(std::min(tiles, n_cu), S), dim3(256), poly5h_lds,
+          hipLaunchKernelGGL((k_ifr_poly5h<48, 125>), dim3(std::min(tiles, n_cu), S), dim3(64 * FMR_POLY5H_WAVES), poly5h_lds,
                              fes, d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag5h.p,
                              poly5h_nkb, poly5h_inv_scale, rs.TB, kB_prev, (int)N_if, ifbuf, (long long)(H_if + max_if), H_if,
                              poly2_tile, tiles);

@@ -792,6 +792,9 @@ __global__ __launch_bounds__(256, 2) void k_ifr_poly4(
 //     [512, 1024) before the split (h keeps 11 bits, l the next 11: 2^-22 of the window's maximum);
 //   * the MFMA accumulates in fp32; as in the f32 kernel the accumulators are flushed into a second set every 128 taps;
 //   * the result is multiplied by the inverse of the two scales (powers of two: exact).
+// (SQ counters of round 5's form, one wave per SIMD: matrix pipe busy 28 %, VALU 29 %, parked at s_waitcnt or the barrier
+// 31 % of the wave cycles, 36 % of the LDS cycles bank conflicts: ds_read_b128 is served in groups of sixteen NON-adjacent
+// lanes -- {0-3, 12-15, 20-27} ... -- not the half-waves the layout below was made for.)
 // Layouts: the tile's window as four fp16 planes in LDS (re_h, re_l, im_h, im_l); a B fragment is eight consecutive
 // elements of a plane from (period n/2) 125 + 32 kb + 8 kq -- a 16-byte read on a 2-byte boundary (LDS takes it,
 // tools/test_mfma_f16.hip).  A fragments [k-block][row tile][h | l][lane][8], streamed through LDS in chunks of four
@@ -799,6 +802,13 @@ __global__ __launch_bounds__(256, 2) void k_ifr_poly4(
 // row tiles = six accumulators, 18 MFMAs per k-block on ten 16-byte reads.
 // ---------------------------------------------------------------------------
 #define FMR_POLY5H_KCH 4                       // k-blocks (of 32 taps) per A chunk
+// Waves per workgroup: 8 = two per SIMD with one column tile each (round 6: the shifts and LDS reads of one wave run under the
+// MFMAs of the other; 0.34 -> 0.30 ms), 4 = one per SIMD with two tiles each (rounds 4-5).  Measured and dropped in round 6
+// (NOTEBOOK.md): a deeper ring of A chunks, a third register set with the shifts between the MFMAs, reads in flight across
+// the chunk barrier -- every one of them slower (more barriers, or spills at the 256 registers two waves per SIMD leave).
+#ifndef FMR_POLY5H_WAVES
+#define FMR_POLY5H_WAVES 8
+#endif
 typedef _Float16 fmr_h8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ fmr_h8 lds_read_h8(const void *p, int byte_off) {     // 16 bytes from any 2-byte boundary
   fmr_h8 v;
@@ -835,12 +845,13 @@ struct FmrH8Shifted {
 };
 
 template <int LB, int MB>
-__global__ __launch_bounds__(256) void k_ifr_poly5h(
+__global__ __launch_bounds__(64 * FMR_POLY5H_WAVES) void k_ifr_poly5h(
     const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
     const _Float16 *__restrict__ afrag, int n_kb, float inv_tap_scale, int TB, long long k0, int count,
     float2 *__restrict__ out, long long out_stride, int out_off, int tile_len, int n_tiles) {
   static_assert(LB == 48, "three 16-row tiles");
-  constexpr int KCH = FMR_POLY5H_KCH, MT = LB / 16, NWV = 4, NT = 256, NH = 2;
+  constexpr int KCH = FMR_POLY5H_KCH, MT = LB / 16, NWV = FMR_POLY5H_WAVES, NT = 64 * NWV, NH = 8 / NWV;
+  static_assert(NWV == 4 || NWV == 8, "eight column tiles per tile: two per wave or one");
   constexpr int CHB = KCH * MT * 2 * 64 * 16;                  // bytes per A chunk
   typedef float v4f __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_5h[];
@@ -849,7 +860,9 @@ __global__ __launch_bounds__(256) void k_ifr_poly5h(
   const int x_len = ((tile_len + 127) / 128) * 128 + 96;
   _Float16 *pl = reinterpret_cast<_Float16 *>(lds_5h);        // [4][x_len]: re_h, re_l, im_h, im_l
   unsigned char *abuf = lds_5h + (size_t)4 * x_len * 2;        // [2][CHB]
-  float2 *stage = reinterpret_cast<float2 *>(abuf + 2 * CHB);  // NWV x (8 periods x LB)
+  // NWV x (8 periods x LB): the results' staging area lies over the A buffers, which are idle by then (a barrier in between)
+  float2 *stage = reinterpret_cast<float2 *>(abuf);
+  static_assert(2 * CHB >= NWV * 8 * LB * (int)sizeof(float2), "the staging area fits over the A buffers");
   __shared__ float s_max[NWV];
   const int s = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -878,7 +891,7 @@ __global__ __launch_bounds__(256) void k_ifr_poly5h(
     };
     // one pass over the window: every lane keeps its (up to 48) samples in registers across the maximum -- all its loads
     // in flight at once, nothing read twice
-    constexpr int NPL = 48;                                    // x_len <= NPL * NT (checked by the host)
+    constexpr int NPL = 48 * 256 / NT;                         // x_len <= NPL * NT (checked by the host)
     float2 wv[NPL];
     float mx = 0.f;
 #pragma unroll
@@ -889,7 +902,9 @@ __global__ __launch_bounds__(256) void k_ifr_poly5h(
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) s_max[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    mx = s_max[0];
+#pragma unroll
+    for (int w = 1; w < NWV; w++) mx = fmaxf(mx, s_max[w]);
     // 2^e with mx 2^e in [512, 1024); a window of zeros (or one that holds no finite maximum) is not scaled
     int ex = 0;
     if (mx > 0.f && mx < 3.0e38f) ex = 9 - (int)((__float_as_uint(mx) >> 23) & 0xff) + 127;
@@ -923,14 +938,14 @@ __global__ __launch_bounds__(256) void k_ifr_poly5h(
     // the planes: 5 t mod 8 elements past a 16-byte boundary, the same for every lane and k-block -- a compile-time
     // constant per wave (FmrH8Shifted).
     auto run_chunks = [&](auto a0_tag, auto a1_tag) {
-      constexpr int A0 = decltype(a0_tag)::value, A1 = decltype(a1_tag)::value;
-      constexpr int NRD = 2 * FmrH8Shifted<A0>::kReads + 2 * FmrH8Shifted<A1>::kReads + 2 * MT;    // LDS reads per k-block
+      constexpr int A0 = decltype(a0_tag)::value, A1 = decltype(a1_tag)::value;        // (one column tile per wave: A1 unused)
+      constexpr int NRD = 2 * FmrH8Shifted<A0>::kReads + (NH == 2 ? 2 * FmrH8Shifted<A1>::kReads : 0) + 2 * MT;    // LDS reads per k-block
       FmrH8Shifted<A0> b0h[2], b0l[2];
       FmrH8Shifted<A1> b1h[2], b1l[2];
       fmr_h8 ah[2][MT], al[2][MT];
       auto read_b = [&](int set, int kb) {
         b0h[set].issue(pl, bofs[0] + 64 * kb); b0l[set].issue(pl, bofs[0] + 64 * kb + 2 * x_len);
-        b1h[set].issue(pl, bofs[1] + 64 * kb); b1l[set].issue(pl, bofs[1] + 64 * kb + 2 * x_len);
+        if constexpr (NH == 2) { b1h[set].issue(pl, bofs[NH - 1] + 64 * kb); b1l[set].issue(pl, bofs[NH - 1] + 64 * kb + 2 * x_len); }
       };
       auto read_a = [&](int set, const unsigned char *ab, int k) {
 #pragma unroll
@@ -962,10 +977,13 @@ __global__ __launch_bounds__(256) void k_ifr_poly5h(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           }
           // (the MFMAs must depend on something behind the wait: every fragment through an empty asm)
-          b0h[cur].pin(); b0l[cur].pin(); b1h[cur].pin(); b1l[cur].pin();
+          b0h[cur].pin(); b0l[cur].pin();
+          if constexpr (NH == 2) { b1h[cur].pin(); b1l[cur].pin(); }
 #pragma unroll
           for (int mt = 0; mt < MT; mt++) { asm volatile("" : "+v"(ah[cur][mt])); asm volatile("" : "+v"(al[cur][mt])); }
-          const fmr_h8 bh[NH] = {b0h[cur].get(), b1h[cur].get()}, bl[NH] = {b0l[cur].get(), b1l[cur].get()};
+          fmr_h8 bh[NH], bl[NH];
+          bh[0] = b0h[cur].get(); bl[0] = b0l[cur].get();
+          if constexpr (NH == 2) { bh[NH - 1] = b1h[cur].get(); bl[NH - 1] = b1l[cur].get(); }
 #pragma unroll
           for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -985,16 +1003,29 @@ __global__ __launch_bounds__(256) void k_ifr_poly5h(
           for (int mt = 0; mt < MT; mt++) tot[h][mt] += acc[h][mt];
       }
     };
-    // column tiles w and w + 4: 125 w and 125 (w + 4) elements in, i.e. (5 w) mod 8 and (5 w + 4) mod 8 past a boundary
+    // column tile t: 125 t elements in, i.e. (5 t) mod 8 past a 16-byte boundary (four waves: tiles w and w + 4; eight: tile w)
     static_assert(MB == 125, "the misalignment table below is 125 t mod 8");
-    using I = std::integral_constant<int, 0>;
-    switch (wave) {
-    case 0: run_chunks(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); break;
-    case 1: run_chunks(std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{}); break;
-    case 2: run_chunks(std::integral_constant<int, 2>{}, std::integral_constant<int, 6>{}); break;
-    default: run_chunks(std::integral_constant<int, 7>{}, std::integral_constant<int, 3>{}); break;
+    using I0 = std::integral_constant<int, 0>;
+    if constexpr (NWV == 4) {
+      switch (wave) {
+      case 0: run_chunks(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); break;
+      case 1: run_chunks(std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{}); break;
+      case 2: run_chunks(std::integral_constant<int, 2>{}, std::integral_constant<int, 6>{}); break;
+      default: run_chunks(std::integral_constant<int, 7>{}, std::integral_constant<int, 3>{}); break;
+      }
+    } else {
+      switch (wave) {
+      case 0: run_chunks(std::integral_constant<int, 0>{}, I0{}); break;
+      case 1: run_chunks(std::integral_constant<int, 5>{}, I0{}); break;
+      case 2: run_chunks(std::integral_constant<int, 2>{}, I0{}); break;
+      case 3: run_chunks(std::integral_constant<int, 7>{}, I0{}); break;
+      case 4: run_chunks(std::integral_constant<int, 4>{}, I0{}); break;
+      case 5: run_chunks(std::integral_constant<int, 1>{}, I0{}); break;
+      case 6: run_chunks(std::integral_constant<int, 6>{}, I0{}); break;
+      default: run_chunks(std::integral_constant<int, 3>{}, I0{}); break;
+      }
     }
-    (void)sizeof(I);
+    __syncthreads();                                          // everybody has read its last A fragments: the buffers become the staging area
     // D[row = 4 kq + v][col = n] -> position p = 16 mt + 4 kq + v of period 8 (n / 2) + t, component n & 1
 #pragma unroll
     for (int h = 0; h < NH; h++) {

@@ -14,7 +14,7 @@ agg = {}
 for fn in files:
     for r in csv.DictReader(open(fn)):
         n = r["Kernel_Name"]
-        if "fmr::" not in n or (flt and flt not in n):
+        if "fmr" not in n or (flt and flt not in n):
             continue
         n = n.split("(")[0].replace("void ", "").replace("fmr::", "")
         d = agg.setdefault(n, {}).setdefault(r["Counter_Name"], [0, 0.0])
