@@ -121,9 +121,10 @@ struct EnvKnobs {
   int x_spare_aside = -1;       // FMR_X_SPARE_ASIDE=n  the PLL's spare rounds go to the side stream for calls of <= n blocks
   int x_cpll = 0;               // FMR_X_CPLL=n         PLL chunk length
   int x_ballast = 0;            // FMR_X_BALLAST=mask   8 KB of LDS ballast (keeps a kernel off the front end's compute units): 1 lock walk, 2 commit
+  int x_amtol = 0;              // FMR_X_AMTOL=n        AM: the IF AGC's acceptance from round 3 on, in 1e-6 (0: the product's 5e-6; 1000 + n: from round 2 on)
   int x_sumw = -1;              // FMR_X_SUMW=n         weight of a macro tile with partial sums, in 1/1000 above 1 (default kFusedSumWeight)
 #else
-  static constexpr int x_spare_aside = -1, x_cpll = 0, x_ballast = 0, x_sumw = -1;
+  static constexpr int x_spare_aside = -1, x_cpll = 0, x_ballast = 0, x_sumw = -1, x_amtol = 0;
 #endif
   static bool on(const char *n) { const char *e = getenv(n); return e && e[0] == '1'; }
   static bool set(const char *n) { return getenv(n) != nullptr; }
@@ -138,7 +139,7 @@ struct EnvKnobs {
 #endif
     if (const char *e = getenv("FMR_PLL_RTOL")) if (e[0]) pll_rtol = atof(e);
 #ifdef FMR_DIAG_KNOBS
-    x_spare_aside = num("FMR_X_SPARE_ASIDE", -1); x_cpll = num("FMR_X_CPLL", 0); x_ballast = num("FMR_X_BALLAST", 0); x_sumw = num("FMR_X_SUMW", -1);
+    x_spare_aside = num("FMR_X_SPARE_ASIDE", -1); x_cpll = num("FMR_X_CPLL", 0); x_ballast = num("FMR_X_BALLAST", 0); x_sumw = num("FMR_X_SUMW", -1); x_amtol = num("FMR_X_AMTOL", 0);
 #endif
   }
 };
@@ -1749,7 +1750,7 @@ int fmr_chain::run_if_stage(CallCtx &k) {
     // solved for its state only, and its 4 bytes per IF sample stay out of HBM unless the debug tap asks for them
     float *const gain_out = (agc_aside && !debug_taps) ? (float *)nullptr : d_gain.p;
     timed_on(as, "if_agc", [&] {
-      const int ginv = (mode == FMR_MODE_FM || mode == FMR_MODE_NBFM) ? (gain_out ? 1 : 2) : 0;
+      const int ginv = (mode == FMR_MODE_FM || mode == FMR_MODE_NBFM) ? (gain_out ? 1 : 2) : -env.x_amtol;
       // (four waves, one per SIMD: a workgroup of sixteen finds no compute unit with room for all of them while the PLL's
       // first pass -- one 260-register wave per SIMD, 1258 workgroups queueing -- holds the chip)
       constexpr int kAgcWg = 256;
