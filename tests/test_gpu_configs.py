@@ -78,7 +78,7 @@ def test_config5_32_streams_per_gpu(pilotcut):
         assert st.stereo_detected == int(fm.stereo_detected()) == 1, s
         assert st.if_rms == pytest.approx(fm.get_if_rms(), rel=1e-5)
         assert st.if_agc_gain == pytest.approx(fm.get_if_agc_gain(), rel=1e-4)
-        assert st.pilot_level == pytest.approx(fm.get_pilot_level(), rel=5e-6)
+        assert st.pilot_level == pytest.approx(fm.get_pilot_level(), rel=4e-6)      # (the acceptance rule's floor: test_gpu_parity._fm_case)
     _report("config5_32_streams", audio_rms_err_max=max(errs), audio_rms_err_mean=float(np.mean(errs)),
             samples_per_stream=n, blocks=len(lens), pll_fallback_per_call=fallbacks)
     assert max(errs) < 1e-5, errs       # north-star tolerance

@@ -135,12 +135,16 @@ def _fm_case(name, x, blk, batch, *, fir=None, stereo=True, deemph=50.0, pilot_s
     assert st.baseband_mean * 75000.0 == pytest.approx(fm.get_tuning_offset(), rel=1e-3, abs=1e-2)
     assert st.if_agc_gain == pytest.approx(fm.get_if_agc_gain(), rel=1e-5)
     if stereo:
-        # get_pilot_level is a status display value: the PLL rounds stop at a chunk-boundary mismatch of 1e-6
-        # relative in the pilot filter states; audio is unaffected at the 1e-9 level
-        # (tools/diag_rtol.py).  Measured over the suite: 1.5e-8 .. 1.5e-6 (the largest with 2517-sample blocks,
-        # whose short calls accept on the first mismatch under the threshold)
+        # get_pilot_level is a status display value.  Its floor is the PLL's acceptance rule, not rounding: a pass is
+        # accepted at a chunk-boundary mismatch of 16 units, and the unit of the pilot filter's delay states -- whose
+        # magnitude IS the level -- is 1e-7 of the size of the (I, Q) delay pair, so each of the two delays of
+        # an accepted trajectory may sit 1.6e-6 of that size from the serial one's: 3.2e-6 in the level at worst; audio is
+        # unaffected at the 1e-9 level (tools/diag_rtol.py).  Measured over the suite: 1.5e-8 .. 2.1e-6 (the largest behind a
+        # two-tap IF filter and with 2517-sample blocks, whose short calls accept on the first mismatch under the
+        # threshold).  Hence 4e-6 (rounds 1-5 asserted 5e-6); 1e-6 would need the acceptance at 5 units: a third pass for
+        # every call, +0.15 ms per 2^27-sample step
         # (behind the equaliser the level follows the taps, which are held to 1e-4)
-        assert st.pilot_level == pytest.approx(fm.get_pilot_level(), rel=5e-6 if stages == 0 else 1e-4, abs=1e-9)
+        assert st.pilot_level == pytest.approx(fm.get_pilot_level(), rel=4e-6 if stages == 0 else 1e-4, abs=1e-9)
     return ch, fm, got, ref
 
 

@@ -85,7 +85,7 @@ def test_pipelined_chain_is_bit_identical_to_the_in_order_chain(pilotcut, monkey
     ref, fm = _oracle(x[0], CALLS, pilotcut)
     assert len(ref) == len(piped[0])
     assert rms(piped[0] - ref) < 1e-5
-    assert st1.pilot_level == pytest.approx(fm.get_pilot_level(), rel=5e-6)
+    assert st1.pilot_level == pytest.approx(fm.get_pilot_level(), rel=4e-6)      # (the acceptance rule's floor: test_gpu_parity._fm_case)
 
 
 @pytest.mark.parametrize("env", [{"FMR_FE_CUS": "200"}, {"FMR_FE_CUS": "256"}, {"FMR_FE_CUS": "61"}])
@@ -125,3 +125,31 @@ def test_pipelined_two_streams_mono_and_if_filter(pilotcut, monkeypatch):
     assert np.array_equal(f0[0], f1[0])
     ref, _ = _oracle(x[0], calls, pilotcut, fir=fir)
     assert rms(f1[0] - ref) < 1e-5
+
+
+def test_fused_runs_of_equal_weight_and_call_edges(pilotcut, monkeypatch):
+    """Round 6: (i) a call of more than ~450 blocks -- only its last ~400 blocks carry the per-block partial sums, and the
+    front end's runs are cut by WEIGHT (a macro tile with sums counts 1.10), so the workgroups' runs differ in length; (ii)
+    the epochs at the two ends of a call go through the loader's DMA path with a per-lane source (samples / in_halo / a zero
+    block) when the call's length is even, and through element loads when it is odd.  Neither may change a sample: against
+    the three-kernel front end (no runs, no epochs) to rounding, against the oracle to the tolerance, and the statistics the
+    partial sums feed to theirs."""
+    calls = [[BLK] * 470, [BLK] * 3 + [4099], [BLK] * 4, [BLK] * 2 + [30001, 1], [BLK] * 8]      # even | odd length | (odd start) | odd | ...
+    n = sum(sum(c) for c in calls)
+    x = siggen.fm_stereo_iq(n, 10e6)[None, :]
+    fused, al1, st1 = _run_async(x, calls, monkeypatch, {})
+    three, al0, st0 = _run_async(x, calls, monkeypatch, {"FMR_NO_FUSED": "1"})
+    assert [list(a) for a in al0] == [list(a) for a in al1]
+    assert rms(fused[0] - three[0]) < 1e-6
+    ref, fm = _oracle(x[0], calls, pilotcut)
+    assert len(ref) == len(fused[0])
+    assert rms(fused[0] - ref) < 1e-5
+    assert st1.stereo_detected == 1 and st1.pll_fallback == 0
+    assert st1.if_rms == pytest.approx(fm.get_if_rms(), rel=1e-5)
+    assert st1.baseband_level == pytest.approx(fm.get_baseband_level(), rel=1e-4, abs=1e-7)
+
+
+def test_probe_shader_clock_is_plausible():
+    """fmr_probe_shader_clock (bench.py's `clock` object): between 0.5 and 3 GHz, and an output pointer is required."""
+    mhz = fmr.probe_shader_clock(0)
+    assert 500.0 < mhz < 3000.0, mhz
