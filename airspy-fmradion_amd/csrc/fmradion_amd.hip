@@ -66,6 +66,11 @@ constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 512, K_A
 #endif
 constexpr int C_PLL_MIN = FMR_C_PLL_MIN;   // smallest PLL chunk (capacity); the actual length is c_pll
 constexpr long long kSmallCall = 8192;   // IF samples: calls up to this size enqueue fewer spare Newton rounds
+// ... and cut their blocks into PLL chunks of 16 samples instead of c_pll = 64: a lane integrates its chunk serially whatever
+// the call's size, and ONE 65536-sample block (2517 IF samples) is 40 chunks of 64 -- one wave, 52 + 44 us for the two
+// passes of a call whose whole budget is ~250 us (main.cpp:916-956 calls block by block) -- or 158 chunks of 16: three
+// waves side by side, a quarter of the samples each (round 6)
+constexpr int kCPllSmall = 16;
 constexpr unsigned kAgcWaitTicks = 50000000u;   // 0.5 s of the 100 MHz clock: how long k_mpf4 waits for a chunk's gains (the AGC
                                                 // kernel beside it is three times faster than the equaliser: it never waits in practice)
 constexpr int K_AGC_ITERS = 6, K_PLL_ITERS = 4;   // PLL: 2 rounds in lock, 2 spare (an unused round is three launches that return at once: ~6 us measured)
@@ -843,7 +848,7 @@ int fmr_chain::init(const fmr_config *c) {
     st.af_gain = 1.0;
   }
   if ((rc = upload(d_state, h_state.data(), h_state.size()))) return rc;
-  max_ck = max_if / (size_t)c_pll + (size_t)max_blocks + 2;
+  max_ck = std::max(max_if / (size_t)c_pll, std::min<size_t>(max_if, (size_t)kSmallCall) / (size_t)kCPllSmall) + (size_t)max_blocks + 2;
   tab_ints = 5 * (size_t)max_blocks + 3 * max_ck + (size_t)max_blocks + 1 + kMaxFusedWg;   // tail: first block of each fused workgroup
   HIPCHK(hipHostMalloc((void **)&h_tab_all, sizeof(int) * kTabSlots * tab_ints));
   // The marks are written by one-thread kernels and polled by the host while more work is queued behind them: COHERENT
@@ -1420,9 +1425,10 @@ int fmr_chain::run_tables(CallCtx &k) {
   // host only sends 6*max_blocks+1 ints per call.
   int *t_first = h_tab + 5 * (size_t)max_blocks;
   nck = 0;
+  const int c_call = (N_if <= kSmallCall && env.x_cpll == 0) ? kCPllSmall : c_pll;       // (the same rule in both chain forms: N_if only)
   for (int b = 0; b < nb; b++) {
     t_first[b] = nck;
-    nck += (t_if_len[b] + c_pll - 1) / c_pll;
+    nck += (t_if_len[b] + c_call - 1) / c_call;
   }
   t_first[nb] = nck;
   const size_t head_ints = 6 * (size_t)max_blocks + 1;
@@ -1506,7 +1512,7 @@ int fmr_chain::run_tables(CallCtx &k) {
   ct = ChunkTab{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_first, nck};
   hipLaunchKernelGGL(k_signal_host, dim3(1), dim3(1), 0, side, &h_marks[0], call_seq);
   if (mode == FMR_MODE_FM && nck > 0) {
-    hipLaunchKernelGGL(k_chunk_tab, dim3(nb), dim3(64), 0, side, d_tab_slot, d_tab_slot + max_blocks, d_first, c_pll,
+    hipLaunchKernelGGL(k_chunk_tab, dim3(nb), dim3(64), 0, side, d_tab_slot, d_tab_slot + max_blocks, d_first, c_call,
                        d_ck, d_ck + max_ck, d_ck + 2 * max_ck);
     if (stereo && !serial_mode)
       timed_on(side, "pll_begin", [&] {

@@ -6,21 +6,33 @@
 // Shape: the 10 MS/s class -- stage A D = 10, NA = 103 (the equiripple design, design.hpp) onto 1 MHz, followed by the
 // LB/MB = 48/125, TB = 210 polyphase stage (the k_ifr_poly4 shape).
 //
-// One 768-lane workgroup per CU owns a CONTIGUOUS run of "macro tiles" (8 periods of stage B = 384 IF samples
-// = 1000 mid samples = 10 000 input samples) of one stream and walks it in EPOCHS of half a macro tile
-// (500 mid samples, 5 000 input samples, 40 KB).  Wave roles (one s_barrier per epoch, nothing else synchronises):
-//   wave 0       loader  : LDS-DMA (global_load_lds_dwordx4) of the input region of epoch e+2 into a 3-slot ring,
-//                          80 KB in flight per CU; it never reads LDS, so the compiler puts no wait in its path and
-//                          its loads stay in flight across the barriers (s_waitcnt vmcnt(40) by hand)
-//   waves 4..11  stage A : quad form (FusedQuad): four lanes share four consecutive outputs, a quarter of the tap
-//                          window each, out of the natural-order slot; results go to a 3-window `mid` ring in LDS
-//   waves 1..3   stage B : the 48 x 332 banded polyphase matrix as v_mfma_f32_16x16x4_f32 (rows = 16 positions,
-//                          columns = 8 periods x (re, im)), one row tile per wave, the 63 live k-steps of a macro tile
-//                          spread over the two epochs that follow its last input; then a third each of the
-//                          EPILOGUE: IF samples of the finished macro tile -> atan2 / wrapped difference (the
-//                          discriminator), float -> double widening, per-block partial sums, coalesced stores
-// Arithmetic: every stage-A output is fp32 FMAs in a fixed order (quarter of the window, word, even / odd sample, then
-// the quad's reduction tree); stage B is bit-identical to k_ifr_poly4 (an f32 MFMA is a k-ordered fmaf chain).
+// One 512-lane workgroup per CU (eight waves, two per SIMD; 152 KB of the CU's 160 KB of LDS) owns a CONTIGUOUS run of
+// "macro tiles" (8 periods of stage B = 384 IF samples = 1000 mid samples = 10 000 input samples) of one stream and walks
+// it in EPOCHS of half a macro tile (500 mid samples, 5 000 input samples, 40 KB).  The runs are cut by weight on the host
+// (a tile whose epilogue writes per-block partial sums counts 1.10: fmradion_amd.hip, run_tables).  Wave roles -- one
+// `s_waitcnt lgkmcnt(0); s_barrier` per epoch (fused_barrier), nothing else synchronises:
+//   wave 0       loader  : LDS-DMA (global_load_lds_dwordx4, nt) of the input region two epochs ahead into a 3-slot ring
+//                          (FusedShape: a 16-byte hole after every 160 samples keeps stage A's sixteen column windows on
+//                          sixteen bank quads); it never reads LDS, its loads stay in flight across the barriers and a slot
+//                          is released by `s_waitcnt vmcnt(n)` by hand (fused_wait_upto).  The epochs at the two ends of a
+//                          call take the same instructions with a per-lane source: samples, in_halo or a zero block (fused_fill)
+//   waves 4..7   stage A : FusedMfmaA -- mid[J] = sum_i c[i] x[10 J + i] as a banded product on v_mfma_f32_16x16x32_f16:
+//                          A = the taps (16 outputs x 256 inputs, fragments from the host), B = sixteen column tiles of 256
+//                          input samples of one component; taps and samples as two fp16 terms (x = xh + xl / 2048, the low
+//                          term formed inside v_fma_mixlo/hi_f16), three products, fp32 accumulate; wave (unit, component)
+//                          owns 256 consecutive outputs, k-tile kt + 1 read while kt is converted and multiplied.  Results
+//                          go to the `mid` ring: three macro-tile windows in LDS as four fp16 planes (high / low x re / im)
+//   waves 1..3   stage B : FusedB16 -- the 48 x 250 banded polyphase matrix on the same instruction (rows = 16 positions of
+//                          the wave's row tile, columns = 8 periods x (re, im), nine k-tiles of 32 ring positions), then a
+//                          third each of the EPILOGUE (fused_epilogue): IF samples of the finished macro tile -> 22-instruction
+//                          atan2, wrapped difference through DPP (the discriminator), per-block partial sums for the
+//                          statistics, and 8 bytes per IF sample of stores: the MPX as the float it is and |x|^2 for the
+//                          IF AGC's state solve (an IF FIR or the equaliser behind the kernel: the IF pair instead)
+// Arithmetic: fp32 accumulation inside the MFMA (its internal summation order); 3.1e-7 relative RMS from the fp64 oracle at
+// the IF (tolerance 2e-6).  A tile that holds a non-finite value or a sample beyond fp16's range is recomputed with plain
+// fp32 tap loops (exact tap support, tests/test_gpu_fused_levels.py).  Results are a function of the absolute sample index:
+// neither the cut into calls nor into workgroups changes a bit (tests/test_gpu_pipeline.py).
+// History of the forms this replaced (768 lanes, the quad form of stage A, stage B on the f32 MFMA): NOTEBOOK.md.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
