@@ -34,6 +34,13 @@ timeout 300 python bench.py --resampler-class r8b --steps 20 --warmup 3 > gpurun
 timeout 300 python bench.py --if-filter --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_if_filter.json 2>/dev/null < /dev/null
 for sg in 1e-2 3e-2; do timeout 200 python bench.py --sigma $sg --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_sigma_${sg}.json 2>/dev/null < /dev/null; done
 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_driver_form.json 2>/dev/null < /dev/null
+# round 6: the same form without the spin-up (the region as rounds 1-5 timed it), and with the per-workgroup / per-step stamps
+timeout 200 python bench.py --steps 20 --warmup 5 --spinup-ms 0 --no-cpu-baseline > gpurun_out/${tag}_bench_driver_form_no_spinup.json 2>/dev/null < /dev/null
+FMR_FE_STAMPS=1 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-r8b-leg 2>&1 > /dev/null < /dev/null | grep "fe stamps" > gpurun_out/${tag}_fe_stamps.txt
+FMR_FE_STAMPS=1 timeout 200 python bench.py --steps 20 --warmup 5 --spinup-ms 0 --no-cpu-baseline --no-r8b-leg 2>&1 > /dev/null < /dev/null | grep "fe stamps" | sed 's/^/[no spin-up] /' >> gpurun_out/${tag}_fe_stamps.txt
+timeout 280 python tools/am_tol_check.py 2048 4 2>/dev/null | grep "^call" > gpurun_out/${tag}_am_agc_rounds.txt < /dev/null
+timeout 200 python tools/block1_trace.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_block1_trace.txt < /dev/null
+timeout 200 python tools/step_time.py --steps 200 2>/dev/null | grep ms_per_step > gpurun_out/${tag}_step_time.txt < /dev/null
 # the drop-in call: one block per fmr_process() through host buffers (latency percentiles)
 timeout 200 python bench.py --api-mode block --steps 300 --blocks 400 --no-cpu-baseline > gpurun_out/${tag}_bench_block1.json 2>/dev/null < /dev/null
 timeout 120 tools/bench_fused.bin > gpurun_out/${tag}_fused_harness.log 2>&1 < /dev/null
@@ -44,6 +51,9 @@ timeout 120 python tools/step_timeline.py --show 1 --if-filter --out gpurun_out/
 timeout 120 python tools/step_timeline.py --show 1 --sigma 1e-2 --out gpurun_out/${tag}_step_timeline_sigma_1e-2.txt > /dev/null 2>&1 < /dev/null
 { timeout 120 python tools/mpf_rate.py < /dev/null; } 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_mpf_account.txt
 timeout 120 python tools/pll_mismatch.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_pll_mismatch.txt
+# SQ counters of the R8B class's stage B (three --pmc passes, kernel trace only)
+bash tools/gpu_pmc_r8b.sh k_ifr_poly5h > gpurun_out/${tag}_pmc_r8b_stage_b.txt 2>&1 < /dev/null
+rm -rf gpurun_out/pmcr_1 gpurun_out/pmcr_2 gpurun_out/pmcr_3
 tail -3 gpurun_out/${tag}_pytest_gpu.log
 cat gpurun_out/${tag}_smoke.log | tail -2
 cut -c1-400 gpurun_out/${tag}_bench.json

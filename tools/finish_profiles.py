@@ -38,7 +38,10 @@ if _fk and bench["roofline"].get("traffic") is None:
     bench["roofline"]["traffic_source"] = (f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same "
                                            f"collection (kernel sources {_pm.get('csrc_sha256_16')}), filled in by tools/finish_profiles.py")
     json.dump(bench, open(prof(f"{tag}_bench.json"), "w"), indent=1)
-for extra in (f"{tag}_pytest_gpu.log", f"{tag}_smoke.log", f"{tag}_fused_harness.log"):
+for extra in (f"{tag}_pytest_gpu.log", f"{tag}_smoke.log", f"{tag}_fused_harness.log", f"{tag}_fe_stamps.txt", f"{tag}_am_agc_rounds.txt",
+              f"{tag}_block1_trace.txt", f"{tag}_step_time.txt", f"{tag}_pmc_r8b_stage_b.txt", f"{tag}_step_timeline.txt",
+              f"{tag}_step_timeline_r8b.txt", f"{tag}_step_timeline_if_filter.txt", f"{tag}_step_timeline_sigma_1e-2.txt",
+              f"{tag}_mpf_account.txt", f"{tag}_pll_mismatch.txt"):
     if os.path.exists(g(extra)):
         shutil.copy(g(extra), prof(extra))
 for rep in ("parity_report.json", "parity_report_configs.json"):
