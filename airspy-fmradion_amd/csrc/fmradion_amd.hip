@@ -110,7 +110,7 @@ struct EnvKnobs {
                                 //                    (0: all but one per XCD)
   bool debug_taps = false;      // FMR_DEBUG_TAPS=1   keep intermediate signals readable through fmr_debug_read
   bool host_prof = false;       // FMR_HOST_PROF=1    host enqueue time per call on stderr
-  bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end (tests: fused vs three-kernel property test)
+  bool no_fused = false;        // FMR_NO_FUSED=1     three-kernel front end, 384 k -> 48 k stage B on the vector ALUs (tests: the product against the form it replaced)
 #ifdef FMR_AB_PARTNERS          // (libfmradion_amd_ab.so only: the slower forms two GPU tests compare the product with, and a test hook)
   bool pll_v1 = false;          // FMR_PLL_V1         seven launches per Newton round of the PLL instead of three: no hand-off
                                 //                    between workgroups inside a launch (tests: bit-equality stress test)
@@ -242,6 +242,10 @@ struct fmr_chain {
   int in_fmt = 0, in_bps = 8;          // source sample format (fmr_config.input_format) and its bytes per IQ sample
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
+  bool fir_mfma = false;               // the 255-tap IF FIR of the 48 kHz modes on the matrix cores (k_ifr_poly4<48, 48, 255> + k_fir_finish)
+  DevBuf<float> d_afrag_fir;
+  bool poly4_am = false;               // ... the 3/8 shape (384 k -> 48 k, AM / NBFM) as sixteen periods per row block: 48/128
+  int poly4_am_tile = 0;
   bool poly5h = false;                 // ... on the fp16 matrix cores, three-product split (k_ifr_poly5h): the form that runs
   int poly5h_nkb = 0;
   float poly5h_inv_scale = 1.f;
@@ -359,7 +363,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag_fir.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_walk_go.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -780,6 +784,24 @@ int fmr_chain::init(const fmr_config *c) {
             }
           }
         }
+        if (poly3 && rs.LB == 3 && rs.MB == 8 && rs.TB == 214 && !env.no_fused) {
+          // 384 k -> 48 k (config 3): sixteen periods of 3 outputs / 8 mid samples are one period of 48 / 128 -- output
+          // 3 a + b of it starts (8 (3 a + b)) / 3 = 8 a + off[b] samples in and takes phase row phi[b] -- so the banded
+          // matrix-core kernel of the 48/125 shape serves it (round 6: k_ifr_poly3 took 0.147 ms per 2.1 M IF samples)
+          using SH = Poly4Shape<48, 128, 214>;
+          std::vector<float> af((size_t)SH::MT * SH::NK * 64, 0.f);
+          for (int mt = 0; mt < SH::MT; mt++)
+            for (int i = 0; i < SH::nks(mt); i++)
+              for (int l = 0; l < 64; l++) {
+                const int pp = 16 * mt + (l & 15), m = 4 * (SH::ks_lo(mt) + i) + (l >> 4), j = m - SH::off(pp);
+                if (j >= 0 && j < rs.TB) af[((size_t)mt * SH::NK + i) * 64 + l] = fb[(size_t)phi[pp % 3] * rs.TB + j];
+              }
+          if ((rc = upload(d_afrag, af.data(), af.size()))) return rc;
+          poly4_am = true;
+          poly4_am_tile = 64 * 128 + SH::off(47) + rs.TB + 64;
+          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 128, 214>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        }
         if (poly3 && rs.LB == 48 && rs.MB == 125 && rs.TB == 210) {
           using SH = Poly4Shape<48, 125, 210>;
           std::vector<float> af((size_t)SH::MT * SH::NK * 64, 0.f);
@@ -874,6 +896,23 @@ int fmr_chain::init(const fmr_config *c) {
 
   if ((rc = upload(d_coeff, filter_src, (size_t)ntaps))) return rc;
   if (fir_enable && (rc = d_fir.alloc((size_t)S * max_if))) return rc;
+  if (fir_enable && mode != FMR_MODE_FM && !ssb_like && ntaps == 255 && !env.no_fused && !env.serial) {
+    // AM / DSB / NBFM: out[i] = sum_{j = 1 .. 254} c[j] x[i - j] as the 1 : 1 "polyphase" shape 48 / 48 of the banded matrix-core
+    // kernel -- one phase, window start = output index; tap row h[j'] = c[254 - j'] over x[i - 254 + j'], with the lag-0 tap
+    // (j' = 254) left out: k_fir_finish adds it where the reference has it.  (Round 6: k_fm_block2 took 0.139 ms per 2.1 M IF
+    // samples, a fifth of the AM step.)
+    using SH = Poly4Shape<48, 48, 255>;
+    std::vector<float> af((size_t)SH::MT * SH::NK * 64, 0.f);
+    for (int mt = 0; mt < SH::MT; mt++)
+      for (int i = 0; i < SH::nks(mt); i++)
+        for (int l = 0; l < 64; l++) {
+          const int pp = 16 * mt + (l & 15), m = 4 * (SH::ks_lo(mt) + i) + (l >> 4), j = m - SH::off(pp);
+          if (j >= 0 && j < 254) af[((size_t)mt * SH::NK + i) * 64 + l] = filter_src[254 - j];
+        }
+    if ((rc = upload(d_afrag_fir, af.data(), af.size()))) return rc;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 48, 255, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    fir_mfma = true;
+  }
   if ((rc = d_gain.alloc((size_t)S * max_if))) return rc;
   if ((rc = d_dec.alloc((size_t)S * max_if))) return rc;
   if (fused_ok && (rc = d_fused_part.alloc((size_t)S * 3 * (max_if / 384 + 4)))) return rc;
@@ -1290,7 +1329,14 @@ int fmr_chain::run_front_end(CallCtx &k) {
                              fes, d_mid.p, (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag5h.p,
                              poly5h_nkb, poly5h_inv_scale, rs.TB, kB_prev, (int)N_if, ifbuf, (long long)(H_if + max_if), H_if,
                              poly2_tile, tiles);
-        else if (poly4)
+        else if (poly4_am) {
+          const long long Pf = kB_prev / 48, Pl = (kB_prev + N_if - 1) / 48;
+          const int tiles_am = (int)((Pl - Pf) / 64 + 1);
+          hipLaunchKernelGGL((k_ifr_poly4<48, 128, 214>), dim3(std::min(tiles_am, 512), S), dim3(256),
+                             sizeof(float2) * (size_t)(((poly4_am_tile + 127) / 128) * 128 + 4 * 8 * 48), fes, d_mid.p,
+                             (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag.p, kB_prev,
+                             (int)N_if, ifbuf, (long long)(H_if + max_if), H_if, poly4_am_tile, tiles_am);
+        } else if (poly4)
           hipLaunchKernelGGL((k_ifr_poly4<48, 125, 210>), dim3(std::min(tiles, 512), S), dim3(256),
                              sizeof(float2) * (size_t)(((poly2_tile + 127) / 128) * 128 + 4 * 8 * 48), fes, d_mid.p,
                              (long long)(H_mid + max_mid), mA_prev - H_mid, H_mid + count_mid, d_afrag.p, kB_prev,
@@ -1665,6 +1711,18 @@ int fmr_chain::run_if_stage(CallCtx &k) {
                            (long long)max_if, k.base, H_b + (long long)max_if, H_b, d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);
       }
       else if (blocked && mode == FMR_MODE_FM) go(k_fm_block3<256, false>);       // (FM with the equaliser behind the filter)
+      else if (blocked && fir_mfma && N_if >= 48) {
+        // AM / DSB / NBFM, 255 taps: the matrix-core form (call-relative periods of 48 outputs; buffer index m of the kernel's
+        // window arithmetic is x[m - 128], i.e. the "absolute" index of the buffer's first element is 128 - H_if)
+        constexpr int kTile = 64 * 48 + 47 + 255 + 64;
+        const int tiles_f = (int)((N_if - 1) / 48 / 64 + 1);
+        hipLaunchKernelGGL((k_ifr_poly4<48, 48, 255, 1>), dim3(std::min(tiles_f, 1024), S), dim3(256),
+                           sizeof(float2) * (size_t)(((kTile + 127) / 128) * 128 + 4 * 8 * 48), stream, ifbuf, if_stride,
+                           (long long)(128 - H_if), H_if + (int)N_if, d_afrag_fir.p, 0ll, (int)N_if, d_fir.p, (long long)max_if, 0,
+                           kTile, tiles_f);
+        hipLaunchKernelGGL(k_fir_finish<256>, dim3(nb, S), dim3(256), 0, stream, ifbuf, if_stride, H_if, bt, d_coeff.p, ntaps,
+                           d_fir.p, (long long)max_if, d_if_rms_blk.p);
+      }
       else if (blocked) {
         // the 48 kHz modes: blocks of a few hundred samples behind 255 or 2049 taps, nearly every output a head output
         constexpr int TL2 = 1024;

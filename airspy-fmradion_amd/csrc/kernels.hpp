@@ -695,8 +695,8 @@ struct Poly4Shape {
   static constexpr int XLEN = 4 * KS_ALL;                   // mid samples one period touches
 };
 
-template <int LB, int MB, int TB>
-__global__ __launch_bounds__(256, 2) void k_ifr_poly4(
+template <int LB, int MB, int TB, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void k_ifr_poly4(
     const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
     const float *__restrict__ afrag, long long k0, int count, float2 *__restrict__ out, long long out_stride,
     int out_off, int tile_len, int n_tiles) {
@@ -1247,6 +1247,39 @@ __global__ __launch_bounds__(BLOCK) void k_fm_block2(
       const float2 v = rms_after_fir ? o : xl[0];
       acc += v.x * v.x + v.y * v.y;
     }
+  }
+  const float tot = block_sum<BLOCK>(acc, scratch);
+  if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);
+}
+
+// ---------------------------------------------------------------------------
+// k_fir_finish (round 6): behind the IF FIR of the 48 kHz modes on the matrix cores.  LowPassFilterFirIQ::process
+// (Filter.cpp:37-96) sums the lags 1 .. order for the first `order` outputs of a block (the head path has no lag 0) and the
+// lags 0 .. order for the others: k_ifr_poly4<48, 48, 255> runs the lags 1 .. order for every output, one fmaf chain in lag
+// order over the stream (no block structure), this kernel adds c[0] x[i] to the outputs behind a block's head and takes the
+// block's RMS (Utility.h:118-132, AmDecode.cpp:107 / NbfmDecode.cpp) in k_fm_block2's summation order.
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fir_finish(
+    const float2 *__restrict__ ifb, long long if_stride, int if_halo, BlockTab bt, const float *__restrict__ coeff, int ntaps,
+    float2 *__restrict__ firb, long long fir_stride, float *__restrict__ if_rms_blk) {
+  __shared__ float scratch[BLOCK / 64];
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int n = bt.if_len[b];
+  if (n == 0) return;
+  const int order = ntaps - 1;
+  const float2 *x = ifb + (long long)s * if_stride + if_halo + bt.if_off[b];
+  float2 *y = firb + (long long)s * fir_stride + bt.if_off[b];
+  const float c0 = coeff[0];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += BLOCK) {
+    float2 o = y[i];
+    if (i >= order) {
+      const float2 xi = x[i];
+      o.x = fmaf(xi.x, c0, o.x); o.y = fmaf(xi.y, c0, o.y);
+      y[i] = o;
+    }
+    acc += o.x * o.x + o.y * o.y;
   }
   const float tot = block_sum<BLOCK>(acc, scratch);
   if (threadIdx.x == 0) if_rms_blk[(long long)s * bt.nb + b] = sqrtf(tot / (float)(unsigned)n);

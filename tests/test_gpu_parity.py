@@ -63,6 +63,43 @@ def test_if_resampler(fin, fout_mode, blk, nblk):
     ch.close()
 
 
+def test_if_resampler_384k_matrix_core_form_against_the_vector_form(monkeypatch):
+    """Round 6: 384 k -> 48 k (LB / MB = 3 / 8, TB = 214) runs as sixteen periods per 48 / 128 row block on the banded
+    matrix-core kernel of the 48 / 125 shape (k_ifr_poly4<48, 128, 214>).  Ragged blocks in calls of several tiles, so
+    that the call starts fall on every output position mod 48; against the oracle (2e-6) and against the kernel it
+    replaced (FMR_NO_FUSED=1: k_ifr_poly3, the same taps in the same order on the vector ALUs)."""
+    rng = np.random.default_rng(11)
+    lens = [int(v) for v in rng.integers(1, 2049, 300)] + [2048] * 200
+    n = sum(lens)
+    x = siggen.am_iq(n, 384e3)
+    calls, i = [], 0
+    while i < len(lens):
+        k = int(rng.integers(1, 101))
+        calls.append(lens[i:i + k]); i += k
+
+    def run():
+        ch = fmr.Chain(mode=fmr.MODE_AM, input_rate=384e3, enable_resampler=True, max_block_len=2048, max_blocks=100,
+                       filter_coeff=load_filter("jj1bdx_am_48khz_narrow"))
+        out, pos = [], 0
+        for ll in calls:
+            m = sum(ll)
+            ch.process_blocks(x[None, pos:pos + m], ll)
+            out.append(ch.debug_read(0))
+            pos += m
+        ch.close()
+        return np.concatenate(out)
+
+    a = run()
+    monkeypatch.setenv("FMR_NO_FUSED", "1")
+    b = run()
+    r = ora.IfResampler(384e3, 48e3)
+    q = np.concatenate([r.process(blk) for blk in np.split(x, np.cumsum(lens)[:-1])])
+    assert len(a) == len(b) == len(q)
+    rel_o, rel_v = rms(a - q) / rms(q), rms(a - b) / rms(q)
+    _report("if_resampler_384k_poly4_am", n=len(q), rel_rms_vs_oracle=rel_o, rel_rms_vs_vector_form=rel_v, max_abs_vs_vector_form=float(np.max(np.abs(a - b))))
+    assert rel_o < 2e-6 and rel_v < 1e-6
+
+
 def test_fourth_converter_front_end():
     blk, nblk = 16384, 4
     # zero-IF receivers deliver the station at +fs/4 (main.cpp:912-919): put it there

@@ -28,14 +28,21 @@ def main():
     ap.add_argument("--r8b", action="store_true", help="the R8B resampler class (three-kernel front end, fp16 stage B)")
     ap.add_argument("--if-filter", action="store_true", help="the IF filter (-f medium) behind the fused front end")
     ap.add_argument("--sigma", type=float, default=1e-3, help="noise per I / Q component (bench.py --sigma)")
+    ap.add_argument("--am", action="store_true", help="config 3: AM 384 kS/s -> 48 k narrow (8192 blocks of 2048 samples per step)")
     args = ap.parse_args()
     import torch
     fmr = importlib.import_module("airspy-fmradion_amd")
     dev = torch.device("cuda", 0)
     B, blk = args.blocks, bench.BLK
+    if args.am:
+        B, blk = (8192 if args.blocks == 2048 else args.blocks), bench.AM_BLK
     n = B * blk
-    iq = torch.stack([bench.synth_fm_stereo_torch(n, bench.FS, 0, dev, sigma=args.sigma)])
-    audio = torch.zeros((1, 2 * (int(n * 0.0048) + 64)), dtype=torch.float64, device=dev)
+    if args.am:
+        iq = torch.stack([bench.synth_am_torch(n, bench.AM_FS, 0, dev)])
+        audio = torch.zeros((1, int(n * 0.125) + 64), dtype=torch.float64, device=dev)
+    else:
+        iq = torch.stack([bench.synth_fm_stereo_torch(n, bench.FS, 0, dev, sigma=args.sigma)])
+        audio = torch.zeros((1, 2 * (int(n * 0.0048) + 64)), dtype=torch.float64, device=dev)
     kw = {}
     if args.r8b:
         kw["resampler_class"] = fmr.RESAMPLER_R8B
@@ -43,7 +50,12 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from conftest import load_filter
         kw.update(fmfilter_enable=True, filter_coeff=load_filter("jj1bdx_fm_384kHz_medium"))
-    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=bench.FS, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=B, **kw)
+    if args.am:
+        import numpy as np
+        narrow = np.load(os.path.join(ROOT, "tests", "golden", "filters", "jj1bdx_am_48khz_narrow.npy"))
+        ch = fmr.Chain(mode=fmr.MODE_AM, input_rate=bench.AM_FS, enable_resampler=True, filter_coeff=narrow, max_block_len=blk, max_blocks=B)
+    else:
+        ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=bench.FS, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=B, **kw)
     bl = [blk] * B
 
     def step():
