@@ -254,6 +254,8 @@ struct fmr_chain {
   DevBuf<float> d_afrag;               // v4: constant A fragments
   // fused front end (kernels_fused.hpp): stage A + stage B + discriminator in one persistent kernel
   bool fused_ok = false;               // the chain's shape fits (10 MS/s class, FM, cf32, no Fs/4)
+  bool r8b_disc_ok = false;            // R8B class, FM, nothing between resampler and discriminator: the discriminator is k_ifr_poly5h's epilogue
+  DevBuf<float> d_run_ph;              // ... [S][workgroup][2]: phases on either side of the workgroups' run boundaries (k_poly5h_heads)
   bool fused_disc_ok = false;          // ... and nothing sits between the resampler and the discriminator (no IF FIR, no equaliser)
   DevBuf<float> d_hB_last;             // stage-B tap row of position 47
   DevBuf<unsigned short> d_fused_afragA;   // stage-A tap fragments (fp16 high / low terms, both parities)
@@ -363,7 +365,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag_fir.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_run_ph.release(); d_afrag_fir.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_walk_go.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -510,6 +512,9 @@ struct fmr_chain {
     bool use_fused{};
     bool fused_disc{};     // the fused kernel's epilogue is the discriminator (else: IF samples only)
     bool fir_disc{};       // the IF filter kernel's epilogue is the discriminator (k_fm_block3<.., true>)
+    bool r8b_tail{};       // R8B class: stage B is launched from run_tables with the discriminator as its epilogue (fused_disc is set too)
+    long long r8b_mA_prev{}, r8b_kB_prev{};
+    int r8b_count_mid{};
     FusedGeom fused_geom{};
     int par{};
     float2 *ifbuf = nullptr;
@@ -780,6 +785,10 @@ int fmr_chain::init(const fmr_config *c) {
                 if ((rc = upload(d_afrag5h, ah.data(), ah.size()))) return rc;
                 poly5h = true; poly5h_nkb = nkb; poly5h_inv_scale = std::ldexp(1.0f, -ea); poly5h_lds = lds5h;
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly5h<48, 125>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5h));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly5h<48, 125, Poly5hDiscEpi>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5h));
+                r8b_disc_ok = mode == FMR_MODE_FM && in_fmt == 0 && !c->fmfilter_enable && c->multipath_stages == 0 && !env.no_fused;
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
               }
             }
           }
@@ -915,7 +924,8 @@ int fmr_chain::init(const fmr_config *c) {
   }
   if ((rc = d_gain.alloc((size_t)S * max_if))) return rc;
   if ((rc = d_dec.alloc((size_t)S * max_if))) return rc;
-  if (fused_ok && (rc = d_fused_part.alloc((size_t)S * 3 * (max_if / 384 + 4)))) return rc;
+  if ((fused_ok || r8b_disc_ok) && (rc = d_fused_part.alloc((size_t)S * 3 * (max_if / 384 + 20)))) return rc;
+  if (r8b_disc_ok && (rc = d_run_ph.alloc((size_t)S * 2 * kMaxFusedWg))) return rc;
   if (fused_ok && (rc = d_fused_mid32.alloc((size_t)std::max(std::max(n_cu, S), 256) * 2 * FusedShape<kFusedD, kFusedNA>::MIDR))) return rc;
   if (fused_ok && (rc = d_zero16.alloc(4))) return rc;
   if (fused_ok && env.fe_stamps && (rc = d_fe_stamps.alloc(3 * (size_t)kMaxFusedWg * S + 2 * kStampCalls * 16))) return rc;
@@ -998,7 +1008,7 @@ int fmr_chain::init(const fmr_config *c) {
       for (int q = 1; q < kPipe; q++) {
         if ((rc = d_base_pp[q].alloc((size_t)S * (H_b + max_if)))) return rc;
         if ((rc = d_raw_pp[q].alloc((size_t)S * (H_b + max_if)))) return rc;
-        if (fused_ok && (rc = d_part_pp[q].alloc(d_fused_part.n))) return rc;
+        if ((fused_ok || r8b_disc_ok) && (rc = d_part_pp[q].alloc(d_fused_part.n))) return rc;
         if ((rc = d_stereo_pp[q].alloc((size_t)S * max_blocks))) return rc;
       }
     if ((rc = d_base_de.alloc((size_t)S * (H_a + max_if)))) return rc;
@@ -1262,6 +1272,13 @@ int fmr_chain::run_front_end(CallCtx &k) {
       for (int b = 0; b < nb; b++) if (t_if_len[b] != 0 && t_if_len[b] < 128) use_fused = false;
     }
     k.fused_disc = use_fused && fused_disc_ok;
+    // R8B class: the dense stage B carries the discriminator epilogue (it needs the block table: launched from run_tables)
+    k.r8b_tail = false;
+    if (!use_fused && r8b_disc_ok && poly5h && has_dec && !serial_mode && N_if >= 3072 && count_mid > 0) {
+      k.r8b_tail = true;
+      for (int b = 0; b < nb; b++) if (t_if_len[b] != 0 && t_if_len[b] < 128) k.r8b_tail = false;
+    }
+    if (k.r8b_tail) { k.fused_disc = true; k.r8b_mA_prev = mA_prev; k.r8b_kB_prev = kB_prev; k.r8b_count_mid = count_mid; }
     dec_valid = !k.fused_disc || debug_taps;   // the float copy of the discriminator output is a debug tap of the fused kernel
     if_valid = dec_valid;                      // ... and so are the IF samples behind its discriminator epilogue (the slot holds |x|^2 then)
     if (use_fused) {
@@ -1319,7 +1336,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
         });
       }
     }
-    if (use_fused) {
+    if (use_fused || k.r8b_tail) {
     } else if (N_if > 0 && poly2_tile > 0) {
       const long long P_first = kB_prev / rs.LB, P_last = (kB_prev + N_if - 1) / rs.LB;
       const int tiles = (int)((P_last - P_first) / 64 + 1);
@@ -1373,7 +1390,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
                            ifbuf, (long long)(H_if + max_if), H_if);
       });
     }
-    if (N_in > 0 && !use_fused) {
+    if (N_in > 0 && !use_fused && !(k.r8b_tail && pipelined)) {
       timed_on(fes, "in_halo", [&] {
         switch (in_fmt) {
         case 1: hipLaunchKernelGGL((k_update_in_halo<256, 1>), dim3(1, S), dim3(256), 0, fes, d_in_halo.p, H_in, d_iq, (long long)stride, N_in); break;
@@ -1400,7 +1417,7 @@ int fmr_chain::run_front_end(CallCtx &k) {
   if (has_rs && pipelined) {
     // the front-end stage keeps its own history: the stage-B halo is re-seated on its stream (after the fused kernel,
     // which is launched from run_tables, when that one runs)
-    if (!use_fused) {
+    if (!use_fused && !k.r8b_tail) {
       if (int rcf = finish_front_end_stage(k)) return rcf;
     }
   } else if (has_rs) {
@@ -1553,6 +1570,41 @@ int fmr_chain::run_tables(CallCtx &k) {
       hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((kFusedTile0Off + fused_grid + 1 + 255) / 256)), dim3(256), 0, side,
                          (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), kFusedTile0Off + fused_grid + 1);
   }
+  int r8b_grid = 0, r8b_tpw = 0, r8b_tiles = 0;
+  if (k.r8b_tail) {
+    // R8B class: contiguous runs of stage-B tiles (64 periods = 3072 IF samples) per workgroup; the table's tail carries the
+    // block that holds the first IF sample of every run, as for the fused front end
+    const long long P_first = k.r8b_kB_prev / 48, P_last = (k.r8b_kB_prev + N_if - 1) / 48;
+    r8b_tiles = (int)((P_last - P_first) / 64 + 1);
+    const int wgs = std::max(1, std::min(kFusedTile0Off - 1, n_cu / S));
+    r8b_tpw = (r8b_tiles + wgs - 1) / wgs;
+    r8b_grid = (r8b_tiles + r8b_tpw - 1) / r8b_tpw;
+    fused_n_tiles = 8 * r8b_tiles;                             // in the epilogue's macro tiles of 384 samples
+    const long long kb_ref = 48 * P_first - k.r8b_kB_prev;
+    fused_kb_ref = (int)kb_ref;
+    {   // the first block k_stats walks (same rule as above)
+      int seen = 0, b_first = 0;
+      for (int b0 = ((nb - 1) / 64) * 64; b0 > 0 && !b_first; b0 -= 64) {
+        for (int b = b0; b < std::min(b0 + 64, nb); b++) seen += t_if_len[b] != 0;
+        if (seen >= 400) b_first = b0;
+      }
+      fused_part_from = t_if_off[b_first];
+    }
+    int *t_wg = h_tab + (tab_ints - kMaxFusedWg);
+    int b = 0;
+    for (int w = 0; w < r8b_grid; w++) {
+      const long long kf = std::max<long long>(0, kb_ref + 3072ll * w * r8b_tpw);
+      while (b < nb && (long long)t_if_off[b] + t_if_len[b] <= kf) b++;
+      t_wg[w] = b;
+    }
+    if (pipelined)
+      hipLaunchKernelGGL(k_copy_ints2, dim3((unsigned)((r8b_grid + 2 * (size_t)max_blocks + 255) / 256)), dim3(256), 0, stream,
+                         (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), r8b_grid, (const int *)h_tab, d_tab_slot,
+                         2 * max_blocks);
+    else
+      hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((r8b_grid + 255) / 256)), dim3(256), 0, side,
+                         (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), r8b_grid);
+  }
   int *d_first = d_tab_slot + 5 * (size_t)max_blocks;
   int *d_ck = d_tab_slot + head_ints;
   ct = ChunkTab{d_ck, d_ck + max_ck, d_ck + 2 * max_ck, d_first, nck};
@@ -1667,6 +1719,43 @@ int fmr_chain::run_tables(CallCtx &k) {
                            d_mid.p, (long long)(H_mid + max_mid), H_mid, count_mid, d_state.p, commit);
       };
       // the previous call's tail stage: behind this front end, beside this call's PLL stage
+      if (int rc = flush_tail(ev_fe[k.par])) return rc;
+    }
+  }
+  if (k.r8b_tail) {
+    // ---- R8B class: stage B with the discriminator epilogue (the fused front end's, a wave per 384 staged samples)
+    FusedArgs a{};
+    a.n_if = (int)N_if; a.kb_ref = fused_kb_ref;
+    a.out = nullptr; a.out_stride = if_stride; a.out_off = H_if;
+    a.nrm = reinterpret_cast<float *>(ifbuf); a.nrm_stride = 2 * if_stride; a.nrm_off = 0;
+    if (debug_taps) { a.out = ifbuf; a.nrm = nullptr; }      // the IF samples themselves (fmr_debug_read 0); the AGC reads them then
+    k.nrm = a.nrm; k.nrm_stride = a.nrm_stride;
+    a.base = k.base; a.base_stride = H_b + (long long)max_if; a.base_off = H_b;
+    a.dec = debug_taps ? d_dec.p : nullptr; a.dec_stride = (long long)max_if;
+    a.nf = disc_nf; a.bound = disc_bound;
+    a.st = d_state.p; a.part = k.part; a.n_tiles = fused_n_tiles; a.part_from = fused_part_from;
+    a.if_off = bt.if_off; a.if_len = bt.if_len; a.nb = nb;
+    a.wg_blk0 = d_tab_slot + (tab_ints - kMaxFusedWg);
+    a.mid32 = d_run_ph.p;
+    if ((size_t)a.n_tiles * 3 * S > d_fused_part.n || (size_t)r8b_grid * 2 * S > d_run_ph.n) { set_err("internal capacity exceeded (stage-B tiles)"); return FMR_ERR_CAPACITY; }
+    if (pipelined && disc_commit_on_side) HIPCHK(hipStreamWaitEvent(stream, ev_stats, 0));
+    timed_on(stream, "ifr_poly", [&] {
+      hipLaunchKernelGGL((k_ifr_poly5h<48, 125, Poly5hDiscEpi>), dim3(r8b_grid, S), dim3(64 * FMR_POLY5H_WAVES), poly5h_lds, stream,
+                         d_mid.p, (long long)(H_mid + max_mid), k.r8b_mA_prev - H_mid, H_mid + k.r8b_count_mid, d_afrag5h.p,
+                         poly5h_nkb, poly5h_inv_scale, rs.TB, k.r8b_kB_prev, (int)N_if, (float2 *)nullptr, 0ll, 0, poly2_tile, r8b_tiles,
+                         a, r8b_tpw);
+      if (r8b_grid > 1)
+        hipLaunchKernelGGL(k_poly5h_heads, dim3((r8b_grid + 62) / 64, S), dim3(64), 0, stream, a, r8b_grid, r8b_tpw);
+    });
+    if (pipelined) {
+      // as behind the fused front end: the PLL stage starts from here; input history, stage-B history and the
+      // discriminator's phase are one small kernel behind the PLL's first pass
+      HIPCHK(hipEventRecord(ev_fe[k.par], stream));
+      const int count_mid = k.r8b_count_mid;
+      k.fe_post = [=] {
+        hipLaunchKernelGGL(k_fe_post<256>, dim3(3, S), dim3(256), 0, stream, d_in_halo.p, H_in, d_iq, (long long)stride, N_in,
+                           d_mid.p, (long long)(H_mid + max_mid), H_mid, count_mid, d_state.p, 1);
+      };
       if (int rc = flush_tail(ev_fe[k.par])) return rc;
     }
   }

@@ -844,11 +844,21 @@ struct FmrH8Shifted {
   static constexpr int kReads = A ? 2 : 1;
 };
 
-template <int LB, int MB>
+// What happens to a finished tile (64 periods = 3072 IF samples, staged in LDS): Poly5hStoreIf writes the IF samples out (the
+// tiles of a call interleaved over the workgroups); Poly5hDiscEpi (kernels_fused.hpp, round 6) runs the phase discriminator
+// and the block statistics there -- the fused front end's epilogue, a wave per 384 samples -- over CONTIGUOUS runs of
+// tiles_per_wg tiles per workgroup, and the IF samples never go to HBM (k_disc was a separate 52-57 us pass over them).
+struct Poly5hStoreIf {
+  struct Args { int unused; };
+  static constexpr bool kOn = false;
+};
+
+template <int LB, int MB, class EPI = Poly5hStoreIf>
 __global__ __launch_bounds__(64 * FMR_POLY5H_WAVES) void k_ifr_poly5h(
     const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
     const _Float16 *__restrict__ afrag, int n_kb, float inv_tap_scale, int TB, long long k0, int count,
-    float2 *__restrict__ out, long long out_stride, int out_off, int tile_len, int n_tiles) {
+    float2 *__restrict__ out, long long out_stride, int out_off, int tile_len, int n_tiles,
+    typename EPI::Args ea = typename EPI::Args{}, int tiles_per_wg = 0) {
   static_assert(LB == 48, "three 16-row tiles");
   constexpr int KCH = FMR_POLY5H_KCH, MT = LB / 16, NWV = FMR_POLY5H_WAVES, NT = 64 * NWV, NH = 8 / NWV;
   static_assert(NWV == 4 || NWV == 8, "eight column tiles per tile: two per wave or one");
@@ -864,6 +874,7 @@ __global__ __launch_bounds__(64 * FMR_POLY5H_WAVES) void k_ifr_poly5h(
   float2 *stage = reinterpret_cast<float2 *>(abuf);
   static_assert(2 * CHB >= NWV * 8 * LB * (int)sizeof(float2), "the staging area fits over the A buffers");
   __shared__ float s_max[NWV];
+  __shared__ float s_carry[2];                                 // (EPI: phase of the previous tile's last sample, double buffered)
   const int s = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
@@ -872,6 +883,12 @@ __global__ __launch_bounds__(64 * FMR_POLY5H_WAVES) void k_ifr_poly5h(
   float2 *os = out + (long long)s * out_stride + out_off;
   float2 *mystage = stage + wave * (8 * LB);
   const int n_chunks = n_kb / KCH;
+  // the workgroup's tiles: blockIdx.x, + gridDim.x, ... or (EPI) the contiguous run [tile_lo, tile_hi)
+  const int tile_lo = EPI::kOn ? (int)blockIdx.x * tiles_per_wg : (int)blockIdx.x;
+  const int tile_hi = EPI::kOn ? min(tile_lo + tiles_per_wg, n_tiles) : n_tiles;
+  const int tile_step = EPI::kOn ? 1 : (int)gridDim.x;
+  EPI epi;
+  if constexpr (EPI::kOn) { static_assert(NWV == 8 && LB == 48, "a wave per 384 staged samples"); if (tile_lo < tile_hi) epi.begin(ea, s, lane); }
   auto fetch_a = [&](int c) {       // chunk c -> buffer c & 1: CHB / 1024 one-KB pieces, wave w issues pieces w, w + 4, ...
     const unsigned char *src = reinterpret_cast<const unsigned char *>(afrag) + (size_t)c * CHB;
     unsigned char *dst = abuf + (c & 1) * CHB;
@@ -879,7 +896,7 @@ __global__ __launch_bounds__(64 * FMR_POLY5H_WAVES) void k_ifr_poly5h(
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
   };
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int tile = tile_lo; tile < tile_hi; tile += tile_step) {
     const long long P0 = k0 / LB + (long long)tile * 64;
     const long long a0 = P0 * MB - W + 1;
     __syncthreads();                                          // previous tile fully consumed
@@ -1026,6 +1043,19 @@ __global__ __launch_bounds__(64 * FMR_POLY5H_WAVES) void k_ifr_poly5h(
       }
     }
     __syncthreads();                                          // everybody has read its last A fragments: the buffers become the staging area
+    if constexpr (EPI::kOn) {
+      // the tile in sample order: period 8 (n / 2) + wave of the tile, position 16 mt + 4 kq + v, component n & 1
+      float *sf = reinterpret_cast<float *>(stage);
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) sf[2 * ((8 * (n >> 1) + wave) * LB + 16 * mt + 4 * kq + v) + (n & 1)] = tot[0][mt][v] * inv;
+      __syncthreads();
+#ifndef FMR_P5H_NO_EPI_CALL
+      epi.tile(ea, s, stage, (int)(P0 * LB - k0), tile, tile == tile_lo, tile + 1 == tile_hi, lane, wave, s_carry);
+#endif
+      continue;
+    }
     // D[row = 4 kq + v][col = n] -> position p = 16 mt + 4 kq + v of period 8 (n / 2) + t, component n & 1
 #pragma unroll
     for (int h = 0; h < NH; h++) {

@@ -846,6 +846,83 @@ __global__ void k_fused_blk_reduce(const FusedPart *__restrict__ part, int n_til
   if_rms_blk[(long long)s * nb + b] = sqrtf(se / fn);
 }
 
+// ---- the same epilogue behind the dense stage B of the R8B resampler class (k_ifr_poly5h, kernels.hpp; round 6) ----------
+// A tile of that kernel is 3072 consecutive IF samples staged in LDS in sample order: wave w takes samples 384 w .. 384 w + 383
+// -- a "macro tile" of the epilogue above, three thirds of 128 -- with the same partial-sum records (FusedPart, macro tile
+// 8 tile + w), so that everything behind the front end (k_stats, the IF AGC's state solve on |x|^2, the PLL stage) is what it
+// is behind the fused kernel.  A workgroup walks a contiguous run of tiles: the phase of the sample before a tile is the
+// previous tile's last one (s_carry), and the first sample of a RUN is left to k_poly5h_heads -- the phases on either side
+// of a run boundary are each computed by the tile that owns the sample, so the result does not depend on how the call is
+// cut into runs.  Of FusedArgs this uses: n_if, nf, bound, base*, nrm*, out*, dec*, st, part, n_tiles (= 8 x tiles),
+// part_from, if_off / if_len / nb, wg_blk0.
+struct Poly5hDiscEpi {
+  using Args = FusedArgs;
+  static constexpr bool kOn = true;
+  int blk, it;
+  FusedBlkWin win;
+  float save0;
+  __device__ __forceinline__ void begin(const Args &a, int s, int lane) {
+    save0 = a.st[s].disc_save;
+    blk = a.wg_blk0[(int)blockIdx.x];
+    win.load(a, blk, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(save0), "+v"(win.end_l), "+v"(win.len_l));
+    blk = __builtin_amdgcn_readfirstlane(blk);
+    it = 0;
+  }
+  // kb: call-relative IF index of the tile's first sample; run_ph = a.mid32 reused: [stream][workgroup][2] phases of the
+  // run's first and last sample
+  __device__ __forceinline__ void tile(const Args &a, int s, const float2 *stage, int kb, int tile, bool first, bool last, int lane,
+                                       int wave, float *s_carry) {
+    const float inv_nf = 1.0f / a.nf;
+    const float2 *mst = stage + 384 * wave;
+    const int kbm = kb + 384 * wave, tile_g = 8 * tile + wave;
+    float2 *os = a.out ? a.out + (long long)s * a.out_stride + a.out_off : nullptr;
+    float *run_ph = a.mid32 + ((size_t)s * gridDim.x + blockIdx.x) * 2;
+    float prev0;
+    if (wave == 0) {
+      if (kb <= 0) prev0 = save0;                             // (the call's sample 0 takes save0 by its own test)
+      else if (first) prev0 = __builtin_nanf("");             // unknown here: difference 0, k_poly5h_heads fills it in
+      else prev0 = s_carry[it & 1];
+    } else { const float2 xp = stage[384 * wave - 1]; prev0 = fused_atan2(xp.y, xp.x) * inv_nf; }
+#ifndef FMR_P5H_EPI_ABL
+#define FMR_P5H_EPI_ABL 0        // (diagnostic builds: fused_epilogue's ablation mask -- 128 no global stores, 256 no block sums)
+#endif
+    fused_epilogue<0, FMR_P5H_EPI_ABL>(a, s, mst, kbm, tile_g, blk, win, prev0, save0, os, lane);
+    { const float2 xp = mst[127]; prev0 = fused_atan2(xp.y, xp.x) * inv_nf; }
+    fused_epilogue<1, FMR_P5H_EPI_ABL>(a, s, mst, kbm, tile_g, blk, win, prev0, save0, os, lane);
+    { const float2 xp = mst[255]; prev0 = fused_atan2(xp.y, xp.x) * inv_nf; }
+    fused_epilogue<2, FMR_P5H_EPI_ABL>(a, s, mst, kbm, tile_g, blk, win, prev0, save0, os, lane);
+    if (wave == 7 && lane == 0) {
+      const float2 xl = stage[3071];
+      const float ph = fused_atan2(xl.y, xl.x) * inv_nf;
+      s_carry[(it + 1) & 1] = ph;
+      if (last) run_ph[1] = ph;
+    }
+    if (wave == 0 && lane == 0 && first) { const float2 xf = stage[0]; run_ph[0] = fused_atan2(xf.y, xf.x) * inv_nf; }
+    it++;
+  }
+};
+
+// the first sample of every run but the call's first: phase difference across the run boundary, and its share of the block sums
+__global__ void k_poly5h_heads(FusedArgs a, int grid, int tiles_per_wg) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x + 1, s = blockIdx.y;
+  if (w >= grid) return;
+  const int kb = a.kb_ref + 3072 * (w * tiles_per_wg);
+  if (kb <= 0 || kb >= a.n_if) return;
+  const float *run_ph = a.mid32 + (size_t)s * grid * 2;
+  float d = run_ph[2 * w] - run_ph[2 * (w - 1) + 1];                                 // V5, as fused_epilogue
+  if (d > a.bound) d -= 2 * a.bound;
+  if (d < -a.bound) d += 2 * a.bound;
+  if (isnan(d)) d = 0.f;
+  a.base[(long long)s * a.base_stride + a.base_off + kb] = d;
+  if (a.dec) a.dec[(long long)s * a.dec_stride + kb] = d;
+  if (kb + 128 > a.part_from) {
+    FusedPart *pt = a.part + ((long long)s * a.n_tiles + 8ll * w * tiles_per_wg) * 3;
+    pt->sum[0][0] += d; pt->sum[0][1] += d * d;
+  }
+}
+
 // ABL: ablation mask for tools/bench_fused.hip (0 = product; 1 no stage-A arithmetic, 2 no stage-B MFMAs, 4 no input DMA)
 #define FUSED_THREADS 512     // eight waves, two per SIMD: loader, three stage-B waves, four stage-A waves
 template <int D, int NA, int PAR, int ABL = 0>

@@ -157,3 +157,53 @@ def test_r8b_fp16_stage_b_strong_and_weak_signal():
         ref = np.concatenate([r.process(b) for b in siggen.blocks(x, blk)])
         assert len(got) == len(ref)
         assert rms(got - ref) / rms(ref) < 2e-6, (amp, rms(got - ref) / rms(ref))
+
+
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_r8b_discriminator_epilogue_against_the_separate_kernel(pipeline, monkeypatch):
+    """Round 6: in the R8B class the phase discriminator and the block statistics are the epilogue of the dense stage B
+    (k_ifr_poly5h<.., Poly5hDiscEpi> + k_poly5h_heads), the IF samples stay on chip.  The same two streams, cut into random
+    blocks and random calls (short calls and calls with tiny blocks take the three-kernel path with k_disc, long ones the
+    epilogue), through the product and through a chain built with FMR_NO_FUSED=1 (stage B stores the IF, k_disc reads it):
+    the IF samples are the same numbers either way, the two discriminators differ by the rounding of atan2 (1e-7): audio
+    within 1e-6 RMS, identical block lengths, lock decisions and PPS events, levels to 1e-5; pipelined chain and in-order
+    chain."""
+    monkeypatch.setenv("FMR_PIPELINE", pipeline)
+    rng = np.random.default_rng(21)
+    lens = []
+    while sum(lens) < 5_000_000:
+        lens.append(int(rng.integers(1, 65537)) if rng.random() < 0.4 else 65536)
+    n = sum(lens)
+    xs = np.stack([siggen.fm_stereo_iq(n, 10e6, stream_id=s) for s in range(2)])
+    calls, i = [], 0
+    while i < len(lens):
+        k = int(rng.integers(1, 31))
+        calls.append(lens[i:i + k]); i += k
+
+    def run():
+        ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, n_streams=2,
+                       max_block_len=65536, max_blocks=30, resampler_class=fmr.RESAMPLER_R8B)
+        out, alens, locks, pps, lv, pos = [[], []], [], [], [], [], 0
+        for ll in calls:
+            m = sum(ll)
+            a, alen = ch.process_blocks(xs[:, pos:pos + m], ll)
+            out[0].append(a[0]); out[1].append(a[1])
+            alens += list(alen); pos += m
+            st = [ch.status(0), ch.status(1)]
+            locks.append((st[0].stereo_detected, st[1].stereo_detected))
+            lv.append([(q.if_rms, q.baseband_mean, q.baseband_level, q.pilot_level, q.if_agc_gain) for q in st])
+            pps.append([(e[0], e[1], e[3]) for e in ch.pps_events(0)])
+        ch.close()
+        return np.concatenate(out[0]), np.concatenate(out[1]), alens, locks, pps, np.array(lv)
+
+    a0, a1, al_a, lk_a, pp_a, lv_a = run()
+    monkeypatch.setenv("FMR_NO_FUSED", "1")
+    b0, b1, al_b, lk_b, pp_b, lv_b = run()
+    assert al_a == al_b and lk_a == lk_b and pp_a == pp_b
+    assert lk_a[-1] == (1, 1)
+    assert rms(a0 - b0) < 1e-6 and rms(a1 - b1) < 1e-6, (rms(a0 - b0), rms(a1 - b1))
+    # levels: if_rms, baseband level, AGC gain relative 1e-5; the baseband mean sits near zero (absolute 1e-6); pilot level 4e-6 of its scale
+    for c, tol in ((0, 1e-5), (2, 1e-5), (4, 2e-4)):
+        assert np.max(np.abs(lv_a[..., c] - lv_b[..., c]) / np.maximum(np.abs(lv_b[..., c]), 1e-12)) < tol, c
+    assert np.max(np.abs(lv_a[..., 1] - lv_b[..., 1])) < 1e-6
+    assert np.max(np.abs(lv_a[..., 3] - lv_b[..., 3])) < 1e-6
