@@ -28,6 +28,7 @@
 #include "kernels.hpp"
 #include "kernels_par.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_decim16.hpp"
 
 namespace {
 #include "filter_tables.inc"
@@ -254,6 +255,8 @@ struct fmr_chain {
   DevBuf<float> d_afrag;               // v4: constant A fragments
   // fused front end (kernels_fused.hpp): stage A + stage B + discriminator in one persistent kernel
   bool fused_ok = false;               // the chain's shape fits (10 MS/s class, FM, cf32, no Fs/4)
+  bool decim16_ok = false;             // R8B class at 10 MS/s: stage A in the fused front end's matrix-core form (k_ifr_decim16<10, 195>)
+  DevBuf<unsigned short> d_dec16_afrag;
   bool r8b_disc_ok = false;            // R8B class, FM, nothing between resampler and discriminator: the discriminator is k_ifr_poly5h's epilogue
   DevBuf<float> d_run_ph;              // ... [S][workgroup][2]: phases on either side of the workgroups' run boundaries (k_poly5h_heads)
   bool fused_disc_ok = false;          // ... and nothing sits between the resampler and the discriminator (no IF FIR, no equaliser)
@@ -365,7 +368,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_run_ph.release(); d_afrag_fir.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_dec16_afrag.release(); d_run_ph.release(); d_afrag_fir.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_walk_go.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -710,6 +713,22 @@ int fmr_chain::init(const fmr_config *c) {
         std::vector<float> hp((size_t)rs.D * qa, 0.f);
         for (int k = 0; k < rs.NA; k++) hp[(size_t)(k % rs.D) * qa + k / rs.D] = fa[k];
         if ((rc = upload(d_hpA, hp.data(), hp.size()))) return rc;
+      }
+    }
+    if (rs.D == 10 && rs.NA == 195 && in_fmt == 0 && !c->enable_fourth_down && !env.no_fused && !env.serial) {
+      bool sym = true;
+      for (int k = 0; sym && k < rs.NA / 2; k++) sym = (fa[k] == fa[rs.NA - 1 - k]);
+      if (sym) {
+        using SH16 = Decim16Shape<10, 195>;
+        std::vector<unsigned short> fr((size_t)2 * SH16::NKT * 2 * 64 * 8);
+        decim16_make_afragA<10, 195>(fa.data(), fr.data());
+        if ((rc = upload(d_dec16_afrag, fr.data(), fr.size()))) return rc;
+        if ((rc = d_zero16.alloc(4))) return rc;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_decim16<10, 195, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SH16::LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_decim16<10, 195, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, SH16::LDS_BYTES));
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        decim16_ok = true;
       }
     }
     if (in_fmt != 0) {
@@ -1323,6 +1342,30 @@ int fmr_chain::run_front_end(CallCtx &k) {
         });
         v2_done = true;
       };
+      // R8B class, 10 MS/s: the matrix-core form behind the fused front end's input ring, a contiguous run of 500-output epochs
+      // per workgroup (calls of a few epochs per compute unit and up)
+      if (decim16_ok && count_mid >= 4 * 500 && ((uintptr_t)d_iq % 16) == 0 && (stride % 2) == 0) {
+        using SH16 = Decim16Shape<10, 195>;
+        FusedArgs a{};
+        a.iq = d_iq; a.iq_stride = (long long)stride; a.n_valid = N_in;
+        a.in_halo = d_in_halo.p; a.H_in = H_in; a.afragA = reinterpret_cast<const uint4 *>(d_dec16_afrag.p); a.hA = d_hA.p;
+        a.zero16 = reinterpret_cast<const float2 *>(d_zero16.p);
+        const long long lo0 = top0 - (rs.NA - 1);
+        const int par16 = (int)(((lo0 % 2) + 2) % 2);
+        a.nbase = lo0 - par16;
+        a.count_mid = count_mid;
+        a.mid = d_mid.p; a.mid_stride = (long long)(H_mid + max_mid); a.H_mid = H_mid;
+        a.n_tiles = (count_mid + SH16::ME - 1) / SH16::ME;
+        const int fe_cus = pipelined ? std::max(8, n_cu - kFeSpareCus) : n_cu;
+        const int wgs = std::max(1, fe_cus / S);
+        a.tiles_per_wg = (a.n_tiles + wgs - 1) / wgs;
+        const int grid16 = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+        timed_on(fes, "ifr_decim", [&] {
+          if (par16) hipLaunchKernelGGL((k_ifr_decim16<10, 195, 1>), dim3(grid16, S), dim3(DECIM16_THREADS), SH16::LDS_BYTES, fes, a);
+          else hipLaunchKernelGGL((k_ifr_decim16<10, 195, 0>), dim3(grid16, S), dim3(DECIM16_THREADS), SH16::LDS_BYTES, fes, a);
+        });
+        v2_done = true;
+      } else
       launch_decim2(std::integral_constant<int, 128>{});
       if (v2_done) {
       } else if (in_fmt != 0) {

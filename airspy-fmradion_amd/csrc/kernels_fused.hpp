@@ -104,6 +104,7 @@ constexpr int kFusedD = 10, kFusedNA = 103;      // the shape the product instan
 
 template <int D, int NA>
 struct FusedShape {
+  static constexpr int DEC = D;
   static constexpr int ME = 500;                 // mid samples per epoch
   static constexpr int EPT = 1000 / ME;          // epochs per macro tile
   // Input samples per ring slot.  Stage A runs on the matrix cores in column tiles of 16 outputs x 256 inputs (FusedMfmaA): the
@@ -119,7 +120,8 @@ struct FusedShape {
   static constexpr int NPOS = NPIECE + (NPIECE - 1) / PADP;
   static constexpr int PREPOS = PRE + PRE / PADP;  // position of the first piece a region does not share (below it: shared pieces and their holes)
   static constexpr int SLOT_BYTES = NPOS * 16;
-  static_assert(PREPOS > 64 && PREPOS <= 128, "fused_fill / fused_copy_preroll handle the shared pieces in DMA instructions 0 and 1");
+  static constexpr int CSKIP = PREPOS / 64;        // DMA instructions that hold shared pieces only (fused_fill skips them, fused_copy_preroll fills their positions)
+  static_assert(CSKIP == 1, "the 103-tap shape");
   static constexpr int NDMA = (NPOS + 63) / 64;
   static constexpr int NSLOT = 3, AHEAD = NSLOT - 1;   // ring slots; the loader runs AHEAD epochs in front of stage A
   // The mid signal between the stages: a ring of three macro-tile windows (3000 samples) in LDS as FOUR fp16 planes -- high
@@ -198,27 +200,28 @@ struct FusedRing {
 };
 
 // ---- role: loader ---------------------------------------------------------------------------------------
-template <int D, int NA>
 // The first PRE pieces of a region are the last PRE of the region before it (regions advance by D * ME samples): only the
 // first region of a workgroup is read whole; later ones skip them and a stage-A wave copies them from the previous slot
 // (fused_copy_preroll) -- the input crosses HBM once.  Lane l of DMA instruction c fills position 64 c + l; the lane
 // that lands on a hole fetches its neighbour's piece again (same cache line, never read from LDS).
-__device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, const float2 *hs, int jE,
-                                          unsigned char *slot, int lane, bool whole) {
-  using SH = FusedShape<D, NA>;
+// (SH: FusedShape, or Decim16Shape of kernels_decim16.hpp -- the same ring under the stage-A-only kernel of the R8B class)
+template <class SH>
+__device__ __forceinline__ int fused_fill_sh(const FusedArgs &a, const float2 *xs, const float2 *hs, int jE,
+                                             unsigned char *slot, int lane, bool whole) {
+  constexpr int D = SH::DEC;
   const long long nb = a.nbase + (long long)D * jE;
   if (nb >= 0 && nb + SH::RS <= a.n_valid) {
     const float2 *src = xs + nb;
     int issued = 0;
 #pragma unroll
     for (int c = 0; c < SH::NDMA; c++) {
-      if (c == 0 && !whole) continue;
+      if (c < SH::CSKIP && !whole) continue;
       issued++;
       const int pos = 64 * c + lane;
       const int q = pos / (SH::PADP + 1), hole = (pos % (SH::PADP + 1)) == SH::PADP;
       const int piece = pos - q - hole;
       if (FUSED_DMA_CAP > 0 && !whole) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FUSED_DMA_CAP > 0 ? FUSED_DMA_CAP - 1 : 0) : "memory");
-      if ((c < SH::NDMA - 1 || pos < SH::NPOS) && (c > 1 || whole || pos >= SH::PREPOS))
+      if ((c < SH::NDMA - 1 || pos < SH::NPOS) && (c > SH::CSKIP || whole || pos >= SH::PREPOS))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * piece),
                                          (__attribute__((address_space(3))) void *)(slot + 1024 * c), 16, 0, FUSED_DMA_AUX);
     }
@@ -233,14 +236,14 @@ __device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, 
     int issued = 0;
 #pragma unroll
     for (int c = 0; c < SH::NDMA; c++) {
-      if (c == 0 && !whole) continue;
+      if (c < SH::CSKIP && !whole) continue;
       issued++;
       const int pos = 64 * c + lane;
       const int q = pos / (SH::PADP + 1), hole = (pos % (SH::PADP + 1)) == SH::PADP;
       const int piece = pos - q - hole;
       const long long n0 = nb + 2 * piece;
       const float2 *gp = (n0 >= 0 && n0 + 2 <= a.n_valid) ? xs + n0 : (n0 < 0 && n0 >= -(long long)a.H_in) ? hs + (a.H_in + n0) : a.zero16;
-      if ((c < SH::NDMA - 1 || pos < SH::NPOS) && (c > 1 || whole || pos >= SH::PREPOS))
+      if ((c < SH::NDMA - 1 || pos < SH::NPOS) && (c > SH::CSKIP || whole || pos >= SH::PREPOS))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
                                          (__attribute__((address_space(3))) void *)(slot + 1024 * c), 16, 0, FUSED_DMA_AUX);
     }
@@ -273,16 +276,24 @@ __device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, 
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   return 0;
 }
+template <int D, int NA>
+__device__ __forceinline__ int fused_fill(const FusedArgs &a, const float2 *xs, const float2 *hs, int jE, unsigned char *slot, int lane, bool whole) {
+  return fused_fill_sh<FusedShape<D, NA>>(a, xs, hs, jE, slot, lane, whole);
+}
 
 // stage-A side of the above: pieces [D*ME/2, D*ME/2 + PRE) of the slot of this epoch -> pieces [0, PRE) of the next
-template <int D, int NA>
-__device__ __forceinline__ void fused_copy_preroll(const unsigned char *cur, unsigned char *nxt, int lane) {
-  using SH = FusedShape<D, NA>;
+template <class SH>
+__device__ __forceinline__ void fused_copy_preroll_sh(const unsigned char *cur, unsigned char *nxt, int lane) {
   const float4 *src = reinterpret_cast<const float4 *>(cur);
   float4 *dst = reinterpret_cast<float4 *>(nxt);
-  constexpr int P0 = D * SH::ME / 2;
-  dst[SH::pos_of_piece(lane)] = src[SH::pos_of_piece(P0 + lane)];
-  if (64 + lane < SH::PRE) dst[SH::pos_of_piece(64 + lane)] = src[SH::pos_of_piece(P0 + 64 + lane)];
+  constexpr int P0 = SH::DEC * SH::ME / 2;
+#pragma unroll
+  for (int g = 0; 64 * g < SH::PRE; g++)
+    if (64 * (g + 1) <= SH::PRE || 64 * g + lane < SH::PRE) dst[SH::pos_of_piece(64 * g + lane)] = src[SH::pos_of_piece(P0 + 64 * g + lane)];
+}
+template <int D, int NA>
+__device__ __forceinline__ void fused_copy_preroll(const unsigned char *cur, unsigned char *nxt, int lane) {
+  fused_copy_preroll_sh<FusedShape<D, NA>>(cur, nxt, lane);
 }
 
 // wait until at most `young` DMA instructions are outstanding (young = those issued for later epochs), for the few batch sizes

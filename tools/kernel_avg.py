@@ -12,6 +12,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--r8b", action="store_true"); ap.add_argument("--am", action="store_true"); ap.add_argument("--if-filter", action="store_true")
     ap.add_argument("--steps", type=int, default=16); ap.add_argument("--tag", default="")
+    ap.add_argument("--front-only", action="store_true", help="MODE_NONE: the resampler alone (no decoder behind it, nothing beside it)")
     args = ap.parse_args()
     import numpy as np, torch
     fmr = importlib.import_module("airspy-fmradion_amd")
@@ -32,7 +33,10 @@ def main():
         if args.r8b: kw["resampler_class"] = fmr.RESAMPLER_R8B
         if args.if_filter:
             kw.update(fmfilter_enable=True, filter_coeff=np.load(os.path.join(ROOT, "tests", "golden", "filters", "jj1bdx_fm_384kHz_medium.npy")))
-        ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=bench.FS, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=B, **kw)
+        if args.front_only:
+            ch = fmr.Chain(mode=fmr.MODE_NONE, input_rate=bench.FS, enable_resampler=True, max_block_len=blk, max_blocks=B, **kw)
+        else:
+            ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=bench.FS, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=B, **kw)
     bl = [blk] * B
     step = lambda: ch.process_blocks_device(iq.data_ptr(), n, bl, audio.data_ptr(), audio.shape[1], sync=False)
     for _ in range(60): step()
