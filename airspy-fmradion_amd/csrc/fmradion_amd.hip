@@ -225,6 +225,7 @@ struct fmr_chain {
   int max_blocks = 0;
   int H_in = 0, H_mid = 0, H_if = 0, H_a = 0, H_am = 0, H_pc = 0;
   int ntaps = 0, n_pilotcut = 0, mpf_N = 0, mpf_ref = 0;
+  float h_coeff0 = 0.f;                // filter_coeff[0]
   // device buffers
   DevBuf<float2> d_in, d_in_halo, d_mid, d_if, d_fir, d_mpf, d_mpf_coeff, d_mpf_state;
   // FM with the equaliser: the serial IF AGC runs beside the equaliser kernel, which follows its progress counter
@@ -243,6 +244,8 @@ struct fmr_chain {
   int in_fmt = 0, in_bps = 8;          // source sample format (fmr_config.input_format) and its bytes per IQ sample
   bool poly3 = false;                  // stage-B v3 (Q positions per wave share the LDS reads)
   bool poly4 = false;                  // stage-B v4 (f32 MFMA, 48/125 shape)
+  bool fir_mfma_fm = false;            // FM with the 127-tap IF filter (-f): k_ifr_poly4<48, 48, 127, 2, Poly4FirDiscEpi> (filter + discriminator + block sums)
+  DevBuf<float> d_afrag_fir_fm;
   bool fir_mfma = false;               // the 255-tap IF FIR of the 48 kHz modes on the matrix cores (k_ifr_poly4<48, 48, 255> + k_fir_finish)
   DevBuf<float> d_afrag_fir;
   bool poly4_am = false;               // ... the 3/8 shape (384 k -> 48 k, AM / NBFM) as sixteen periods per row block: 48/128
@@ -305,7 +308,8 @@ struct fmr_chain {
   // block tables: ring of pinned host slots + device slots so that queued
   // asynchronous calls never overwrite a table that is still being copied
   static constexpr int kTabSlots = 8;
-  static constexpr int kMaxFusedWg = 1024;
+  static constexpr int kMaxFusedWg = 2048;
+  static constexpr int kFirBlk0Off = 1024;                // ... [1024, 2048) first block of every run of the IF filter's matrix-core kernel
   static constexpr int kFusedTile0Off = 512;             // the table's tail: [0, 512) first block of every run of the fused front end, [512, 1024) first macro tile of every run (+ the end)
   static constexpr double kFusedSumWeight = 0.10;        // what a macro tile with per-block partial sums costs more than one without (run_tables)
 #ifndef FMR_FE_SPARE_CUS
@@ -368,7 +372,7 @@ struct fmr_chain {
     d_bb_mean_blk.release(); d_bb_rms_blk.release(); d_blk_ph.release(); d_base.release(); d_raw.release();
     d_am0.release(); d_am1.release(); d_a10.release(); d_a11.release(); d_pc0.release();
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
-    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_dec16_afrag.release(); d_run_ph.release(); d_afrag_fir.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
+    d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag_fir_fm.release(); d_dec16_afrag.release(); d_run_ph.release(); d_afrag_fir.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
     d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_walk_go.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
@@ -515,6 +519,9 @@ struct fmr_chain {
     bool use_fused{};
     bool fused_disc{};     // the fused kernel's epilogue is the discriminator (else: IF samples only)
     bool fir_disc{};       // the IF filter kernel's epilogue is the discriminator (k_fm_block3<.., true>)
+    bool tail_deferred{};  // the previous call's tail stage is still to be enqueued (behind this call's IF filter kernel)
+    bool fir_tail{};       // FM -f: the IF filter on the matrix cores with the discriminator epilogue (fir_disc is set too; block sums as FusedPart)
+    int fir_grid{}, fir_tpw{}, fir_rem{}, fir_tiles{}, fir_part_from{};
     bool r8b_tail{};       // R8B class: stage B is launched from run_tables with the discriminator as its epilogue (fused_disc is set too)
     long long r8b_mA_prev{}, r8b_kB_prev{};
     int r8b_count_mid{};
@@ -923,7 +930,25 @@ int fmr_chain::init(const fmr_config *c) {
   if (!has_dec) return FMR_OK;
 
   if ((rc = upload(d_coeff, filter_src, (size_t)ntaps))) return rc;
+  h_coeff0 = filter_src[0];
   if (fir_enable && (rc = d_fir.alloc((size_t)S * max_if))) return rc;
+  if (fir_enable && mode == FMR_MODE_FM && ntaps == 127 && c->multipath_stages == 0 && !env.no_fused && !env.serial) {
+    // FM -f: lags 1 .. 126 as the 48 / 48 shape of the banded matrix-core kernel (see the 48 kHz modes below), lag 0 and the
+    // discriminator in its epilogue (Poly4FirDiscEpi)
+    using SH = Poly4Shape<48, 48, 127>;
+    std::vector<float> af((size_t)SH::MT * SH::NK * 64, 0.f);
+    for (int mt = 0; mt < SH::MT; mt++)
+      for (int i = 0; i < SH::nks(mt); i++)
+        for (int l = 0; l < 64; l++) {
+          const int pp = 16 * mt + (l & 15), m = 4 * (SH::ks_lo(mt) + i) + (l >> 4), j = m - SH::off(pp);
+          if (j >= 0 && j < 126) af[((size_t)mt * SH::NK + i) * 64 + l] = filter_src[126 - j];
+        }
+    if ((rc = upload(d_afrag_fir_fm, af.data(), af.size()))) return rc;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 48, 127, 2, Poly4FirDiscEpi>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    fir_mfma_fm = true;
+  }
   if (fir_enable && mode != FMR_MODE_FM && !ssb_like && ntaps == 255 && !env.no_fused && !env.serial) {
     // AM / DSB / NBFM: out[i] = sum_{j = 1 .. 254} c[j] x[i - j] as the 1 : 1 "polyphase" shape 48 / 48 of the banded matrix-core
     // kernel -- one phase, window start = output index; tap row h[j'] = c[254 - j'] over x[i - 254 + j'], with the lag-0 tap
@@ -943,8 +968,8 @@ int fmr_chain::init(const fmr_config *c) {
   }
   if ((rc = d_gain.alloc((size_t)S * max_if))) return rc;
   if ((rc = d_dec.alloc((size_t)S * max_if))) return rc;
-  if ((fused_ok || r8b_disc_ok) && (rc = d_fused_part.alloc((size_t)S * 3 * (max_if / 384 + 20)))) return rc;
-  if (r8b_disc_ok && (rc = d_run_ph.alloc((size_t)S * 2 * kMaxFusedWg))) return rc;
+  if ((fused_ok || r8b_disc_ok || fir_mfma_fm) && (rc = d_fused_part.alloc((size_t)S * 3 * (max_if / 384 + 20)))) return rc;
+  if ((r8b_disc_ok || fir_mfma_fm) && (rc = d_run_ph.alloc((size_t)S * 2 * kMaxFusedWg))) return rc;
   if (fused_ok && (rc = d_fused_mid32.alloc((size_t)std::max(std::max(n_cu, S), 256) * 2 * FusedShape<kFusedD, kFusedNA>::MIDR))) return rc;
   if (fused_ok && (rc = d_zero16.alloc(4))) return rc;
   if (fused_ok && env.fe_stamps && (rc = d_fe_stamps.alloc(3 * (size_t)kMaxFusedWg * S + 2 * kStampCalls * 16))) return rc;
@@ -1027,7 +1052,7 @@ int fmr_chain::init(const fmr_config *c) {
       for (int q = 1; q < kPipe; q++) {
         if ((rc = d_base_pp[q].alloc((size_t)S * (H_b + max_if)))) return rc;
         if ((rc = d_raw_pp[q].alloc((size_t)S * (H_b + max_if)))) return rc;
-        if ((fused_ok || r8b_disc_ok) && (rc = d_part_pp[q].alloc(d_fused_part.n))) return rc;
+        if ((fused_ok || r8b_disc_ok || fir_mfma_fm) && (rc = d_part_pp[q].alloc(d_fused_part.n))) return rc;
         if ((rc = d_stereo_pp[q].alloc((size_t)S * max_blocks))) return rc;
       }
     if ((rc = d_base_de.alloc((size_t)S * (H_a + max_if)))) return rc;
@@ -1613,6 +1638,38 @@ int fmr_chain::run_tables(CallCtx &k) {
       hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((kFusedTile0Off + fused_grid + 1 + 255) / 256)), dim3(256), 0, side,
                          (const int *)t_wg, d_tab_slot + (tab_ints - kMaxFusedWg), kFusedTile0Off + fused_grid + 1);
   }
+  k.fir_tail = false;
+  if (fir_mfma_fm && mode == FMR_MODE_FM && fir_enable && !enable_mpf && !serial_mode && N_if >= 3072) {
+    // FM -f on the matrix cores: contiguous runs of 3072-output tiles per workgroup (call-relative), first block of every run
+    k.fir_tail = true;
+    for (int b = 0; b < nb; b++) if (t_if_len[b] != 0 && t_if_len[b] < 128) k.fir_tail = false;
+  }
+  if (k.fir_tail) {
+    k.fir_tiles = (int)((N_if - 1) / 3072 + 1);
+    const int wgs = std::max(1, std::min(kMaxFusedWg - kFirBlk0Off, 2 * n_cu / S));
+    // (two workgroups share a compute unit: balanced runs -- fir_rem of them one tile longer -- keep all of them busy, where
+    // ceil(tiles / slots) for everybody left 46 of 256 units idle at 2^27 samples per call)
+    k.fir_grid = std::min(wgs, k.fir_tiles);
+    k.fir_tpw = k.fir_tiles / k.fir_grid;
+    k.fir_rem = k.fir_tiles - k.fir_tpw * k.fir_grid;
+    {
+      int seen = 0, b_first = 0;
+      for (int b0 = ((nb - 1) / 64) * 64; b0 > 0 && !b_first; b0 -= 64) {
+        for (int b = b0; b < std::min(b0 + 64, nb); b++) seen += t_if_len[b] != 0;
+        if (seen >= 400) b_first = b0;
+      }
+      k.fir_part_from = t_if_off[b_first];
+    }
+    int *t_fb = h_tab + (tab_ints - kMaxFusedWg) + kFirBlk0Off;
+    int b = 0;
+    for (int w = 0; w < k.fir_grid; w++) {
+      const long long kf = 3072ll * ((long long)w * k.fir_tpw + std::min(w, k.fir_rem));
+      while (b < nb && (long long)t_if_off[b] + t_if_len[b] <= kf) b++;
+      t_fb[w] = b;
+    }
+    hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((k.fir_grid + 255) / 256)), dim3(256), 0, side,
+                       (const int *)t_fb, d_tab_slot + (tab_ints - kMaxFusedWg) + kFirBlk0Off, k.fir_grid);
+  }
   int r8b_grid = 0, r8b_tpw = 0, r8b_tiles = 0;
   if (k.r8b_tail) {
     // R8B class: contiguous runs of stage-B tiles (64 periods = 3072 IF samples) per workgroup; the table's tail carries the
@@ -1762,6 +1819,10 @@ int fmr_chain::run_tables(CallCtx &k) {
                            d_mid.p, (long long)(H_mid + max_mid), H_mid, count_mid, d_state.p, commit);
       };
       // the previous call's tail stage: behind this front end, beside this call's PLL stage
+#ifndef FMR_FIR_TAIL_EARLY
+      // (... and behind the IF filter's kernel where that one sits between front end and PLL: run_fm)
+      if (k.fir_tail) { k.tail_deferred = true; if (int rc = flush_walk()) return rc; } else
+#endif
       if (int rc = flush_tail(ev_fe[k.par])) return rc;
     }
   }
@@ -1788,7 +1849,7 @@ int fmr_chain::run_tables(CallCtx &k) {
                          poly5h_nkb, poly5h_inv_scale, rs.TB, k.r8b_kB_prev, (int)N_if, (float2 *)nullptr, 0ll, 0, poly2_tile, r8b_tiles,
                          a, r8b_tpw);
       if (r8b_grid > 1)
-        hipLaunchKernelGGL(k_poly5h_heads, dim3((r8b_grid + 62) / 64, S), dim3(64), 0, stream, a, r8b_grid, r8b_tpw);
+        hipLaunchKernelGGL(k_poly5h_heads, dim3((r8b_grid + 62) / 64, S), dim3(64), 0, stream, a, r8b_grid, r8b_tpw, 0);
     });
     if (pipelined) {
       // as behind the fused front end: the PLL stage starts from here; input history, stage-B history and the
@@ -1831,13 +1892,34 @@ int fmr_chain::run_if_stage(CallCtx &k) {
       const size_t lds_fb = sizeof(float2) * (4 * (size_t)fm_block3_plane(ntaps - 1, TL) + ((size_t)ntaps + 4) / 2 + (size_t)(ntaps - 1) + TL);
       const bool blocked = fir_enable && ntaps >= 2 && lds_fb <= 60000 && !serial_mode;
       k.fir_disc = blocked && mode == FMR_MODE_FM && !enable_mpf;
+      if (!k.fir_disc) k.fir_tail = false;
       auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(nb, S), dim3(256), lds_fb, stream, ifbuf, if_stride, H_if, bt,
                            d_coeff.p, ntaps, (int)(mode != FMR_MODE_FM), d_fir.p, (long long)max_if, d_if_rms_blk.p,
                            disc_nf, disc_bound, d_dec.p, (long long)max_if, k.base, H_b + (long long)max_if, H_b,
                            d_bb_mean_blk.p, d_bb_rms_blk.p, d_blk_ph.p, TL);
       };
-      if (k.fir_disc) {
+      if (k.fir_disc && k.fir_tail) {
+        FusedArgs a{};
+        a.n_if = (int)N_if; a.kb_ref = 0;
+        a.out = d_fir.p; a.out_stride = (long long)max_if; a.out_off = 0;
+        a.base = k.base; a.base_stride = H_b + (long long)max_if; a.base_off = H_b;
+        a.dec = debug_taps ? d_dec.p : nullptr; a.dec_stride = (long long)max_if;
+        a.nf = disc_nf; a.bound = disc_bound;
+        a.st = d_state.p; a.part = k.part; a.n_tiles = 8 * k.fir_tiles; a.part_from = k.fir_part_from;
+        a.if_off = bt.if_off; a.if_len = bt.if_len; a.nb = nb;
+        a.wg_blk0 = k.d_tab_slot + (tab_ints - kMaxFusedWg) + kFirBlk0Off;
+        a.mid32 = d_run_ph.p;
+        a.fir_c0 = h_coeff0; a.fir_order = ntaps - 1;
+        if ((size_t)a.n_tiles * 3 * S > d_fused_part.n || (size_t)k.fir_grid * 2 * S > d_run_ph.n) { set_err("internal capacity exceeded (IF filter tiles)"); return; }
+        constexpr int kTile = 64 * 48 + 47 + 127 + 64;
+        hipLaunchKernelGGL((k_ifr_poly4<48, 48, 127, 2, Poly4FirDiscEpi>), dim3(k.fir_grid, S), dim3(256),
+                           sizeof(float2) * (size_t)(((kTile + 127) / 128) * 128 + 4 * 8 * 48), stream, ifbuf, if_stride,
+                           (long long)(64 - H_if), H_if + (int)N_if, d_afrag_fir_fm.p, 0ll, (int)N_if, (float2 *)nullptr, 0ll, 0,
+                           kTile, k.fir_tiles, a, k.fir_tpw, k.fir_rem);
+        if (k.fir_grid > 1)
+          hipLaunchKernelGGL(k_poly5h_heads, dim3((k.fir_grid + 62) / 64, S), dim3(64), 0, stream, a, k.fir_grid, k.fir_tpw, k.fir_rem);
+      } else if (k.fir_disc) {
         go(k_fm_block3<256, true>);
         hipLaunchKernelGGL(k_disc_heads, dim3((nb + 255) / 256, S), dim3(256), 0, stream, bt, d_blk_ph.p, disc_bound, d_dec.p,
                            (long long)max_if, k.base, H_b + (long long)max_if, H_b, d_bb_mean_blk.p, d_bb_rms_blk.p, d_state.p);
@@ -2196,6 +2278,7 @@ int fmr_chain::run_fm(CallCtx &k) {
   // the event recorded behind it already (a second marker on the critical stream costs what a small kernel costs).
   k.ev_mpx = (pipelined && k.fused_disc) ? ev_fe[k.par] : ev_disc;
   if (k.ev_mpx == ev_disc) HIPCHK(hipEventRecord(ev_disc, stream));
+  if (k.tail_deferred) { k.tail_deferred = false; if (int rc = flush_tail(ev_disc)) return rc; }
   HIPCHK(hipStreamWaitEvent(side, k.ev_mpx, 0));
   if (use_fused && !pipelined)      // input history for the next call's front end: off the critical path (the next
     timed_on(side, "in_halo", [&] {   // front end waits for this stream's table kernels anyway)
@@ -2205,7 +2288,8 @@ int fmr_chain::run_fm(CallCtx &k) {
   timed_on(side, "stats", [&] {     // (fused front end: the block values are summed from its partial sums on the fly)
     hipLaunchKernelGGL(k_stats, dim3(S), dim3(FMR_STATS_THREADS), stats_ballast, side, bt, d_if_rms_blk.p, d_bb_mean_blk.p,
                        d_bb_rms_blk.p, d_state.p, S, (int)!(pipelined && k.fused_disc),   // (the front-end stage commits its own phase)
-                       k.fused_disc ? k.part : (const FusedPart *)nullptr, fused_n_tiles, fused_kb_ref);
+                       (k.fused_disc || k.fir_tail) ? k.part : (const FusedPart *)nullptr, k.fir_tail ? 8 * k.fir_tiles : fused_n_tiles,
+                       k.fir_tail ? 0 : fused_kb_ref);
   });
   HIPCHK(hipEventRecord(ev_stats, side));
   disc_commit_on_side = !(pipelined && k.fused_disc);

@@ -683,6 +683,15 @@ __global__ __launch_bounds__(BLOCK) void k_ifr_poly3(
 // An MFMA is bit-for-bit a k-ordered fmaf chain, i.e. the same sequential tap-order accumulation
 // as v2/v3 (plus exact zero terms).
 // ---------------------------------------------------------------------------
+// What happens to a finished tile (64 periods = 3072 IF samples, staged in LDS): Poly5hStoreIf writes the IF samples out (the
+// tiles of a call interleaved over the workgroups); Poly5hDiscEpi (kernels_fused.hpp, round 6) runs the phase discriminator
+// and the block statistics there -- the fused front end's epilogue, a wave per 384 samples -- over CONTIGUOUS runs of
+// tiles_per_wg tiles per workgroup, and the IF samples never go to HBM (k_disc was a separate 52-57 us pass over them).
+struct Poly5hStoreIf {
+  struct Args { int unused; };
+  static constexpr bool kOn = false;
+};
+
 template <int LB, int MB, int TB>
 struct Poly4Shape {
   static constexpr int off(int p) { return (p * MB) / LB; }
@@ -695,21 +704,35 @@ struct Poly4Shape {
   static constexpr int XLEN = 4 * KS_ALL;                   // mid samples one period touches
 };
 
-template <int LB, int MB, int TB, int MINB = 2>
+// (EPI: what happens to a wave's 384 staged outputs -- Poly5hStoreIf: stored as they are, tiles interleaved over the
+// workgroups; Poly4FirDiscEpi of kernels_fused.hpp, round 6: the IF filter's discriminator epilogue, contiguous runs of tiles)
+template <int LB, int MB, int TB, int MINB = 2, class EPI = Poly5hStoreIf>
 __global__ __launch_bounds__(256, MINB) void k_ifr_poly4(
     const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
     const float *__restrict__ afrag, long long k0, int count, float2 *__restrict__ out, long long out_stride,
-    int out_off, int tile_len, int n_tiles) {
+    int out_off, int tile_len, int n_tiles, typename EPI::Args ea = typename EPI::Args{}, int tiles_per_wg = 0, int run_rem = 0) {
   using SH = Poly4Shape<LB, MB, TB>;
   static_assert(LB == 48, "three 16-row tiles");
   typedef float v4f __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float2 lds_b4[];
+  __shared__ float s_carry4[2];
   const int x_len = ((tile_len + 127) / 128) * 128;          // the x region holds whole 1 KB wave chunks
   float2 *stage = lds_b4 + x_len;                            // 4 waves x (8 periods x LB) float2
   const int s = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
   constexpr int W = TB >> 1;
+  // (EPI) runs: the first run_rem workgroups take tiles_per_wg + 1 tiles, the others tiles_per_wg
+  const int tile_lo = EPI::kOn ? (int)blockIdx.x * tiles_per_wg + min((int)blockIdx.x, run_rem) : (int)blockIdx.x;
+  const int tile_hi = EPI::kOn ? min(tile_lo + tiles_per_wg + ((int)blockIdx.x < run_rem ? 1 : 0), n_tiles) : n_tiles;
+  const int tile_step = EPI::kOn ? 1 : (int)gridDim.x;
+  EPI epi;
+  if constexpr (EPI::kOn) {
+    static_assert(MB == 48, "the 1 : 1 shape: an FIR");
+    // (on the decoder stream's critical path, beside the audio tail of the call before: issue priority, as the PLL's passes)
+    __builtin_amdgcn_s_setprio(3);
+    if (tile_lo < tile_hi) epi.begin(ea, s, lane);
+  }
   // ---- the constant A fragments: a[mt][i] = A[16 mt + n][4 (ks_lo(mt) + i) + kq]
   float a[SH::MT][SH::NK];
 #pragma unroll
@@ -719,7 +742,7 @@ __global__ __launch_bounds__(256, MINB) void k_ifr_poly4(
   const float2 *ms = mid + (long long)s * mid_stride;
   float2 *os = out + (long long)s * out_stride + out_off;
   float2 *mystage = stage + wave * (8 * LB);
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int tile = tile_lo; tile < tile_hi; tile += tile_step) {
     const long long P0 = k0 / LB + (long long)tile * 64;
     const long long a0 = P0 * MB - W + 1;
     __syncthreads();                                          // previous tile fully consumed
@@ -771,11 +794,19 @@ __global__ __launch_bounds__(256, MINB) void k_ifr_poly4(
         for (int v = 0; v < 4; v++) sf[2 * ((n >> 1) * LB + 16 * mt + 4 * kq + v) + (n & 1)] = acc[mt][v];
       __syncthreads();
       const long long kb = (P0 + q0) * LB - k0;               // local output index of the staged run
+      if constexpr (EPI::kOn) {
+        // the wave's 384 outputs are consecutive samples (eight periods of 48); the input sample of output t of the tile is
+        // window sample t + TB - 1 (MB == LB: the window starts W - 1 samples before the period, the buffer's index 0 is
+        // TB - 1 - (W - 1) samples before sample 0: fmradion_amd.hip)
+        epi.pass(ea, s, stage, wave, h, (int)kb, 8 * tile + wave + 4 * h, tile == tile_lo && h == 0 && wave == 0, tile + 1 == tile_hi && h == 1,
+                 lane, s_carry4, lds_b4 + LB * q0 + (TB - 1));
+      } else {
 #pragma unroll
       for (int t = 0; t < (8 * LB) / 64; t++) {
         const int idx = t * 64 + lane;
         const long long k = kb + idx;
         if (k >= 0 && k < count) os[k] = mystage[idx];
+      }
       }
       __syncthreads();
     }
@@ -842,15 +873,6 @@ struct FmrH8Shifted {
     return r;
   }
   static constexpr int kReads = A ? 2 : 1;
-};
-
-// What happens to a finished tile (64 periods = 3072 IF samples, staged in LDS): Poly5hStoreIf writes the IF samples out (the
-// tiles of a call interleaved over the workgroups); Poly5hDiscEpi (kernels_fused.hpp, round 6) runs the phase discriminator
-// and the block statistics there -- the fused front end's epilogue, a wave per 384 samples -- over CONTIGUOUS runs of
-// tiles_per_wg tiles per workgroup, and the IF samples never go to HBM (k_disc was a separate 52-57 us pass over them).
-struct Poly5hStoreIf {
-  struct Args { int unused; };
-  static constexpr bool kOn = false;
 };
 
 template <int LB, int MB, class EPI = Poly5hStoreIf>

@@ -74,6 +74,7 @@ struct FusedArgs {
   unsigned long long *dbg;                                    // tools/bench_fused.hip: per wave {busy, total} shader cycles of workgroup 0
   float *mid32;                                               // [workgroup][2][3000]: fp32 copies of mid-ring samples fp16 cannot hold (FusedRing::at32), written and read on the repair paths only
   unsigned long long *stamps;                                 // FMR_FE_STAMPS=1 (diagnostics): per workgroup {start, end} of the constant 100 MHz clock and the hardware id
+  float fir_c0; int fir_order;                                // Poly4FirDiscEpi: the IF filter's lag-0 tap and its order (the head outputs of a block have no lag 0, Filter.cpp:57-68)
 };
 
 #ifndef FUSED_DMA_AUX
@@ -682,9 +683,12 @@ __device__ __forceinline__ float fused_atan2(float y, float x) {
 // global stores": 25 of 250 us; one sample per lane and store: 4 us more, plain instead of nt stores: 3 us more).
 // prev0 = normalised phase of the sample before idx0 (wave-uniform); save0 = the previous call's last phase
 // (m_save_value), which precedes the call's sample 0.
-template <int MT0, int ABL = 0>
+// XE: the |x|^2 of the block sums (the IF level, FmDecode.cpp:95) is taken from xe[0 .. 127] instead of the staged samples --
+// behind the IF filter the level is that of the filter's INPUT.
+template <int MT0, int ABL = 0, bool XE = false>
 __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const float2 *stage, int kb, int tile_g, int &blk,
-                                                FusedBlkWin &win, float prev0, float save0, float2 *os, int lane) {
+                                                FusedBlkWin &win, float prev0, float save0, float2 *os, int lane,
+                                                const float2 *xe = nullptr) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef v4f __attribute__((aligned(8))) v4f_u;
@@ -758,8 +762,14 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs &a, int s, const 
     const float e = x.x * x.x + x.y * x.y;
     if (k < cut) { sa[0] += d; sa[1] += d * d; sa[2] += e; } else { sb[0] += d; sb[1] += d * d; sb[2] += e; }
   };
+  if constexpr (XE) {
+    const v4f xi = reinterpret_cast<const v4f *>(xe)[lane];
+    add(va, ka, d0, make_float2(xi.x, xi.y));
+    add(vc, kc, d1, make_float2(xi.z, xi.w));
+  } else {
   add(va, ka, d0, x0);
   add(vc, kc, d1, x1);
+  }
 #pragma unroll
   for (int c = 0; c < 3; c++) { sa[c] = wave_sum_dpp(sa[c]); sb[c] = (blk1 >= 0) ? wave_sum_dpp(sb[c]) : 0.f; }
   if (lane == 0) {
@@ -915,11 +925,90 @@ struct Poly5hDiscEpi {
   }
 };
 
+// ---- ... and behind the IF filter of FM (main.cpp -f: LowPassFilterFirIQ, Filter.cpp:37-96) on the matrix cores: k_ifr_poly4 in
+// its 1 : 1 shape (48 / 48, TB = the filter's taps, the lag-0 tap left out of the banded matrix) with this epilogue, round 6.
+// A wave's pass ends with 384 consecutive filter outputs staged in LDS.  (1) The outputs behind a block's head get their lag-0
+// term c[0] x[i] (the reference's head path sums the lags 1 .. order only), in place; (2) behind a barrier the discriminator
+// epilogue above runs on the corrected samples -- the filtered IF samples go to `out` (the IF AGC reads them), the block sums'
+// |x|^2 is the filter's INPUT (FmDecode.cpp:95).  k_fm_block3<.., true> + k_disc_heads, which this replaces for calls of whole
+// tiles, took 0.145 ms per 5.2 M IF samples with the reference's add / multiply / add rounding on the vector ALUs; here the
+// filter is one fmaf chain in lag order per output (1e-7 relative from that, inside the 2e-6 the front end is held to).
+struct Poly4FirDiscEpi {
+  using Args = FusedArgs;
+  static constexpr bool kOn = true;
+  int blk, blk_c, it;
+  FusedBlkWin win, win_c;
+  float save0;
+  __device__ __forceinline__ void begin(const Args &a, int s, int lane) {
+    save0 = a.st[s].disc_save;
+    blk = a.wg_blk0[(int)blockIdx.x];
+    win.load(a, blk, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(save0), "+v"(win.end_l), "+v"(win.len_l));
+    blk = __builtin_amdgcn_readfirstlane(blk);
+    blk_c = blk; win_c = win;
+    it = 0;
+  }
+  // lag 0 for the outputs of one third that lie behind their block's head; stage: the macro tile's 384 samples, xw: their inputs
+  template <int MT0>
+  __device__ __forceinline__ void lag0(const Args &a, float2 *stage, const float2 *xw, int kb, int lane) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int k0 = kb + 128 * MT0;
+    if (k0 >= a.n_if || k0 + 128 <= 0) return;
+    const int kf = k0 < 0 ? 0 : k0;
+    for (;;) {
+      if (blk_c - win_c.base >= 64) win_c.load(a, blk_c, lane);
+      if (blk_c >= a.nb || win_c.end(blk_c) > kf) break;
+      blk_c++;
+    }
+    if (blk_c >= a.nb) return;
+    const int cut = win_c.end(blk_c), st0 = cut - win_c.len(blk_c);
+    const int ka = k0 + 2 * lane;
+    v4f y = reinterpret_cast<v4f *>(stage + 128 * MT0)[lane];
+    const v4f x = reinterpret_cast<const v4f *>(xw + 128 * MT0)[lane];
+    const bool body_a = ka - (ka < cut ? st0 : cut) >= a.fir_order, body_c = ka + 1 - (ka + 1 < cut ? st0 : cut) >= a.fir_order;
+    if (body_a) { y.x = fmaf(x.x, a.fir_c0, y.x); y.y = fmaf(x.y, a.fir_c0, y.y); }
+    if (body_c) { y.z = fmaf(x.z, a.fir_c0, y.z); y.w = fmaf(x.w, a.fir_c0, y.w); }
+    if (body_a || body_c) reinterpret_cast<v4f *>(stage + 128 * MT0)[lane] = y;
+  }
+  // kb: call-relative index of the wave's first staged sample; stage_all: the four waves' staging areas, 384 samples each
+  __device__ __forceinline__ void pass(const Args &a, int s, float2 *stage_all, int wave, int h, int kb, int tile_g, bool first, bool last,
+                                       int lane, float *s_carry, const float2 *xw) {
+    const float inv_nf = 1.0f / a.nf;
+    float2 *mst = stage_all + 384 * wave;
+    lag0<0>(a, mst, xw, kb, lane); lag0<1>(a, mst, xw, kb, lane); lag0<2>(a, mst, xw, kb, lane);
+    __syncthreads();                                          // every wave's samples are final: the phase before a wave's first one is its neighbour's
+    float2 *os = a.out ? a.out + (long long)s * a.out_stride + a.out_off : nullptr;
+    float *run_ph = a.mid32 + ((size_t)s * gridDim.x + blockIdx.x) * 2;
+    float prev0;
+    if (wave == 0) {
+      if (kb <= 0) prev0 = save0;
+      else if (first) prev0 = __builtin_nanf("");             // k_poly5h_heads fills it in
+      else prev0 = s_carry[it & 1];
+    } else { const float2 xp = stage_all[384 * wave - 1]; prev0 = fused_atan2(xp.y, xp.x) * inv_nf; }
+    fused_epilogue<0, 0, true>(a, s, mst, kb, tile_g, blk, win, prev0, save0, os, lane, xw);
+    { const float2 xp = mst[127]; prev0 = fused_atan2(xp.y, xp.x) * inv_nf; }
+    fused_epilogue<1, 0, true>(a, s, mst, kb, tile_g, blk, win, prev0, save0, os, lane, xw + 128);
+    { const float2 xp = mst[255]; prev0 = fused_atan2(xp.y, xp.x) * inv_nf; }
+    fused_epilogue<2, 0, true>(a, s, mst, kb, tile_g, blk, win, prev0, save0, os, lane, xw + 256);
+    if (wave == 3 && lane == 0) {
+      const float2 xl = mst[383];
+      const float ph = fused_atan2(xl.y, xl.x) * inv_nf;
+      s_carry[(it + 1) & 1] = ph;
+      if (last) run_ph[1] = ph;
+    }
+    if (first && lane == 0) { const float2 xf = mst[0]; run_ph[0] = fused_atan2(xf.y, xf.x) * inv_nf; }
+    it++;
+  }
+};
+
 // the first sample of every run but the call's first: phase difference across the run boundary, and its share of the block sums
-__global__ void k_poly5h_heads(FusedArgs a, int grid, int tiles_per_wg) {
+// (runs as the kernel in front cut them: the first run_rem of tiles_per_wg + 1 tiles, the others of tiles_per_wg)
+__global__ void k_poly5h_heads(FusedArgs a, int grid, int tiles_per_wg, int run_rem = 0) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x + 1, s = blockIdx.y;
   if (w >= grid) return;
-  const int kb = a.kb_ref + 3072 * (w * tiles_per_wg);
+  const int t0 = w * tiles_per_wg + min(w, run_rem);
+  const int kb = a.kb_ref + 3072 * t0;
   if (kb <= 0 || kb >= a.n_if) return;
   const float *run_ph = a.mid32 + (size_t)s * grid * 2;
   float d = run_ph[2 * w] - run_ph[2 * (w - 1) + 1];                                 // V5, as fused_epilogue
@@ -929,7 +1018,7 @@ __global__ void k_poly5h_heads(FusedArgs a, int grid, int tiles_per_wg) {
   a.base[(long long)s * a.base_stride + a.base_off + kb] = d;
   if (a.dec) a.dec[(long long)s * a.dec_stride + kb] = d;
   if (kb + 128 > a.part_from) {
-    FusedPart *pt = a.part + ((long long)s * a.n_tiles + 8ll * w * tiles_per_wg) * 3;
+    FusedPart *pt = a.part + ((long long)s * a.n_tiles + 8ll * t0) * 3;
     pt->sum[0][0] += d; pt->sum[0][1] += d * d;
   }
 }
