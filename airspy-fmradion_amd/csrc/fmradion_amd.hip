@@ -949,21 +949,30 @@ int fmr_chain::init(const fmr_config *c) {
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     fir_mfma_fm = true;
   }
-  if (fir_enable && mode != FMR_MODE_FM && !ssb_like && ntaps == 255 && !env.no_fused && !env.serial) {
-    // AM / DSB / NBFM: out[i] = sum_{j = 1 .. 254} c[j] x[i - j] as the 1 : 1 "polyphase" shape 48 / 48 of the banded matrix-core
-    // kernel -- one phase, window start = output index; tap row h[j'] = c[254 - j'] over x[i - 254 + j'], with the lag-0 tap
-    // (j' = 254) left out: k_fir_finish adds it where the reference has it.  (Round 6: k_fm_block2 took 0.139 ms per 2.1 M IF
-    // samples, a fifth of the AM step.)
-    using SH = Poly4Shape<48, 48, 255>;
-    std::vector<float> af((size_t)SH::MT * SH::NK * 64, 0.f);
-    for (int mt = 0; mt < SH::MT; mt++)
-      for (int i = 0; i < SH::nks(mt); i++)
-        for (int l = 0; l < 64; l++) {
-          const int pp = 16 * mt + (l & 15), m = 4 * (SH::ks_lo(mt) + i) + (l >> 4), j = m - SH::off(pp);
-          if (j >= 0 && j < 254) af[((size_t)mt * SH::NK + i) * 64 + l] = filter_src[254 - j];
-        }
-    if ((rc = upload(d_afrag_fir, af.data(), af.size()))) return rc;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 48, 255, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+  if (fir_enable && mode != FMR_MODE_FM && !ssb_like && (ntaps == 255 || ntaps == 127) && !env.no_fused && !env.serial) {
+    // AM / DSB / NBFM (255 or 127 taps): out[i] = sum_{j = 1 .. order} c[j] x[i - j] as the 1 : 1 "polyphase" shape 48 / 48 of the
+    // banded matrix-core kernel -- one phase, window start = output index; tap row h[j'] = c[order - j'] over x[i - order + j'],
+    // with the lag-0 tap (j' = order) left out: k_fir_finish adds it where the reference has it.  (Round 6: k_fm_block2 took
+    // 0.139 ms per 2.1 M IF samples, a fifth of the AM step.)
+    auto make = [&](auto sh_tag) {
+      using SH = decltype(sh_tag);
+      const int order = ntaps - 1;
+      std::vector<float> af((size_t)SH::MT * SH::NK * 64, 0.f);
+      for (int mt = 0; mt < SH::MT; mt++)
+        for (int i = 0; i < SH::nks(mt); i++)
+          for (int l = 0; l < 64; l++) {
+            const int pp = 16 * mt + (l & 15), m = 4 * (SH::ks_lo(mt) + i) + (l >> 4), j = m - SH::off(pp);
+            if (j >= 0 && j < order) af[((size_t)mt * SH::NK + i) * 64 + l] = filter_src[order - j];
+          }
+      return upload(d_afrag_fir, af.data(), af.size());
+    };
+    if (ntaps == 255) {
+      if ((rc = make(Poly4Shape<48, 48, 255>{}))) return rc;
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 48, 255, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    } else {
+      if ((rc = make(Poly4Shape<48, 48, 127>{}))) return rc;
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ifr_poly4<48, 48, 127, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    }
     fir_mfma = true;
   }
   if ((rc = d_gain.alloc((size_t)S * max_if))) return rc;
@@ -1926,14 +1935,19 @@ int fmr_chain::run_if_stage(CallCtx &k) {
       }
       else if (blocked && mode == FMR_MODE_FM) go(k_fm_block3<256, false>);       // (FM with the equaliser behind the filter)
       else if (blocked && fir_mfma && N_if >= 48) {
-        // AM / DSB / NBFM, 255 taps: the matrix-core form (call-relative periods of 48 outputs; buffer index m of the kernel's
-        // window arithmetic is x[m - 128], i.e. the "absolute" index of the buffer's first element is 128 - H_if)
-        constexpr int kTile = 64 * 48 + 47 + 255 + 64;
+        // AM / DSB / NBFM, 255 or 127 taps: the matrix-core form (call-relative periods of 48 outputs; buffer index m of the
+        // kernel's window arithmetic is x[m - (order - (W - 1))], W = taps / 2: the "absolute" index of the buffer's first element
+        // is order - W + 1 - H_if)
+        const int order = ntaps - 1, Wf = ntaps >> 1;
+        const int kTile = 64 * 48 + 47 + ntaps + 64;
         const int tiles_f = (int)((N_if - 1) / 48 / 64 + 1);
-        hipLaunchKernelGGL((k_ifr_poly4<48, 48, 255, 1>), dim3(std::min(tiles_f, 1024), S), dim3(256),
-                           sizeof(float2) * (size_t)(((kTile + 127) / 128) * 128 + 4 * 8 * 48), stream, ifbuf, if_stride,
-                           (long long)(128 - H_if), H_if + (int)N_if, d_afrag_fir.p, 0ll, (int)N_if, d_fir.p, (long long)max_if, 0,
-                           kTile, tiles_f);
+        auto gof = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3(std::min(tiles_f, 1024), S), dim3(256),
+                             sizeof(float2) * (size_t)(((kTile + 127) / 128) * 128 + 4 * 8 * 48), stream, ifbuf, if_stride,
+                             (long long)(order - Wf + 1 - H_if), H_if + (int)N_if, d_afrag_fir.p, 0ll, (int)N_if, d_fir.p, (long long)max_if, 0,
+                             kTile, tiles_f, Poly5hStoreIf::Args{}, 0, 0);
+        };
+        if (ntaps == 255) gof(k_ifr_poly4<48, 48, 255, 1>); else gof(k_ifr_poly4<48, 48, 127, 2>);
         hipLaunchKernelGGL(k_fir_finish<256>, dim3(nb, S), dim3(256), 0, stream, ifbuf, if_stride, H_if, bt, d_coeff.p, ntaps,
                            d_fir.p, (long long)max_if, d_if_rms_blk.p);
       }
