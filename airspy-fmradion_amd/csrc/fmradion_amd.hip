@@ -61,7 +61,7 @@ constexpr double kR8bAtten = 180.0, kR8bPassFrac = 0.98;   // R8B class: the def
 constexpr double kAudioAtten = 180.0;
 constexpr int FMR_MODE_NONE = -1;
 // chunk lengths of the time-parallel recurrences (kernels_par.hpp)
-constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 512, K_AF_ITERS = 6;
+constexpr int C_AGC = 256, C_DC = 64, C_DE = 256, C_AM = 256, C_AM_DE = 128, K_AF_ITERS = 6;
 #ifndef FMR_C_PLL_MIN
 #define FMR_C_PLL_MIN 32
 #endif

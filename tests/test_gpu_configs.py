@@ -228,8 +228,10 @@ def _run_pair(x, blk, batch, pilotcut, stereo=True):
 @pytest.mark.parametrize("narrow", [False, True])
 def test_if_filter_behind_the_fused_front_end(narrow, pilotcut, fm_medium):
     """10 MS/s FM stereo with the IF filter on (main.cpp -f medium / narrow): the fused front end stores the IF samples
-    (its IF-only epilogue), k_fm_block2 filters them block by block (head path at every block start, H1) and k_disc
-    follows -- against IfResampler + FmDecoder(fmfilter_enable) of the oracle, ragged blocks included."""
+    (its IF-only epilogue); round 6: the filter runs on the matrix cores (k_ifr_poly4<48, 48, 127, 2, Poly4FirDiscEpi>: the lags
+    1 .. 126 as a banded product, the lag-0 term behind every block's head (H1), the discriminator and the block sums in its
+    epilogue; the IF level from the filter's input) -- against IfResampler + FmDecoder(fmfilter_enable) of the oracle, ragged
+    blocks included."""
     from conftest import load_filter
     fir = load_filter("jj1bdx_fm_384kHz_narrow") if narrow else fm_medium
     rng = np.random.default_rng(21)
