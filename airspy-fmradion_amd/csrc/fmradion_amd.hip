@@ -1919,7 +1919,7 @@ int fmr_chain::run_if_stage(CallCtx &k) {
         a.if_off = bt.if_off; a.if_len = bt.if_len; a.nb = nb;
         a.wg_blk0 = k.d_tab_slot + (tab_ints - kMaxFusedWg) + kFirBlk0Off;
         a.mid32 = d_run_ph.p;
-        a.fir_c0 = h_coeff0; a.fir_order = ntaps - 1;
+        a.fir_c0 = h_coeff0; a.fir_order = ntaps - 1; a.hA = d_coeff.p;      // (hA: the filter's taps, for the repair of tiles that hold a non-finite sample)
         if ((size_t)a.n_tiles * 3 * S > d_fused_part.n || (size_t)k.fir_grid * 2 * S > d_run_ph.n) { set_err("internal capacity exceeded (IF filter tiles)"); return; }
         constexpr int kTile = 64 * 48 + 47 + 127 + 64;
         hipLaunchKernelGGL((k_ifr_poly4<48, 48, 127, 2, Poly4FirDiscEpi>), dim3(k.fir_grid, S), dim3(256),

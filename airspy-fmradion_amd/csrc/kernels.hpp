@@ -1326,11 +1326,20 @@ __global__ __launch_bounds__(BLOCK) void k_fir_finish(
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += BLOCK) {
     float2 o = y[i];
+    bool store = false;
+    // exact-support repair: a non-finite input sample has made every output of its banded tile NaN (zero taps times NaN); an
+    // output whose lags 1 .. order hold no such sample is computed again with the plain tap loop (x reaches into the halo)
+    if (!__builtin_isfinite(o.x + o.y)) {
+      float2 r = make_float2(0.f, 0.f);
+      for (int j = order; j >= 1; j--) { const float c = coeff[j]; const float2 u = x[i - j]; r.x = fmaf(c, u.x, r.x); r.y = fmaf(c, u.y, r.y); }
+      o = r; store = true;
+    }
     if (i >= order) {
       const float2 xi = x[i];
       o.x = fmaf(xi.x, c0, o.x); o.y = fmaf(xi.y, c0, o.y);
-      y[i] = o;
+      store = true;
     }
+    if (store) y[i] = o;
     acc += o.x * o.x + o.y * o.y;
   }
   const float tot = block_sum<BLOCK>(acc, scratch);

@@ -966,10 +966,27 @@ struct Poly4FirDiscEpi {
     const int ka = k0 + 2 * lane;
     v4f y = reinterpret_cast<v4f *>(stage + 128 * MT0)[lane];
     const v4f x = reinterpret_cast<const v4f *>(xw + 128 * MT0)[lane];
+    // exact-support repair, as in the fused front end: a non-finite IF sample has made every output of the banded tile whose
+    // k-range holds it NaN (zero taps times NaN).  Rare, wave-uniform: the lane's two outputs again as plain tap loops over the
+    // window -- an output whose lags 1 .. order hold no such sample comes out finite, as in the reference
+    bool fixed = false;
+    if (__builtin_amdgcn_ballot_w64(!__builtin_isfinite(y.x + y.y + y.z + y.w)) != 0) {
+      const float2 *xp = xw + 128 * MT0 + 2 * lane;            // the input of this lane's first output
+      float2 r0 = make_float2(0.f, 0.f), r1 = make_float2(0.f, 0.f);
+#pragma unroll 1
+      for (int j = a.fir_order; j >= 1; j--) {
+        const float c = a.hA[j];
+        const float2 u = xp[-j], w = xp[1 - j];
+        r0.x = fmaf(c, u.x, r0.x); r0.y = fmaf(c, u.y, r0.y);
+        r1.x = fmaf(c, w.x, r1.x); r1.y = fmaf(c, w.y, r1.y);
+      }
+      y = (v4f){r0.x, r0.y, r1.x, r1.y};
+      fixed = true;
+    }
     const bool body_a = ka - (ka < cut ? st0 : cut) >= a.fir_order, body_c = ka + 1 - (ka + 1 < cut ? st0 : cut) >= a.fir_order;
     if (body_a) { y.x = fmaf(x.x, a.fir_c0, y.x); y.y = fmaf(x.y, a.fir_c0, y.y); }
     if (body_c) { y.z = fmaf(x.z, a.fir_c0, y.z); y.w = fmaf(x.w, a.fir_c0, y.w); }
-    if (body_a || body_c) reinterpret_cast<v4f *>(stage + 128 * MT0)[lane] = y;
+    if (body_a || body_c || fixed) reinterpret_cast<v4f *>(stage + 128 * MT0)[lane] = y;
   }
   // kb: call-relative index of the wave's first staged sample; stage_all: the four waves' staging areas, 384 samples each
   __device__ __forceinline__ void pass(const Args &a, int s, float2 *stage_all, int wave, int h, int kb, int tile_g, bool first, bool last,

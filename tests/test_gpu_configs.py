@@ -351,6 +351,41 @@ def test_carrier_dropout_and_nan_samples(pilotcut):
     ch.close()
 
 
+def test_nan_samples_with_the_if_filter_on(pilotcut, fm_medium):
+    """Round 6: with -f the IF filter is a banded matrix-core product too (k_ifr_poly4<48, 48, 127>): zero taps times NaN would
+    turn whole tiles of its output NaN.  Three NaN input samples: the front end spreads them over its tap support, the filter
+    over the 126 lags behind each such IF sample -- outputs whose support holds none must come out as the reference's
+    (Poly4FirDiscEpi::lag0 recomputes the tiles that hold a non-finite value with the plain tap loop), the discriminator
+    zeroes the differences that touch one (Utility.h:336-343), the AGC resets.  Against the oracle with the filter on."""
+    blk, nblk, batch = 65536, 120, 40
+    x = siggen.fm_stereo_iq(nblk * blk, 10e6).copy()
+    k1 = 85 * blk + 4321
+    x[k1:k1 + 3] = np.complex64(complex(np.nan, np.nan))
+    ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=10e6, enable_resampler=True, stereo=True, fmfilter_enable=True,
+                   filter_coeff=fm_medium, max_block_len=blk, max_blocks=batch)
+    r = ora.IfResampler(10e6, 384e3)
+    fm = ora.FmDecoder(True, fm_medium, True, 50.0, False, 0, pilotcut)
+    got, ref = [], []
+    for i in range(0, nblk, batch):
+        seg = x[i * blk:(i + batch) * blk]
+        a, alen = ch.process_blocks(seg[None, :], [blk] * batch)
+        got.append(a[0])
+        rr = [fm.process(r.process(b)) for b in siggen.blocks(seg, blk)]
+        assert list(alen) == [len(q) for q in rr]
+        ref += rr
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    assert not np.isnan(got).any() and not np.isnan(ref).any()
+    a0 = 2 * int((k1 / 10e6 - 0.002) * 48000)
+    a1 = 2 * int((k1 / 10e6 + 0.35) * 48000)
+    assert a1 + 10000 < len(got)
+    err_before, err_during, err_after = rms((got - ref)[:a0]), float(np.max(np.abs((got - ref)[a0:a1]))), rms((got - ref)[a1:])
+    _report("nan_with_if_filter", audio_rms_err_before=err_before, audio_max_err_during=err_during, audio_rms_err_after=err_after)
+    assert err_before < 1e-5 and err_after < 1e-5
+    assert err_during < 1e-3
+    assert ch.status().stereo_detected == int(fm.stereo_detected()) == 1
+    ch.close()
+
+
 @pytest.mark.parametrize("seed,shape", [(11, "plain"), (12, "plain"), (13, "plain"), (14, "if_fir"), (15, "equaliser"),
                                         (16, "if_fir+equaliser")])
 def test_fused_and_three_kernel_front_ends_agree_on_random_partitions(seed, shape, monkeypatch, fm_medium):

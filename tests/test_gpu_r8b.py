@@ -147,7 +147,9 @@ def test_r8b_fp16_stage_b_strong_and_weak_signal():
     depend on the level.  (Round 4 also compared it with an f32 MFMA form of the same kernel, 1e-6 apart; that partner is
     gone from the library.)"""
     fs, blk, nblk = 10e6, 65536, 8
-    for amp in (1.0, 1.0e-3):
+    # (round 6: stage A of the class runs on the fp16 matrix cores as well -- k_ifr_decim16, the fused front end's two-term
+    # split: 1e-5 puts its low terms into fp16's subnormal range, 1e5 every column tile on the fp32 repair path)
+    for amp in (1.0, 1.0e-3, 1.0e-5, 1.0e5):
         x = (siggen.fm_stereo_iq(nblk * blk, fs) * amp).astype(np.complex64)
         ch = fmr.Chain(mode=fmr.MODE_NONE, input_rate=fs, enable_resampler=True, max_block_len=blk,
                        resampler_class=fmr.RESAMPLER_R8B)

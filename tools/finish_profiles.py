@@ -41,10 +41,14 @@ if _fk and bench["roofline"].get("traffic") is None:
 for extra in (f"{tag}_pytest_gpu.log", f"{tag}_smoke.log", f"{tag}_fused_harness.log", f"{tag}_fe_stamps.txt", f"{tag}_am_agc_rounds.txt",
               f"{tag}_block1_trace.txt", f"{tag}_step_time.txt", f"{tag}_pmc_r8b_stage_b.txt", f"{tag}_step_timeline.txt",
               f"{tag}_step_timeline_r8b.txt", f"{tag}_step_timeline_if_filter.txt", f"{tag}_step_timeline_sigma_1e-2.txt",
-              f"{tag}_mpf_account.txt", f"{tag}_pll_mismatch.txt"):
+              f"{tag}_mpf_account.txt", f"{tag}_pll_mismatch.txt", f"{tag}_step_timeline_am.txt", f"{tag}_kernel_stats_r8b.csv",
+              f"{tag}_kernel_stats_if_filter.csv", f"{tag}_kernel_stats_am.csv"):
     if os.path.exists(g(extra)):
         shutil.copy(g(extra), prof(extra))
-for rep in ("parity_report.json", "parity_report_configs.json"):
+if os.path.exists(g(f"{tag}_pmc_fetch_r8b", "f_counter_collection.csv")):
+    subprocess.check_call([sys.executable, summ, g(f"{tag}_pmc_fetch_r8b", "f_counter_collection.csv"),
+                           g(f"{tag}_pmc_write_r8b", "w_counter_collection.csv"), prof(f"{tag}_pmc_traffic_r8b.json"), blocks])
+for rep in ("parity_report.json", "parity_report_configs.json", "parity_report_levels.json"):
     if os.path.exists(g(rep)):
         shutil.copy(g(rep), prof(f"{tag}_{rep}"))
 others = {}
