@@ -357,7 +357,7 @@ def test_nan_samples_with_the_if_filter_on(pilotcut, fm_medium):
     over the 126 lags behind each such IF sample -- outputs whose support holds none must come out as the reference's
     (Poly4FirDiscEpi::lag0 recomputes the tiles that hold a non-finite value with the plain tap loop), the discriminator
     zeroes the differences that touch one (Utility.h:336-343), the AGC resets.  Against the oracle with the filter on."""
-    blk, nblk, batch = 65536, 120, 40
+    blk, nblk, batch = 65536, 160, 40
     x = siggen.fm_stereo_iq(nblk * blk, 10e6).copy()
     k1 = 85 * blk + 4321
     x[k1:k1 + 3] = np.complex64(complex(np.nan, np.nan))
