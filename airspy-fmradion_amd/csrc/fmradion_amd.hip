@@ -1679,15 +1679,19 @@ int fmr_chain::run_tables(CallCtx &k) {
     hipLaunchKernelGGL(k_copy_ints, dim3((unsigned)((k.fir_grid + 255) / 256)), dim3(256), 0, side,
                        (const int *)t_fb, d_tab_slot + (tab_ints - kMaxFusedWg) + kFirBlk0Off, k.fir_grid);
   }
-  int r8b_grid = 0, r8b_tpw = 0, r8b_tiles = 0;
+  int r8b_grid = 0, r8b_tpw = 0, r8b_rem = 0, r8b_tiles = 0;
   if (k.r8b_tail) {
     // R8B class: contiguous runs of stage-B tiles (64 periods = 3072 IF samples) per workgroup; the table's tail carries the
     // block that holds the first IF sample of every run, as for the fused front end
     const long long P_first = k.r8b_kB_prev / 48, P_last = (k.r8b_kB_prev + N_if - 1) / 48;
     r8b_tiles = (int)((P_last - P_first) / 64 + 1);
-    const int wgs = std::max(1, std::min(kFusedTile0Off - 1, n_cu / S));
-    r8b_tpw = (r8b_tiles + wgs - 1) / wgs;
-    r8b_grid = (r8b_tiles + r8b_tpw - 1) / r8b_tpw;
+    // (pipelined chain: a compute unit per XCD stays free for the kernels beside the front end, as under the fused kernel)
+    const int wgs = std::max(1, std::min(kFusedTile0Off - 1, (pipelined ? std::max(8, n_cu - kFeSpareCus) : n_cu) / S));
+    // balanced runs: r8b_rem of them one tile longer (ceil(tiles / workgroups) for everybody left 16 of 256 compute units idle
+    // at 2^27 samples per call and put seven tiles WITH partial sums on the workgroups that end the launch)
+    r8b_grid = std::min(wgs, r8b_tiles);
+    r8b_tpw = r8b_tiles / r8b_grid;
+    r8b_rem = r8b_tiles - r8b_tpw * r8b_grid;
     fused_n_tiles = 8 * r8b_tiles;                             // in the epilogue's macro tiles of 384 samples
     const long long kb_ref = 48 * P_first - k.r8b_kB_prev;
     fused_kb_ref = (int)kb_ref;
@@ -1702,7 +1706,7 @@ int fmr_chain::run_tables(CallCtx &k) {
     int *t_wg = h_tab + (tab_ints - kMaxFusedWg);
     int b = 0;
     for (int w = 0; w < r8b_grid; w++) {
-      const long long kf = std::max<long long>(0, kb_ref + 3072ll * w * r8b_tpw);
+      const long long kf = std::max<long long>(0, kb_ref + 3072ll * ((long long)w * r8b_tpw + std::min(w, r8b_rem)));
       while (b < nb && (long long)t_if_off[b] + t_if_len[b] <= kf) b++;
       t_wg[w] = b;
     }
@@ -1856,9 +1860,9 @@ int fmr_chain::run_tables(CallCtx &k) {
       hipLaunchKernelGGL((k_ifr_poly5h<48, 125, Poly5hDiscEpi>), dim3(r8b_grid, S), dim3(64 * FMR_POLY5H_WAVES), poly5h_lds, stream,
                          d_mid.p, (long long)(H_mid + max_mid), k.r8b_mA_prev - H_mid, H_mid + k.r8b_count_mid, d_afrag5h.p,
                          poly5h_nkb, poly5h_inv_scale, rs.TB, k.r8b_kB_prev, (int)N_if, (float2 *)nullptr, 0ll, 0, poly2_tile, r8b_tiles,
-                         a, r8b_tpw);
+                         a, r8b_tpw, r8b_rem);
       if (r8b_grid > 1)
-        hipLaunchKernelGGL(k_poly5h_heads, dim3((r8b_grid + 62) / 64, S), dim3(64), 0, stream, a, r8b_grid, r8b_tpw, 0);
+        hipLaunchKernelGGL(k_poly5h_heads, dim3((r8b_grid + 62) / 64, S), dim3(64), 0, stream, a, r8b_grid, r8b_tpw, r8b_rem);
     });
     if (pipelined) {
       // as behind the fused front end: the PLL stage starts from here; input history, stage-B history and the

@@ -880,7 +880,7 @@ __global__ __launch_bounds__(64 * FMR_POLY5H_WAVES) void k_ifr_poly5h(
     const float2 *__restrict__ mid, long long mid_stride, long long mid_abs0, int mid_valid,
     const _Float16 *__restrict__ afrag, int n_kb, float inv_tap_scale, int TB, long long k0, int count,
     float2 *__restrict__ out, long long out_stride, int out_off, int tile_len, int n_tiles,
-    typename EPI::Args ea = typename EPI::Args{}, int tiles_per_wg = 0) {
+    typename EPI::Args ea = typename EPI::Args{}, int tiles_per_wg = 0, int run_rem = 0) {
   static_assert(LB == 48, "three 16-row tiles");
   constexpr int KCH = FMR_POLY5H_KCH, MT = LB / 16, NWV = FMR_POLY5H_WAVES, NT = 64 * NWV, NH = 8 / NWV;
   static_assert(NWV == 4 || NWV == 8, "eight column tiles per tile: two per wave or one");
@@ -905,9 +905,11 @@ __global__ __launch_bounds__(64 * FMR_POLY5H_WAVES) void k_ifr_poly5h(
   float2 *os = out + (long long)s * out_stride + out_off;
   float2 *mystage = stage + wave * (8 * LB);
   const int n_chunks = n_kb / KCH;
-  // the workgroup's tiles: blockIdx.x, + gridDim.x, ... or (EPI) the contiguous run [tile_lo, tile_hi)
-  const int tile_lo = EPI::kOn ? (int)blockIdx.x * tiles_per_wg : (int)blockIdx.x;
-  const int tile_hi = EPI::kOn ? min(tile_lo + tiles_per_wg, n_tiles) : n_tiles;
+  // the workgroup's tiles: blockIdx.x, + gridDim.x, ... or (EPI) the contiguous run [tile_lo, tile_hi): the first run_rem
+  // workgroups take tiles_per_wg + 1 tiles, the others tiles_per_wg -- the longer runs lie at the head of the call, the runs
+  // whose tiles write the per-block partial sums (the last ~400 blocks: 2 us more per tile) at its end
+  const int tile_lo = EPI::kOn ? (int)blockIdx.x * tiles_per_wg + min((int)blockIdx.x, run_rem) : (int)blockIdx.x;
+  const int tile_hi = EPI::kOn ? min(tile_lo + tiles_per_wg + ((int)blockIdx.x < run_rem ? 1 : 0), n_tiles) : n_tiles;
   const int tile_step = EPI::kOn ? 1 : (int)gridDim.x;
   EPI epi;
   if constexpr (EPI::kOn) { static_assert(NWV == 8 && LB == 48, "a wave per 384 staged samples"); if (tile_lo < tile_hi) epi.begin(ea, s, lane); }
