@@ -297,6 +297,7 @@ struct fmr_chain {
       d_dc_G, d_dc_start;
   DevBuf<float> d_agc_nodes, d_agc_G;
   DevBuf<unsigned int> d_agc_tick;      // k_agc_round's last-arrival ticket, one per stream (left at zero by its users)
+  DevBuf<unsigned int> d_af_tick;       // ... and k_af_round's
   DevBuf<double> d_af_nodes, d_af_G, d_af_M, d_af_out;   // AmDecoder audio tail, time-parallel form
   DcCoef am_dk{};
   DevBuf<int> d_ck_wraps, d_blk_wraps, d_walk_go;
@@ -374,7 +375,7 @@ struct fmr_chain {
     d_pc1.release(); d_audio.release(); d_ahA.release(); d_ahB.release(); d_pilotcut.release();
     d_ft_pre.release(); d_ft_post.release(); d_hB_last.release(); d_zero16.release(); d_fe_stamps.release(); d_fused_mid32.release(); d_fused_afragA.release(); d_fused_afragB.release(); d_fused_part.release(); d_afrag.release(); d_afrag_fir_fm.release(); d_dec16_afrag.release(); d_run_ph.release(); d_afrag_fir.release(); d_afrag5h.release(); d_hBp.release(); d_hpA.release(); d_bphi.release(); d_boff.release(); d_tab.release(); d_mpf_ok.release(); d_stereo_blk.release(); d_state.release();
     d_base_de.release(); d_raw_de.release(); d_pll_nodes.release(); d_pll_G.release(); d_pll_M.release();
-    d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_walk_go.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
+    d_pll_wgr.release(); d_pll_pre.release(); d_pll_wfirst.release(); d_pll_sync.release(); d_pll_tick2.release(); d_ck_mask.release(); d_walk_go.release(); d_pll_gres.release(); d_pll_PQ2.release(); d_pll_dstart2.release(); d_pll_PQ.release(); d_pll_dstart.release(); d_blk_level.release(); d_blk_wraps.release(); d_agc_M.release(); d_agc_tick.release(); d_af_tick.release(); d_dc_G.release(); d_dc_start.release(); d_agc_nodes.release();
     d_agc_G.release(); d_ck_wraps.release(); d_flags.release();
     d_af_nodes.release(); d_af_G.release(); d_af_M.release(); d_af_out.release();
     if (h_tab_all) (void)hipHostFree(h_tab_all);
@@ -924,6 +925,7 @@ int fmr_chain::init(const fmr_config *c) {
   if (has_dec) {
     if ((rc = d_agc_nodes.alloc((size_t)S * (max_agc_nc + 1)))) return rc;
     if ((rc = d_agc_tick.alloc((size_t)S))) return rc;
+    if ((rc = d_af_tick.alloc((size_t)S))) return rc;
     if ((rc = d_agc_G.alloc((size_t)S * max_agc_nc))) return rc;
     if ((rc = d_agc_M.alloc((size_t)S * max_agc_nc))) return rc;
   }
@@ -2595,13 +2597,11 @@ int fmr_chain::run_am(CallCtx &k) {
                          (long long)max_if, (int)N_if, am_dk, d_dc_G.p, nc, 0);
       const int dc_nw = std::max(1, std::min(FMR_DC_MAXW, (nc + 64 * FMR_DC_K - 1) / (64 * FMR_DC_K)));
       hipLaunchKernelGGL(k_dc_nodes, dim3(S), dim3(64 * dc_nw), 0, stream, d_dc_G.p, d_dc_start.p, nc, am_dk, d_state.p, S, 0);
-      hipLaunchKernelGGL(k_af_begin, dim3(S), dim3(256), 0, stream, d_flags.p, d_af_nodes.p, nc, d_state.p);
-      for (int it = 0; it < K_AF_ITERS; it++) {
-        hipLaunchKernelGGL(k_af_shoot<C_AM>, dim3((nc + 63) / 64, S), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
+      hipLaunchKernelGGL(k_af_begin, dim3(S), dim3(256), 0, stream, d_flags.p, d_af_nodes.p, nc, d_state.p, d_af_tick.p);
+      for (int it = 0; it < K_AF_ITERS; it++)
+        hipLaunchKernelGGL(k_af_round<C_AM>, dim3((nc + 63) / 64, S), dim3(64), 0, stream, d_base.p, (long long)max_if, (int)N_if,
                            am_dk, d_dc_start.p, af, d_af_nodes.p, d_af_G.p, d_af_M.p, d_af_out.p, (long long)max_if, nc,
-                           d_state.p, d_flags.p);
-        hipLaunchKernelGGL(k_af_nodes, dim3(S), dim3(64), 0, stream, d_af_nodes.p, d_af_G.p, d_af_M.p, nc, d_state.p, d_flags.p);
-      }
+                           d_state.p, d_flags.p, d_af_tick.p);
       const int ncd = (int)((N_if + C_AM_DE - 1) / C_AM_DE);
       hipLaunchKernelGGL(k_am_deemph_out<C_AM_DE>, dim3((ncd + 63) / 64, S), dim3(64), 0, stream, d_af_out.p, (long long)max_if,
                          (int)N_if, am_deemph.b0, am_deemph.a1, (int)(mode == FMR_MODE_AM), d_aud, (long long)astride,

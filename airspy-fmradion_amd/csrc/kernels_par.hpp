@@ -650,14 +650,21 @@ __global__ void k_if_agc_fallback(const XT *__restrict__ x, long long x_stride, 
 #define FMR_AM_DE_WARM 160
 struct AfAgcCoef { double init, maxg, ref, rate; };
 
+__device__ __forceinline__ void af_node_pass(int s, double *__restrict__ nodes, const double *G, const double *M, int nc,
+                                             StreamState *st, IterFlags *fl);
+// One Newton round in one launch (round 6; k_af_shoot + k_af_nodes before: twelve launches of ~9 us for the six rounds of a
+// call): the integration pass, a chunk per lane, one wave per workgroup; the workgroup of a stream that finishes last runs
+// the node pass (last-arrival ticket, as k_agc_round).
 template <int C>
-__global__ void k_af_shoot(const double *__restrict__ demod, long long d_stride, int n, DcCoef k,
-                           const double *__restrict__ dc_start, AfAgcCoef af, const double *__restrict__ nodes,
-                           double *__restrict__ G, double *__restrict__ M, double *__restrict__ agc_out, long long o_stride,
-                           int nc, StreamState *st, const IterFlags *__restrict__ fl) {
+__global__ __launch_bounds__(64) void k_af_round(const double *__restrict__ demod, long long d_stride, int n, DcCoef k,
+                           const double *__restrict__ dc_start, AfAgcCoef af, double *__restrict__ nodes,
+                           double *G, double *M, double *__restrict__ agc_out, long long o_stride,
+                           int nc, StreamState *st, IterFlags *fl, unsigned int *__restrict__ ticket) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
-  if (c >= nc || fl[s].af_converged) return;
+  // (stable for the whole launch: the node pass that sets it runs after every workgroup of the stream has passed here)
+  if (fl[s].af_converged) return;
+  if (c < nc) {
   const double *x = demod + (long long)s * d_stride;
   double *o = agc_out + (long long)s * o_stride;
   const int i0 = c * C, i1 = min(i0 + C, n);
@@ -677,18 +684,30 @@ __global__ void k_af_shoot(const double *__restrict__ demod, long long d_stride,
     if (!isfinite(g)) { g = af.init; dg = 0.0; }
     else if (g > af.maxg) { g = af.maxg; dg = 0.0; }
   });
-  G[(long long)s * nc + c] = g;
-  M[(long long)s * nc + c] = dg;
+  __hip_atomic_store((long long *)&G[(long long)s * nc + c], __double_as_longlong(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((long long *)&M[(long long)s * nc + c], __double_as_longlong(dg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (c == nc - 1) { st[s].am_dc_x1_next = x1; st[s].am_dc_x2_next = x2; }   // DC-block state after the call (exact: linear pass)
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this wave's stores are acknowledged by the L2
+  int last = 0;
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(&ticket[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (t == gridDim.x - 1);
+    if (last) __hip_atomic_store(&ticket[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  af_node_pass(s, nodes, G, M, nc, st, fl);
 }
 
 // node pass of the AF AGC: v[c+1] = G[c] + M[c] (v[c] - old[c]); one wave per stream, K chunk maps per lane.
-__global__ __launch_bounds__(64) void k_af_nodes(double *__restrict__ nodes, const double *__restrict__ G,
-                                                 const double *__restrict__ M, int nc, StreamState *st, IterFlags *fl) {
-  const int s = blockIdx.x, lane = threadIdx.x;
-  if (fl[s].af_converged) return;
+// (G and M are read with agent-scope loads: in k_af_round they were stored by other workgroups of the same launch)
+__device__ __forceinline__ void af_node_pass(int s, double *__restrict__ nodes, const double *G, const double *M, int nc,
+                                             StreamState *st, IterFlags *fl) {
+  const int lane = threadIdx.x;
   double *nd = nodes + (long long)s * (nc + 1);
   const double *g = G + (long long)s * nc, *m = M + (long long)s * nc;
+  auto ld = [](const double *p) { return __longlong_as_double(__hip_atomic_load((const long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
   constexpr int K = 8;
   double carry = nd[0], maxrel = 0.0;
   for (int c0 = 0; c0 < nc; c0 += 64 * K) {
@@ -697,7 +716,7 @@ __global__ __launch_bounds__(64) void k_af_nodes(double *__restrict__ nodes, con
 #pragma unroll
     for (int j = 0; j < K; j++) {
       const int c = cb + j;
-      if (c < nc) { a[j] = m[c]; b[j] = g[c] - a[j] * nd[c]; oldn[j] = nd[c + 1]; }
+      if (c < nc) { a[j] = ld(m + c); b[j] = ld(g + c) - a[j] * nd[c]; oldn[j] = nd[c + 1]; }
       else { a[j] = 1.0; b[j] = 0.0; oldn[j] = 0.0; }
     }
     double ca = 1.0, cbv = 0.0;
@@ -734,9 +753,9 @@ __global__ __launch_bounds__(64) void k_af_nodes(double *__restrict__ nodes, con
   }
 }
 
-__global__ void k_af_begin(IterFlags *fl, double *__restrict__ nodes, int nc, const StreamState *st) {
+__global__ void k_af_begin(IterFlags *fl, double *__restrict__ nodes, int nc, const StreamState *st, unsigned int *__restrict__ ticket) {
   const int s = blockIdx.x;
-  if (threadIdx.x == 0) { fl[s].af_converged = 0; fl[s].af_iters = 0; fl[s].af_fallback = 0; fl[s].af_resid = 0.0; }
+  if (threadIdx.x == 0) { fl[s].af_converged = 0; fl[s].af_iters = 0; fl[s].af_fallback = 0; fl[s].af_resid = 0.0; ticket[s] = 0u; }
   const double g0 = st[s].af_gain;
   for (int c = threadIdx.x; c <= nc; c += blockDim.x) nodes[(long long)s * (nc + 1) + c] = g0;
 }
