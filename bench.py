@@ -692,7 +692,7 @@ def main():
         run_other_configs(1)
 
 
-def r8b_leg(fmr, iq, audio, n, blk, B, device, steps=10, warmup=3, spinup_ms=60.0):
+def r8b_leg(fmr, iq, audio, n, blk, B, device, steps=40, warmup=3, spinup_ms=60.0):
     """The same workload through the REFERENCE-EQUIVALENT resampler class (r8b::CDSPResampler24's default specification:
     0.98 x Nyquist, stop band from Nyquist, 180 dB -- IfResampler.cpp:25-29), timed in a second, short region of the same
     process and put into the headline line as `r8b`: the headline's FAST class is this project's own filter design, this is
