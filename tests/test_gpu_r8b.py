@@ -209,3 +209,45 @@ def test_r8b_discriminator_epilogue_against_the_separate_kernel(pipeline, monkey
         assert np.max(np.abs(lv_a[..., c] - lv_b[..., c]) / np.maximum(np.abs(lv_b[..., c]), 1e-12)) < tol, c
     assert np.max(np.abs(lv_a[..., 1] - lv_b[..., 1])) < 1e-6
     assert np.max(np.abs(lv_a[..., 3] - lv_b[..., 3])) < 1e-6
+
+
+def test_r8b_debug_taps_behind_the_discriminator_epilogue(monkeypatch, pilotcut):
+    """FMR_DEBUG_TAPS=1 on the R8B class: stage B's discriminator epilogue then stores the IF samples (and the float copy of
+    its output) as well, and the IF AGC reads them instead of |x|^2.  fmr_debug_read(0) of a call against the r8brain-class
+    resampler of the oracle (2e-6), tap 1 against the discriminator of the oracle's decoder fed those samples (1e-6 of the
+    MPX's scale), and the audio against the same chain without the taps (the AGC's state solve sees (g x)^2 + (g y)^2
+    instead of g^2 (x^2 + y^2): far below 1e-6)."""
+    fs, blk, nb = 10e6, 65536, 20
+    x = siggen.fm_stereo_iq(3 * nb * blk, fs)
+
+    def run(taps):
+        if taps:
+            monkeypatch.setenv("FMR_DEBUG_TAPS", "1")
+        else:
+            monkeypatch.delenv("FMR_DEBUG_TAPS", raising=False)
+        ch = fmr.Chain(mode=fmr.MODE_FM, input_rate=fs, enable_resampler=True, stereo=True, max_block_len=blk, max_blocks=nb,
+                       resampler_class=fmr.RESAMPLER_R8B)
+        out, ifs, mpx = [], None, None
+        for i in range(3):
+            a, _ = ch.process_blocks(x[None, i * nb * blk:(i + 1) * nb * blk], [blk] * nb)
+            out.append(a[0])
+        if taps:
+            ifs, mpx = ch.debug_read(0), ch.debug_read(1)
+        ch.close()
+        return np.concatenate(out), ifs, mpx
+
+    a_taps, ifs, mpx = run(True)
+    a_plain, _, _ = run(False)
+    r = ora.IfResampler(fs, 384e3, 180.0, 0.98, True)
+    ref_if = [r.process(b) for b in siggen.blocks(x, blk)]
+    last = np.concatenate(ref_if[2 * nb:])
+    assert len(ifs) == len(last) and len(mpx) == len(last)
+    assert rms(ifs - last) / rms(last) < 2e-6
+    # the discriminator of the oracle on the oracle's IF samples of the last call (phase of the sample before it: the call before)
+    prev = np.concatenate(ref_if[:2 * nb])[-1]
+    ph = np.angle(np.concatenate([[prev], last]).astype(np.complex128))
+    d = np.diff(ph)
+    d = (d + np.pi) % (2 * np.pi) - np.pi
+    ref_mpx = d / (2 * np.pi * 75000.0 / 384000.0)
+    assert rms(mpx - ref_mpx) < 1e-5 * max(1.0, rms(ref_mpx)), rms(mpx - ref_mpx)
+    assert rms(a_taps - a_plain) < 1e-6
